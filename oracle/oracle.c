@@ -1,0 +1,454 @@
+/*
+ * CPU ORACLE -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load liboracle.so.  Nothing under battlezips-halo2_amd/ links or calls it.
+ *
+ * Plain-C restatement (4 x 64-bit limbs, unsigned __int128) of the arithmetic
+ * the reference reaches through halo2_proofs::plonk::create_proof
+ * (benches/shot.rs:68, benches/board.rs:61-68, src/circuits/shot.rs:921-928,
+ * src/circuits/board.rs:913-920).  That arithmetic lives in crates that are
+ * NOT under /root/reference:
+ *   halo2_proofs 0.2.0  (Cargo.lock:382-385): arithmetic::best_multiexp,
+ *        arithmetic::best_fft, EvaluationDomain, eval_polynomial
+ *   pasta_curves 0.4.1  (Cargo.lock:567-570): Fp/Fq Montgomery (R = 2^256),
+ *        Pallas/Vesta Jacobian arithmetic
+ * Their published algorithms are restated below; see oracle/pasta.py for the
+ * big-int twin and tests/test_oracle_golden.py for how both are pinned to the
+ * reference's known-answer data (fixed-base GENERATOR / U / Z tables,
+ * src/utils/constants/fixed_bases/board_commit_{v,r}.rs).
+ *
+ * Conventions: field elements cross this API as 4 x u64 little-endian limbs in
+ * CANONICAL (non-Montgomery) form, i.e. ff::PrimeField::to_repr
+ * (src/utils/binary.rs:36).  Affine points are x||y (64 bytes); (0,0) is the
+ * identity (never on y^2 = x^3 + b, b != 0).
+ */
+#include <math.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef unsigned __int128 u128;
+typedef struct { uint64_t l[4]; } fe;
+
+typedef struct {
+    fe p;        /* modulus */
+    fe r;        /* R mod p (Montgomery one) */
+    fe r2;       /* R^2 mod p */
+    uint64_t inv; /* -p^-1 mod 2^64 */
+} field_t;
+
+/* field ids: 0 Fp (Pallas base / Vesta scalar), 1 Fq, 2 BN254 Fr, 3 BN254 Fq
+ * (the Fp literal is src/chips/bitify.rs:461) */
+static const uint64_t MODULI[4][4] = {
+    {0x992d30ed00000001ULL, 0x224698fc094cf91bULL, 0x0000000000000000ULL, 0x4000000000000000ULL},
+    {0x8c46eb2100000001ULL, 0x224698fc0994a8ddULL, 0x0000000000000000ULL, 0x4000000000000000ULL},
+    {0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL},
+    {0x3c208c16d87cfd47ULL, 0x97816a916871ca8dULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL},
+};
+static field_t FIELDS[4];
+static int g_init = 0;
+
+static inline int fe_geq(const fe *a, const fe *b) {
+    for (int i = 3; i >= 0; i--) {
+        if (a->l[i] > b->l[i]) return 1;
+        if (a->l[i] < b->l[i]) return 0;
+    }
+    return 1;
+}
+static inline uint64_t fe_add_raw(fe *o, const fe *a, const fe *b) {
+    u128 c = 0;
+    for (int i = 0; i < 4; i++) { c += (u128)a->l[i] + b->l[i]; o->l[i] = (uint64_t)c; c >>= 64; }
+    return (uint64_t)c;
+}
+static inline uint64_t fe_sub_raw(fe *o, const fe *a, const fe *b) {
+    uint64_t borrow = 0;
+    for (int i = 0; i < 4; i++) {
+        u128 t = (u128)a->l[i] - b->l[i] - borrow;
+        o->l[i] = (uint64_t)t; borrow = (uint64_t)(t >> 64) & 1;
+    }
+    return borrow;
+}
+static inline void f_add(const field_t *F, fe *o, const fe *a, const fe *b) {
+    fe t; uint64_t c = fe_add_raw(&t, a, b);
+    if (c || fe_geq(&t, &F->p)) fe_sub_raw(&t, &t, &F->p);
+    *o = t;
+}
+static inline void f_sub(const field_t *F, fe *o, const fe *a, const fe *b) {
+    fe t; if (fe_sub_raw(&t, a, b)) fe_add_raw(&t, &t, &F->p);
+    *o = t;
+}
+static inline int f_is_zero(const fe *a) { return (a->l[0] | a->l[1] | a->l[2] | a->l[3]) == 0; }
+static inline int f_eq(const fe *a, const fe *b) { return memcmp(a, b, sizeof(fe)) == 0; }
+static inline void f_neg(const field_t *F, fe *o, const fe *a) {
+    if (f_is_zero(a)) { *o = *a; return; }
+    fe_sub_raw(o, &F->p, a);
+}
+/* CIOS Montgomery product a*b*R^-1 mod p */
+static inline void f_mul(const field_t *F, fe *o, const fe *a, const fe *b) {
+    uint64_t t[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 4; i++) {
+        u128 c = 0;
+        for (int j = 0; j < 4; j++) { c += (u128)a->l[j] * b->l[i] + t[j]; t[j] = (uint64_t)c; c >>= 64; }
+        c += t[4]; t[4] = (uint64_t)c; t[5] = (uint64_t)(c >> 64);
+        uint64_t m = t[0] * F->inv;
+        c = (u128)m * F->p.l[0] + t[0]; c >>= 64;
+        for (int j = 1; j < 4; j++) { c += (u128)m * F->p.l[j] + t[j]; t[j - 1] = (uint64_t)c; c >>= 64; }
+        c += t[4]; t[3] = (uint64_t)c; t[4] = t[5] + (uint64_t)(c >> 64);
+    }
+    fe r = {{t[0], t[1], t[2], t[3]}};
+    if (t[4] || fe_geq(&r, &F->p)) fe_sub_raw(&r, &r, &F->p);
+    *o = r;
+}
+static inline void f_sqr(const field_t *F, fe *o, const fe *a) { f_mul(F, o, a, a); }
+static void f_pow(const field_t *F, fe *o, const fe *a, const fe *e) {
+    fe acc = F->r;
+    for (int i = 255; i >= 0; i--) {
+        f_sqr(F, &acc, &acc);
+        if ((e->l[i / 64] >> (i % 64)) & 1) f_mul(F, &acc, &acc, a);
+    }
+    *o = acc;
+}
+static void f_inv(const field_t *F, fe *o, const fe *a) {
+    fe e = F->p, two = {{2, 0, 0, 0}};
+    fe_sub_raw(&e, &e, &two);
+    f_pow(F, o, a, &e);
+}
+static inline void f_to_mont(const field_t *F, fe *o, const fe *a) { f_mul(F, o, a, &F->r2); }
+static inline void f_from_mont(const field_t *F, fe *o, const fe *a) {
+    fe one = {{1, 0, 0, 0}}; f_mul(F, o, a, &one);
+}
+
+static void init_fields(void) {
+    if (g_init) return;
+    for (int f = 0; f < 4; f++) {
+        field_t *F = &FIELDS[f];
+        memcpy(F->p.l, MODULI[f], 32);
+        uint64_t inv = 1;
+        for (int i = 0; i < 63; i++) { inv *= inv; inv *= F->p.l[0]; }
+        F->inv = (uint64_t)0 - inv;
+        /* R = 2^256 mod p by 256 modular doublings of 1; R2 by 256 more */
+        fe x = {{1, 0, 0, 0}};
+        for (int i = 0; i < 512; i++) {
+            fe t; uint64_t c = fe_add_raw(&t, &x, &x);
+            if (c || fe_geq(&t, &F->p)) fe_sub_raw(&t, &t, &F->p);
+            x = t;
+            if (i == 255) F->r = x;
+        }
+        F->r2 = x;
+    }
+    g_init = 1;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Curves y^2 = x^3 + b (a = 0): Jacobian, all special cases handled          */
+/* curve ids: 0 Vesta (base Fq, scalar Fp), 1 Pallas (base Fp, scalar Fq),   */
+/*            2 BN254 G1 (base field 3, scalar field 2)                      */
+/* ------------------------------------------------------------------------ */
+typedef struct { fe x, y, z; } jac;   /* z == 0 <=> identity */
+typedef struct { fe x, y; } aff;      /* (0,0) <=> identity */
+static const int CURVE_BASE[3] = {1, 0, 3};
+static const int CURVE_SCALAR[3] = {0, 1, 2};
+
+static inline int aff_is_id(const aff *a) { return f_is_zero(&a->x) && f_is_zero(&a->y); }
+static inline void jac_set_id(jac *o) { memset(o, 0, sizeof(*o)); }
+
+static void jac_double(const field_t *F, jac *o, const jac *p) {
+    if (f_is_zero(&p->z)) { *o = *p; return; }
+    /* dbl-2009-l (a = 0) */
+    fe A, B, C, D, E, Fq_, t, x3, y3, z3;
+    f_sqr(F, &A, &p->x); f_sqr(F, &B, &p->y); f_sqr(F, &C, &B);
+    f_add(F, &t, &p->x, &B); f_sqr(F, &t, &t); f_sub(F, &t, &t, &A); f_sub(F, &t, &t, &C);
+    f_add(F, &D, &t, &t);
+    f_add(F, &E, &A, &A); f_add(F, &E, &E, &A);
+    f_sqr(F, &Fq_, &E);
+    f_sub(F, &x3, &Fq_, &D); f_sub(F, &x3, &x3, &D);
+    f_sub(F, &t, &D, &x3); f_mul(F, &t, &E, &t);
+    fe c8; f_add(F, &c8, &C, &C); f_add(F, &c8, &c8, &c8); f_add(F, &c8, &c8, &c8);
+    f_sub(F, &y3, &t, &c8);
+    f_mul(F, &z3, &p->y, &p->z); f_add(F, &z3, &z3, &z3);
+    o->x = x3; o->y = y3; o->z = z3;
+}
+static void jac_add(const field_t *F, jac *o, const jac *p, const jac *q) {
+    if (f_is_zero(&p->z)) { *o = *q; return; }
+    if (f_is_zero(&q->z)) { *o = *p; return; }
+    fe z1z1, z2z2, u1, u2, s1, s2, h, r, t, hh, hhh, v;
+    f_sqr(F, &z1z1, &p->z); f_sqr(F, &z2z2, &q->z);
+    f_mul(F, &u1, &p->x, &z2z2); f_mul(F, &u2, &q->x, &z1z1);
+    f_mul(F, &s1, &p->y, &q->z); f_mul(F, &s1, &s1, &z2z2);
+    f_mul(F, &s2, &q->y, &p->z); f_mul(F, &s2, &s2, &z1z1);
+    if (f_eq(&u1, &u2)) {
+        if (f_eq(&s1, &s2)) { jac_double(F, o, p); return; }
+        jac_set_id(o); return;
+    }
+    f_sub(F, &h, &u2, &u1); f_sub(F, &r, &s2, &s1);
+    f_sqr(F, &hh, &h); f_mul(F, &hhh, &hh, &h); f_mul(F, &v, &u1, &hh);
+    jac res;
+    f_sqr(F, &res.x, &r); f_sub(F, &res.x, &res.x, &hhh); f_sub(F, &res.x, &res.x, &v); f_sub(F, &res.x, &res.x, &v);
+    f_sub(F, &t, &v, &res.x); f_mul(F, &t, &r, &t); f_mul(F, &s1, &s1, &hhh); f_sub(F, &res.y, &t, &s1);
+    f_mul(F, &res.z, &p->z, &q->z); f_mul(F, &res.z, &res.z, &h);
+    *o = res;
+}
+static void jac_add_affine(const field_t *F, jac *o, const jac *p, const aff *q) {
+    if (aff_is_id(q)) { *o = *p; return; }
+    if (f_is_zero(&p->z)) { o->x = q->x; o->y = q->y; o->z = F->r; return; }
+    jac qq; qq.x = q->x; qq.y = q->y; qq.z = F->r;
+    jac_add(F, o, p, &qq);
+}
+static void jac_to_affine(const field_t *F, aff *o, const jac *p) {
+    if (f_is_zero(&p->z)) { memset(o, 0, sizeof(*o)); return; }
+    fe zi, zi2, zi3;
+    f_inv(F, &zi, &p->z); f_sqr(F, &zi2, &zi); f_mul(F, &zi3, &zi2, &zi);
+    f_mul(F, &o->x, &p->x, &zi2); f_mul(F, &o->y, &p->y, &zi3);
+}
+
+/* ------------------------------------------------------------------------ */
+/* multiexp_serial as published for halo2_proofs 0.2.0 arithmetic.rs          */
+/* (UPSTREAM/unvendored): unsigned c-bit segments of to_repr(), c = 1 / 3 /   */
+/* ceil(ln n), (256/c)+1 segments high->low with c doublings in between,      */
+/* 2^c - 1 buckets, "summation by parts" running sum.                         */
+/* ------------------------------------------------------------------------ */
+static inline unsigned get_at(unsigned segment, unsigned c, const uint8_t *bytes) {
+    unsigned skip_bits = segment * c, skip_bytes = skip_bits / 8;
+    if (skip_bytes >= 32) return 0;
+    uint64_t v = 0;
+    for (unsigned i = 0; i < 8 && skip_bytes + i < 32; i++) v |= (uint64_t)bytes[skip_bytes + i] << (8 * i);
+    v >>= skip_bits - skip_bytes * 8;
+    return (unsigned)(v % (1ULL << c));
+}
+static void multiexp_serial(const field_t *F, const fe *coeffs_repr, const aff *bases, size_t n, jac *acc) {
+    unsigned c = n < 4 ? 1 : (n < 32 ? 3 : (unsigned)ceil(log((double)n)));
+    unsigned segments = 256 / c + 1;
+    size_t nb = ((size_t)1 << c) - 1;
+    jac *buckets = (jac *)malloc(nb * sizeof(jac));
+    for (int seg = (int)segments - 1; seg >= 0; seg--) {
+        for (unsigned i = 0; i < c; i++) jac_double(F, acc, acc);
+        memset(buckets, 0, nb * sizeof(jac));
+        for (size_t i = 0; i < n; i++) {
+            unsigned d = get_at((unsigned)seg, c, (const uint8_t *)&coeffs_repr[i]);
+            if (d) jac_add_affine(F, &buckets[d - 1], &buckets[d - 1], &bases[i]);
+        }
+        jac run; jac_set_id(&run);
+        for (size_t b = nb; b-- > 0;) {
+            jac_add(F, &run, &run, &buckets[b]);
+            jac_add(F, acc, acc, &run);
+        }
+    }
+    free(buckets);
+}
+
+typedef struct { const field_t *F; const fe *s; const aff *b; size_t n; jac acc; } msm_job;
+static void *msm_worker(void *arg) {
+    msm_job *j = (msm_job *)arg;
+    jac_set_id(&j->acc);
+    multiexp_serial(j->F, j->s, j->b, j->n, &j->acc);
+    return NULL;
+}
+
+/* best_multiexp: chunk = n / threads, one multiexp_serial per chunk, fold. */
+int orc_msm(int curve_id, const uint64_t *scalars, const uint64_t *points_xy, size_t n, int threads,
+            uint64_t *out_xy) {
+    init_fields();
+    if (curve_id < 0 || curve_id > 2) return -1;
+    const field_t *F = &FIELDS[CURVE_BASE[curve_id]];
+    aff *bases = (aff *)malloc((n ? n : 1) * sizeof(aff));
+    for (size_t i = 0; i < n; i++) {
+        fe x, y; memcpy(&x, points_xy + 8 * i, 32); memcpy(&y, points_xy + 8 * i + 4, 32);
+        f_to_mont(F, &bases[i].x, &x); f_to_mont(F, &bases[i].y, &y);
+    }
+    const fe *s = (const fe *)scalars;
+    jac total; jac_set_id(&total);
+    if (threads < 1) threads = 1;
+    if (n > (size_t)threads && threads > 1) {
+        size_t chunk = n / (size_t)threads;
+        size_t nchunks = (n + chunk - 1) / chunk;
+        msm_job *jobs = (msm_job *)calloc(nchunks, sizeof(msm_job));
+        pthread_t *tids = (pthread_t *)calloc(nchunks, sizeof(pthread_t));
+        for (size_t k = 0; k < nchunks; k++) {
+            size_t lo = k * chunk, hi = lo + chunk > n ? n : lo + chunk;
+            jobs[k].F = F; jobs[k].s = s + lo; jobs[k].b = bases + lo; jobs[k].n = hi - lo;
+            pthread_create(&tids[k], NULL, msm_worker, &jobs[k]);
+        }
+        for (size_t k = 0; k < nchunks; k++) { pthread_join(tids[k], NULL); jac_add(F, &total, &total, &jobs[k].acc); }
+        free(jobs); free(tids);
+    } else {
+        multiexp_serial(F, s, bases, n, &total);
+    }
+    aff r; jac_to_affine(F, &r, &total);
+    fe x, y; f_from_mont(F, &x, &r.x); f_from_mont(F, &y, &r.y);
+    memcpy(out_xy, &x, 32); memcpy(out_xy + 4, &y, 32);
+    free(bases);
+    return 0;
+}
+
+/* sum_i [s_i]G_i by double-and-add: the definition, for small n */
+int orc_msm_naive(int curve_id, const uint64_t *scalars, const uint64_t *points_xy, size_t n, uint64_t *out_xy) {
+    init_fields();
+    if (curve_id < 0 || curve_id > 2) return -1;
+    const field_t *F = &FIELDS[CURVE_BASE[curve_id]];
+    jac total; jac_set_id(&total);
+    for (size_t i = 0; i < n; i++) {
+        fe x, y; memcpy(&x, points_xy + 8 * i, 32); memcpy(&y, points_xy + 8 * i + 4, 32);
+        aff b; f_to_mont(F, &b.x, &x); f_to_mont(F, &b.y, &y);
+        jac acc; jac_set_id(&acc);
+        const uint64_t *s = scalars + 4 * i;
+        for (int bit = 255; bit >= 0; bit--) {
+            jac_double(F, &acc, &acc);
+            if ((s[bit / 64] >> (bit % 64)) & 1) jac_add_affine(F, &acc, &acc, &b);
+        }
+        jac_add(F, &total, &total, &acc);
+    }
+    aff r; jac_to_affine(F, &r, &total);
+    fe x, y; f_from_mont(F, &x, &r.x); f_from_mont(F, &y, &r.y);
+    memcpy(out_xy, &x, 32); memcpy(out_xy + 4, &y, 32);
+    return 0;
+}
+
+/* scalar multiplication of one affine point -> affine (used to build bases) */
+int orc_point_mul(int curve_id, const uint64_t *scalar, const uint64_t *pt_xy, uint64_t *out_xy) {
+    return orc_msm_naive(curve_id, scalar, pt_xy, 1, out_xy);
+}
+
+/* bases walk: out[i] = [i+1]G for i < n, affine canonical (batch-normalised) */
+int orc_point_walk(int curve_id, const uint64_t *g_xy, size_t n, uint64_t *out_xy) {
+    init_fields();
+    if (curve_id < 0 || curve_id > 2) return -1;
+    const field_t *F = &FIELDS[CURVE_BASE[curve_id]];
+    fe x, y; memcpy(&x, g_xy, 32); memcpy(&y, g_xy + 4, 32);
+    aff g; f_to_mont(F, &g.x, &x); f_to_mont(F, &g.y, &y);
+    jac *pts = (jac *)malloc((n ? n : 1) * sizeof(jac));
+    fe *pref = (fe *)malloc((n ? n : 1) * sizeof(fe));
+    jac acc; jac_set_id(&acc);
+    for (size_t i = 0; i < n; i++) { jac_add_affine(F, &acc, &acc, &g); pts[i] = acc; }
+    /* batch inversion of z (none is zero unless order divides i+1: not for n << r) */
+    fe run = F->r;
+    for (size_t i = 0; i < n; i++) { pref[i] = run; if (!f_is_zero(&pts[i].z)) f_mul(F, &run, &run, &pts[i].z); }
+    fe inv; f_inv(F, &inv, &run);
+    for (size_t i = n; i-- > 0;) {
+        uint64_t *o = out_xy + 8 * i;
+        if (f_is_zero(&pts[i].z)) { memset(o, 0, 64); continue; }
+        fe zi, zi2, zi3, ax, ay;
+        f_mul(F, &zi, &inv, &pref[i]); f_mul(F, &inv, &inv, &pts[i].z);
+        f_sqr(F, &zi2, &zi); f_mul(F, &zi3, &zi2, &zi);
+        f_mul(F, &ax, &pts[i].x, &zi2); f_mul(F, &ay, &pts[i].y, &zi3);
+        f_from_mont(F, &ax, &ax); f_from_mont(F, &ay, &ay);
+        memcpy(o, &ax, 32); memcpy(o + 4, &ay, 32);
+    }
+    free(pts); free(pref);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* best_fft as published for halo2_proofs 0.2.0 arithmetic.rs (UPSTREAM):     */
+/* bit-reversal permutation, twiddles w^i (i < n/2), log_n radix-2 DIT        */
+/* passes; natural order in and out, no scaling.                              */
+/* ------------------------------------------------------------------------ */
+typedef struct { const field_t *F; fe *a; const fe *tw; size_t n, half, tstride, lo, hi; } fft_job;
+static void *fft_pass_worker(void *arg) {
+    fft_job *j = (fft_job *)arg;
+    const field_t *F = j->F;
+    for (size_t b = j->lo; b < j->hi; b++) { /* b indexes butterflies 0..n/2 */
+        size_t grp = b / j->half, i = b % j->half;
+        fe *x = &j->a[grp * 2 * j->half + i], *y = x + j->half, t;
+        f_mul(F, &t, y, &j->tw[i * j->tstride]);
+        f_sub(F, y, x, &t); f_add(F, x, x, &t);
+    }
+    return NULL;
+}
+static void fft_mont(const field_t *F, fe *a, const fe *omega_m, unsigned log_n, int threads) {
+    size_t n = (size_t)1 << log_n;
+    for (size_t k = 0; k < n; k++) {
+        size_t rk = 0;
+        for (unsigned b = 0; b < log_n; b++) rk |= ((k >> b) & 1) << (log_n - 1 - b);
+        if (k < rk) { fe t = a[k]; a[k] = a[rk]; a[rk] = t; }
+    }
+    size_t nt = n / 2 ? n / 2 : 1;
+    fe *tw = (fe *)malloc(nt * sizeof(fe));
+    fe w = F->r;
+    for (size_t i = 0; i < n / 2; i++) { tw[i] = w; f_mul(F, &w, &w, omega_m); }
+    if (threads < 1) threads = 1;
+    for (unsigned s = 0; s < log_n; s++) {
+        size_t half = (size_t)1 << s, tstride = n / (2 * half), nb = n / 2;
+        int T = (nb >= 4096 && threads > 1) ? threads : 1;
+        fft_job jobs[64]; pthread_t tids[64];
+        if (T > 64) T = 64;
+        for (int t = 0; t < T; t++) {
+            fft_job jb = {F, a, tw, n, half, tstride, nb * (size_t)t / (size_t)T, nb * (size_t)(t + 1) / (size_t)T};
+            jobs[t] = jb;
+        }
+        if (T == 1) fft_pass_worker(&jobs[0]);
+        else {
+            for (int t = 0; t < T; t++) pthread_create(&tids[t], NULL, fft_pass_worker, &jobs[t]);
+            for (int t = 0; t < T; t++) pthread_join(tids[t], NULL);
+        }
+    }
+    free(tw);
+}
+
+/* data: n canonical elements, transformed in place.  If inverse != 0 the
+ * transform uses omega^-1 and multiplies by n^-1 (EvaluationDomain::ifft).
+ * If coset_shift != NULL, element i is first multiplied by shift^i
+ * (forward; distribute_powers_zeta) or, for the inverse, the result i is
+ * multiplied by shift^-i. */
+int orc_ntt(int field_id, uint64_t *data, unsigned log_n, const uint64_t *omega, int inverse,
+            const uint64_t *coset_shift, int threads) {
+    init_fields();
+    if (field_id < 0 || field_id > 3) return -1;
+    const field_t *F = &FIELDS[field_id];
+    size_t n = (size_t)1 << log_n;
+    fe *a = (fe *)data;
+    fe w; memcpy(&w, omega, 32); f_to_mont(F, &w, &w);
+    for (size_t i = 0; i < n; i++) f_to_mont(F, &a[i], &a[i]);
+    fe shift;
+    if (coset_shift) { memcpy(&shift, coset_shift, 32); f_to_mont(F, &shift, &shift); }
+    if (!inverse) {
+        if (coset_shift) { fe s = F->r; for (size_t i = 0; i < n; i++) { f_mul(F, &a[i], &a[i], &s); f_mul(F, &s, &s, &shift); } }
+        fft_mont(F, a, &w, log_n, threads);
+    } else {
+        fe wi; f_inv(F, &wi, &w);
+        fft_mont(F, a, &wi, log_n, threads);
+        fe nn = {{n, 0, 0, 0}}, ninv; f_to_mont(F, &nn, &nn); f_inv(F, &ninv, &nn);
+        fe si, s = ninv;
+        if (coset_shift) f_inv(F, &si, &shift); else si = F->r;
+        for (size_t i = 0; i < n; i++) { f_mul(F, &a[i], &a[i], &s); if (coset_shift) f_mul(F, &s, &s, &si); }
+    }
+    for (size_t i = 0; i < n; i++) f_from_mont(F, &a[i], &a[i]);
+    return 0;
+}
+
+/* ---- small helpers exposed for cross-checking the Python twin ---- */
+int orc_field_mul(int field_id, const uint64_t *a, const uint64_t *b, uint64_t *out) {
+    init_fields();
+    const field_t *F = &FIELDS[field_id];
+    fe x, y; memcpy(&x, a, 32); memcpy(&y, b, 32);
+    f_to_mont(F, &x, &x); f_to_mont(F, &y, &y); f_mul(F, &x, &x, &y); f_from_mont(F, &x, &x);
+    memcpy(out, &x, 32);
+    return 0;
+}
+int orc_field_inv(int field_id, const uint64_t *a, uint64_t *out) {
+    init_fields();
+    const field_t *F = &FIELDS[field_id];
+    fe x; memcpy(&x, a, 32);
+    f_to_mont(F, &x, &x); f_inv(F, &x, &x); f_from_mont(F, &x, &x);
+    memcpy(out, &x, 32);
+    return 0;
+}
+int orc_field_consts(int field_id, uint64_t *p, uint64_t *r, uint64_t *r2, uint64_t *inv) {
+    init_fields();
+    const field_t *F = &FIELDS[field_id];
+    memcpy(p, &F->p, 32); memcpy(r, &F->r, 32); memcpy(r2, &F->r2, 32); *inv = F->inv;
+    return 0;
+}
+/* Horner: arithmetic::eval_polynomial */
+int orc_eval_poly(int field_id, const uint64_t *coeffs, size_t n, const uint64_t *x, uint64_t *out) {
+    init_fields();
+    const field_t *F = &FIELDS[field_id];
+    fe xm, acc; memcpy(&xm, x, 32); f_to_mont(F, &xm, &xm); memset(&acc, 0, sizeof(acc));
+    for (size_t i = n; i-- > 0;) {
+        fe c; memcpy(&c, coeffs + 4 * i, 32); f_to_mont(F, &c, &c);
+        f_mul(F, &acc, &acc, &xm); f_add(F, &acc, &acc, &c);
+    }
+    f_from_mont(F, &acc, &acc); memcpy(out, &acc, 32);
+    return 0;
+}
