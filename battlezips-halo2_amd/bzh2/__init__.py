@@ -1,0 +1,261 @@
+"""bzh2 -- ctypes host binding over the C ABI of include/bzh2.h (libbzh2.so).
+
+The product path: every call below lands in hand-written HIP kernels for
+gfx950.  There is NO CPU fallback: if libbzh2.so is missing or there is no GPU,
+calls raise.  This module never imports anything from oracle/.
+
+Host-side mirror of the interface the reference reaches for the create_proof hot
+path (halo2_proofs 0.2.0, un-vendored):
+    best_multiexp(coeffs, bases)            -> Context.msm(bases, scalars)
+    Params::commit / commit_lagrange        -> Context.upload_bases + Context.msm
+    best_fft(a, omega, log_n)               -> Context.ntt(...)
+    EvaluationDomain::ifft / coeff_to_extended / extended_to_coeff
+                                            -> Context.ntt(inverse=, coset_shift=)
+Names, argument meaning and error behaviour follow the upstream functions: a
+length mismatch between scalars and bases is an error (upstream asserts), field
+elements are 4 x u64 little-endian limbs.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(os.path.dirname(_PKG), "libbzh2.so")
+
+OK, E_ARG, E_OOM, E_HIP, E_RANGE, E_NOGPU = 0, -1, -2, -3, -4, -5
+CURVE_VESTA, CURVE_PALLAS, CURVE_BN254 = 0, 1, 2
+FIELD_FP, FIELD_FQ, FIELD_BN254_FR, FIELD_BN254_FQ = 0, 1, 2, 3
+FORM_CANONICAL, FORM_MONTGOMERY = 0, 1
+MEM_HOST, MEM_DEVICE = 0, 1
+T_MSM_DIGITS, T_MSM_ACCUMULATE, T_MSM_REDUCE, T_MSM_FINALIZE, T_NTT, T_COUNT = 0, 1, 2, 3, 4, 8
+TIMER_NAMES = {0: "msm_digits", 1: "msm_accumulate", 2: "msm_reduce", 3: "msm_finalize", 4: "ntt"}
+
+# scalar field of each curve (Vesta scalars are Fp, Pallas scalars are Fq)
+CURVE_SCALAR_FIELD = {CURVE_VESTA: FIELD_FP, CURVE_PALLAS: FIELD_FQ, CURVE_BN254: FIELD_BN254_FR}
+
+# every symbol include/bzh2.h declares
+EXPORTS = [
+    "bzh_version", "bzh_strerror", "bzh_device_count", "bzh_ctx_create", "bzh_ctx_create_on_stream",
+    "bzh_ctx_destroy", "bzh_ctx_sync", "bzh_last_error", "bzh_ctx_profile", "bzh_ctx_timings",
+    "bzh_bases_upload", "bzh_bases_free", "bzh_bases_len", "bzh_msm", "bzh_ntt",
+    "bzh_jacobian_to_affine", "bzh_affine_compress", "bzh_field_omega",
+]
+
+
+class BzhError(RuntimeError):
+    def __init__(self, status: int, where: str, detail: str = ""):
+        self.status = status
+        super().__init__("%s failed: %s (%d)%s" % (where, _strerror(status), status, (": " + detail) if detail else ""))
+
+
+_lib = None
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def load():
+    """Load libbzh2.so or raise -- the product path has no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise ImportError("libbzh2.so not built at %s: run `python -c 'import __graft_entry__ as g; g.build()'`" % _LIB_PATH)
+    L = ctypes.CDLL(_LIB_PATH)
+    u64p = ctypes.POINTER(ctypes.c_uint64)
+    vp = ctypes.c_void_p
+    L.bzh_version.restype = ctypes.c_char_p
+    L.bzh_strerror.restype = ctypes.c_char_p
+    L.bzh_strerror.argtypes = [ctypes.c_int]
+    L.bzh_device_count.restype = ctypes.c_int
+    L.bzh_ctx_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
+    L.bzh_ctx_create_on_stream.argtypes = [ctypes.c_int, vp, ctypes.POINTER(vp)]
+    L.bzh_ctx_destroy.argtypes = [vp]
+    L.bzh_ctx_sync.argtypes = [vp]
+    L.bzh_last_error.argtypes = [vp]
+    L.bzh_last_error.restype = ctypes.c_char_p
+    L.bzh_ctx_profile.argtypes = [vp, ctypes.c_int]
+    L.bzh_ctx_timings.argtypes = [vp, ctypes.POINTER(ctypes.c_double), u64p]
+    L.bzh_bases_upload.argtypes = [vp, ctypes.c_int, vp, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.POINTER(vp)]
+    L.bzh_bases_free.argtypes = [vp, vp]
+    L.bzh_bases_len.argtypes = [vp]
+    L.bzh_bases_len.restype = ctypes.c_size_t
+    L.bzh_msm.argtypes = [vp, vp, vp, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, vp]
+    L.bzh_ntt.argtypes = [vp, ctypes.c_int, vp, ctypes.c_uint, ctypes.c_size_t, u64p, u64p, ctypes.c_int, ctypes.c_int,
+                          ctypes.c_int]
+    L.bzh_jacobian_to_affine.argtypes = [ctypes.c_int, u64p, ctypes.c_size_t, ctypes.c_int, u64p]
+    L.bzh_affine_compress.argtypes = [ctypes.c_int, u64p, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(ctypes.c_uint8)]
+    L.bzh_field_omega.argtypes = [ctypes.c_int, ctypes.c_uint, ctypes.c_int, u64p]
+    _lib = L
+    return L
+
+
+def _strerror(status: int) -> str:
+    try:
+        return load().bzh_strerror(status).decode()
+    except Exception:  # pragma: no cover
+        return "status %d" % status
+
+
+def device_count() -> int:
+    return load().bzh_device_count()
+
+
+def _u64(a: np.ndarray):
+    assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"], "need contiguous uint64"
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))
+
+
+def int_to_limbs(x: int) -> np.ndarray:
+    return np.frombuffer(int(x).to_bytes(32, "little"), dtype=np.uint64).copy()
+
+
+def limbs_to_int(a) -> int:
+    return int.from_bytes(np.ascontiguousarray(a, dtype=np.uint64).tobytes(), "little")
+
+
+class Bases:
+    """Device-resident commitment bases (halo2 Params.g / g_lagrange)."""
+
+    def __init__(self, ctx: "Context", handle, curve: int, n: int):
+        self.ctx, self.handle, self.curve, self.n = ctx, handle, curve, n
+
+    def free(self):
+        if self.handle is not None:
+            load().bzh_bases_free(self.ctx.handle, self.handle)
+            self.handle = None
+
+    def __len__(self):
+        return self.n
+
+
+class Context:
+    """One device + one HIP stream (bzh_ctx)."""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        L = load()
+        h = ctypes.c_void_p()
+        if stream is None:
+            rc = L.bzh_ctx_create(device, ctypes.byref(h))
+        else:
+            rc = L.bzh_ctx_create_on_stream(device, ctypes.c_void_p(stream), ctypes.byref(h))
+        if rc != OK:
+            raise BzhError(rc, "bzh_ctx_create")
+        self.handle = h
+        self.device = device
+
+    def _check(self, rc: int, where: str):
+        if rc != OK:
+            raise BzhError(rc, where, load().bzh_last_error(self.handle).decode())
+
+    def close(self):
+        if self.handle is not None:
+            load().bzh_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def sync(self):
+        self._check(load().bzh_ctx_sync(self.handle), "bzh_ctx_sync")
+
+    def profile(self, enable: bool = True):
+        self._check(load().bzh_ctx_profile(self.handle, int(enable)), "bzh_ctx_profile")
+
+    def timings(self) -> dict:
+        ms = (ctypes.c_double * T_COUNT)()
+        n = (ctypes.c_uint64 * T_COUNT)()
+        self._check(load().bzh_ctx_timings(self.handle, ms, n), "bzh_ctx_timings")
+        return {TIMER_NAMES[i]: {"ms": ms[i], "launches": int(n[i])} for i in TIMER_NAMES}
+
+    # ---- bases ----
+    def upload_bases(self, curve: int, xy, n: int | None = None, form: int = FORM_CANONICAL, device_ptr: bool = False) -> Bases:
+        h = ctypes.c_void_p()
+        if device_ptr:
+            ptr, mem = ctypes.c_void_p(int(xy)), MEM_DEVICE
+            assert n is not None
+        else:
+            xy = np.ascontiguousarray(xy, dtype=np.uint64)
+            n = xy.size // 8 if n is None else n
+            ptr, mem = ctypes.c_void_p(xy.ctypes.data), MEM_HOST
+        self._check(load().bzh_bases_upload(self.handle, curve, ptr, n, form, mem, ctypes.byref(h)), "bzh_bases_upload")
+        return Bases(self, h, curve, n)
+
+    # ---- MSM ----
+    def msm(self, bases: Bases, scalars: np.ndarray, form: int = FORM_CANONICAL) -> np.ndarray:
+        """best_multiexp for `batch` scalar vectors: scalars (batch, n, 4) or (n, 4) uint64 -> (batch, 12) Jacobian."""
+        s = np.ascontiguousarray(scalars, dtype=np.uint64)
+        if s.ndim == 2:
+            s = s.reshape(1, *s.shape)
+        batch, n = s.shape[0], s.shape[1]
+        assert s.shape[2] == 4
+        out = np.zeros((batch, 12), dtype=np.uint64)
+        rc = load().bzh_msm(self.handle, bases.handle, ctypes.c_void_p(s.ctypes.data), n, batch, form, MEM_HOST,
+                            ctypes.c_void_p(out.ctypes.data))
+        self._check(rc, "bzh_msm")
+        return out
+
+    def msm_device(self, bases: Bases, scalars_ptr: int, n: int, batch: int, out_ptr: int, form: int = FORM_MONTGOMERY):
+        """Device-pointer form: enqueues on the ctx stream, no copies, no sync."""
+        rc = load().bzh_msm(self.handle, bases.handle, ctypes.c_void_p(scalars_ptr), n, batch, form, MEM_DEVICE,
+                            ctypes.c_void_p(out_ptr))
+        self._check(rc, "bzh_msm")
+
+    # ---- NTT ----
+    def ntt(self, field: int, data: np.ndarray, omega: int | None = None, inverse: bool = False,
+            coset_shift: int | None = None, form: int = FORM_CANONICAL) -> np.ndarray:
+        """best_fft over (batch, n, 4) or (n, 4) uint64; returns a new array."""
+        a = np.ascontiguousarray(data, dtype=np.uint64).copy()
+        shape = a.shape
+        if a.ndim == 2:
+            a = a.reshape(1, *a.shape)
+        batch, n = a.shape[0], a.shape[1]
+        log_n = n.bit_length() - 1
+        if n == 0 or (1 << log_n) != n:
+            raise BzhError(E_ARG, "bzh_ntt", "length must be a power of two")
+        w = field_omega(field, log_n, form) if omega is None else int_to_limbs(omega)
+        cs = None if coset_shift is None else int_to_limbs(coset_shift)
+        rc = load().bzh_ntt(self.handle, field, ctypes.c_void_p(a.ctypes.data), log_n, batch, _u64(w),
+                            _u64(cs) if cs is not None else None, int(inverse), form, MEM_HOST)
+        self._check(rc, "bzh_ntt")
+        return a.reshape(shape)
+
+    def ntt_device(self, field: int, data_ptr: int, log_n: int, batch: int, omega: np.ndarray,
+                   coset_shift: np.ndarray | None = None, inverse: bool = False, form: int = FORM_MONTGOMERY):
+        rc = load().bzh_ntt(self.handle, field, ctypes.c_void_p(data_ptr), log_n, batch, _u64(omega),
+                            _u64(coset_shift) if coset_shift is not None else None, int(inverse), form, MEM_DEVICE)
+        self._check(rc, "bzh_ntt")
+
+
+# ---- host helpers -----------------------------------------------------------
+def jacobian_to_affine(curve: int, xyz: np.ndarray, form: int = FORM_CANONICAL) -> np.ndarray:
+    a = np.ascontiguousarray(xyz, dtype=np.uint64).reshape(-1, 12)
+    out = np.zeros((a.shape[0], 8), dtype=np.uint64)
+    rc = load().bzh_jacobian_to_affine(curve, _u64(a), a.shape[0], form, _u64(out))
+    if rc != OK:
+        raise BzhError(rc, "bzh_jacobian_to_affine")
+    return out
+
+
+def affine_compress(curve: int, xy: np.ndarray, form: int = FORM_CANONICAL) -> list:
+    a = np.ascontiguousarray(xy, dtype=np.uint64).reshape(-1, 8)
+    out = np.zeros((a.shape[0], 32), dtype=np.uint8)
+    rc = load().bzh_affine_compress(curve, _u64(a), a.shape[0], form, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)))
+    if rc != OK:
+        raise BzhError(rc, "bzh_affine_compress")
+    return [bytes(r) for r in out]
+
+
+def field_omega(field: int, log_n: int, form: int = FORM_CANONICAL) -> np.ndarray:
+    out = np.zeros(4, dtype=np.uint64)
+    rc = load().bzh_field_omega(field, log_n, form, _u64(out))
+    if rc != OK:
+        raise BzhError(rc, "bzh_field_omega")
+    return out

@@ -1,0 +1,350 @@
+// C ABI entry points (include/bzh2.h): context, base tables, host<->device
+// staging around the MSM / NTT drivers, and the host-side helpers.
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "ctx.hpp"
+#include "curve.cuh"
+
+namespace bzh {
+void ntt_cache_drop(bzh_ctx* ctx);
+}
+
+using namespace bzh;
+
+static bool valid_curve(int c) { return c >= 0 && c <= 2; }
+static bool valid_field(int f) { return f >= 0 && f <= 3; }
+static bool valid_form(int f) { return f == BZH_FORM_CANONICAL || f == BZH_FORM_MONTGOMERY; }
+static bool valid_mem(int m) { return m == BZH_MEM_HOST || m == BZH_MEM_DEVICE; }
+static unsigned field_two_adicity(int f) { return f == BZH_FIELD_BN254_FR ? 28u : (f == BZH_FIELD_BN254_FQ ? 1u : 32u); }
+
+// ---- host helpers (CPU build of the same field templates) ------------------
+namespace {
+template <class P>
+static Fe<P> load_host(const uint64_t* p, int form) {
+    Fe<P> v;
+    for (int i = 0; i < 4; i++) {
+        v.l[2 * i] = (uint32_t)p[i];
+        v.l[2 * i + 1] = (uint32_t)(p[i] >> 32);
+    }
+    return form == BZH_FORM_CANONICAL ? fe_to_mont(v) : v;
+}
+template <class P>
+static void store_host(uint64_t* p, Fe<P> v, int form) {
+    if (form == BZH_FORM_CANONICAL) v = fe_from_mont(v);
+    for (int i = 0; i < 4; i++) p[i] = (uint64_t)v.l[2 * i] | ((uint64_t)v.l[2 * i + 1] << 32);
+}
+
+template <class P>
+static void jac_to_aff_host(const uint64_t* xyz, size_t n, int form, uint64_t* out) {
+    // batch inversion of Z (Montgomery's trick), identity -> (0,0)
+    std::vector<Fe<P>> z(n), pref(n);
+    Fe<P> run = fe_one<P>();
+    for (size_t i = 0; i < n; i++) {
+        z[i] = load_host<P>(xyz + 12 * i + 8, form);
+        pref[i] = run;
+        if (!fe_is_zero(z[i])) run = fe_mul(run, z[i]);
+    }
+    Fe<P> inv = fe_inv(run);
+    for (size_t i = n; i-- > 0;) {
+        if (fe_is_zero(z[i])) {
+            memset(out + 8 * i, 0, 64);
+            continue;
+        }
+        Fe<P> zi = fe_mul(inv, pref[i]);
+        inv = fe_mul(inv, z[i]);
+        Fe<P> zi2 = fe_sqr(zi), zi3 = fe_mul(zi2, zi);
+        store_host<P>(out + 8 * i, fe_mul(load_host<P>(xyz + 12 * i, form), zi2), form);
+        store_host<P>(out + 8 * i + 4, fe_mul(load_host<P>(xyz + 12 * i + 4, form), zi3), form);
+    }
+}
+
+template <class P>
+static void compress_host(const uint64_t* xy, size_t n, int form, uint8_t* out) {
+    for (size_t i = 0; i < n; i++) {
+        uint64_t x[4], y[4];
+        store_host<P>(x, load_host<P>(xy + 8 * i, form), BZH_FORM_CANONICAL);
+        store_host<P>(y, load_host<P>(xy + 8 * i + 4, form), BZH_FORM_CANONICAL);
+        memcpy(out + 32 * i, x, 32);
+        out[32 * i + 31] |= (uint8_t)((y[0] & 1) << 7);
+    }
+}
+
+template <class P>
+static void omega_host(unsigned S, uint32_t gen, unsigned log_n, int form, uint64_t* out) {
+    // ROOT_OF_UNITY = gen^((p-1) >> S); omega = ROOT^(2^(S - log_n))
+    uint32_t e[8];
+    uint64_t br = 1;
+    for (int i = 0; i < 8; i++) {
+        uint64_t d = (uint64_t)P::mod(i) - br;
+        e[i] = (uint32_t)d;
+        br = (d >> 63) & 1;
+    }
+    uint32_t sh[8];
+    for (int i = 0; i < 8; i++) {
+        uint64_t lo = (S < 32) ? ((uint64_t)e[i] >> S) : 0;
+        unsigned src = i + S / 32;
+        uint64_t v = 0;
+        if (S % 32 == 0) {
+            v = src < 8 ? e[src] : 0;
+        } else {
+            uint64_t a = src < 8 ? e[src] : 0, b = src + 1 < 8 ? e[src + 1] : 0;
+            v = ((a | (b << 32)) >> (S % 32)) & 0xffffffffu;
+        }
+        (void)lo;
+        sh[i] = (uint32_t)v;
+    }
+    Fe<P> g = fe_from_u32<P>(gen);
+    Fe<P> root = fe_pow(g, sh);
+    for (unsigned i = log_n; i < S; i++) root = fe_sqr(root);
+    store_host<P>(out, root, form);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* bzh_version(void) { return "bzh2 0.1 (gfx950)"; }
+
+const char* bzh_strerror(int status) {
+    switch (status) {
+        case BZH_OK: return "ok";
+        case BZH_E_ARG: return "invalid argument";
+        case BZH_E_OOM: return "out of memory";
+        case BZH_E_HIP: return "HIP runtime error";
+        case BZH_E_RANGE: return "value out of range";
+        case BZH_E_NOGPU: return "no usable GPU";
+    }
+    return "unknown status";
+}
+
+int bzh_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+static int ctx_create_common(int device, void* stream, bool own, bzh_ctx** out) {
+    if (!out) return BZH_E_ARG;
+    *out = nullptr;
+    int n = bzh_device_count();
+    if (n <= 0) return BZH_E_NOGPU;
+    if (device < 0 || device >= n) return BZH_E_ARG;
+    bzh_ctx* ctx = new (std::nothrow) bzh_ctx();
+    if (!ctx) return BZH_E_OOM;
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess) {
+        delete ctx;
+        return BZH_E_HIP;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cu = prop.multiProcessorCount;
+    if (own) {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete ctx;
+            return BZH_E_HIP;
+        }
+        ctx->own_stream = true;
+    } else {
+        ctx->stream = (hipStream_t)stream;
+    }
+    *out = ctx;
+    return BZH_OK;
+}
+
+int bzh_ctx_create(int device, bzh_ctx** out) { return ctx_create_common(device, nullptr, true, out); }
+int bzh_ctx_create_on_stream(int device, void* hip_stream, bzh_ctx** out) {
+    return ctx_create_common(device, hip_stream, false, out);
+}
+
+int bzh_ctx_destroy(bzh_ctx* ctx) {
+    if (!ctx) return BZH_E_ARG;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    ntt_cache_drop(ctx);
+    for (int i = 0; i < 4; i++)
+        if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
+    for (auto& s : ctx->spans) {
+        (void)hipEventDestroy(s.a);
+        (void)hipEventDestroy(s.b);
+    }
+    for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return BZH_OK;
+}
+
+int bzh_ctx_sync(bzh_ctx* ctx) {
+    if (!ctx) return BZH_E_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    BZH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return BZH_OK;
+}
+
+const char* bzh_last_error(const bzh_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+static int drain_spans(bzh_ctx* ctx) {
+    BZH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto& s : ctx->spans) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+            ctx->acc_ms[s.cls] += ms;
+            ctx->acc_n[s.cls] += 1;
+        }
+        ctx->event_pool.push_back(s.a);
+        ctx->event_pool.push_back(s.b);
+    }
+    ctx->spans.clear();
+    return BZH_OK;
+}
+
+int bzh_ctx_profile(bzh_ctx* ctx, int enable) {
+    if (!ctx) return BZH_E_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    int rc = drain_spans(ctx);
+    if (rc) return rc;
+    for (int i = 0; i < BZH_T_COUNT; i++) {
+        ctx->acc_ms[i] = 0;
+        ctx->acc_n[i] = 0;
+    }
+    ctx->profiling = enable != 0;
+    return BZH_OK;
+}
+
+int bzh_ctx_timings(bzh_ctx* ctx, double* ms, uint64_t* launches) {
+    if (!ctx || !ms || !launches) return BZH_E_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    int rc = drain_spans(ctx);
+    if (rc) return rc;
+    for (int i = 0; i < BZH_T_COUNT; i++) {
+        ms[i] = ctx->acc_ms[i];
+        launches[i] = ctx->acc_n[i];
+    }
+    return BZH_OK;
+}
+
+int bzh_bases_upload(bzh_ctx* ctx, int curve, const uint64_t* xy, size_t n, int form, int mem, bzh_bases** out) {
+    if (!ctx || !out || (!xy && n) || !valid_curve(curve) || !valid_form(form) || !valid_mem(mem)) return BZH_E_ARG;
+    *out = nullptr;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    BZH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    bzh_bases* b = new (std::nothrow) bzh_bases();
+    if (!b) return BZH_E_OOM;
+    b->curve = curve;
+    b->n = n;
+    b->device = ctx->device;
+    hipError_t e = hipMalloc((void**)&b->d_xy, (n ? n : 1) * 64);
+    if (e != hipSuccess) {
+        delete b;
+        ctx->last_error = std::string("hipMalloc(bases): ") + hipGetErrorString(e);
+        return BZH_E_OOM;
+    }
+    e = hipMemcpyAsync(b->d_xy, xy, n * 64, mem == BZH_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice,
+                       ctx->stream);
+    int rc = BZH_OK;
+    if (e != hipSuccess) {
+        ctx->last_error = std::string("hipMemcpyAsync(bases): ") + hipGetErrorString(e);
+        rc = BZH_E_HIP;
+    }
+    if (!rc && form == BZH_FORM_CANONICAL) rc = bases_to_montgomery(ctx, curve, b->d_xy, n);
+    if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = BZH_E_HIP;
+    if (rc) {
+        (void)hipFree(b->d_xy);
+        delete b;
+        return rc;
+    }
+    *out = b;
+    return BZH_OK;
+}
+
+int bzh_bases_free(bzh_ctx* ctx, bzh_bases* bases) {
+    if (!ctx || !bases) return BZH_E_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(bases->d_xy);
+    delete bases;
+    return BZH_OK;
+}
+
+size_t bzh_bases_len(const bzh_bases* bases) { return bases ? bases->n : 0; }
+
+int bzh_msm(bzh_ctx* ctx, const bzh_bases* bases, const uint64_t* scalars, size_t n, size_t batch, int form, int mem,
+            uint64_t* out_xyz) {
+    if (!ctx || !bases || !out_xyz || (!scalars && n && batch) || !valid_form(form) || !valid_mem(mem)) return BZH_E_ARG;
+    if (n > bases->n) return BZH_E_ARG;  // halo2: assert_eq!(coeffs.len(), bases.len())
+    if (bases->device != ctx->device) return BZH_E_ARG;
+    if (batch == 0) return BZH_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    BZH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (mem == BZH_MEM_DEVICE) return msm_run(ctx, bases, (const uint32_t*)scalars, n, batch, form, (uint32_t*)out_xyz);
+    void* stage = nullptr;
+    const size_t sbytes = batch * n * 32, obytes = batch * 96;
+    int rc = ws_ensure(ctx, 3, sbytes + obytes + 64, &stage);
+    if (rc) return rc;
+    uint32_t* d_s = (uint32_t*)stage;
+    uint32_t* d_o = (uint32_t*)((char*)stage + ((sbytes + 63) & ~(size_t)63));
+    if (sbytes) BZH_HIP_TRY(ctx, hipMemcpyAsync(d_s, scalars, sbytes, hipMemcpyHostToDevice, ctx->stream));
+    rc = msm_run(ctx, bases, d_s, n, batch, form, d_o);
+    if (rc) return rc;
+    BZH_HIP_TRY(ctx, hipMemcpyAsync(out_xyz, d_o, obytes, hipMemcpyDeviceToHost, ctx->stream));
+    BZH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return BZH_OK;
+}
+
+int bzh_ntt(bzh_ctx* ctx, int field, uint64_t* data, unsigned log_n, size_t batch, const uint64_t* omega,
+            const uint64_t* coset_shift, int inverse, int form, int mem) {
+    if (!ctx || !data || !omega || !valid_field(field) || !valid_form(form) || !valid_mem(mem)) return BZH_E_ARG;
+    if (log_n > field_two_adicity(field) || log_n > 30) return BZH_E_RANGE;
+    if (batch == 0) return BZH_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    BZH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (mem == BZH_MEM_DEVICE) return ntt_run(ctx, field, (uint32_t*)data, log_n, batch, omega, coset_shift, inverse, form);
+    void* stage = nullptr;
+    const size_t bytes = (batch << log_n) * 32;
+    int rc = ws_ensure(ctx, 3, bytes, &stage);
+    if (rc) return rc;
+    BZH_HIP_TRY(ctx, hipMemcpyAsync(stage, data, bytes, hipMemcpyHostToDevice, ctx->stream));
+    rc = ntt_run(ctx, field, (uint32_t*)stage, log_n, batch, omega, coset_shift, inverse, form);
+    if (rc) return rc;
+    BZH_HIP_TRY(ctx, hipMemcpyAsync(data, stage, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    BZH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return BZH_OK;
+}
+
+int bzh_jacobian_to_affine(int curve, const uint64_t* xyz, size_t n, int form, uint64_t* out_xy) {
+    if ((!xyz || !out_xy) && n) return BZH_E_ARG;
+    if (!valid_curve(curve) || !valid_form(form)) return BZH_E_ARG;
+    switch (curve) {
+        case BZH_CURVE_VESTA: jac_to_aff_host<FqParams>(xyz, n, form, out_xy); break;
+        case BZH_CURVE_PALLAS: jac_to_aff_host<FpParams>(xyz, n, form, out_xy); break;
+        case BZH_CURVE_BN254: jac_to_aff_host<BnFqParams>(xyz, n, form, out_xy); break;
+    }
+    return BZH_OK;
+}
+
+int bzh_affine_compress(int curve, const uint64_t* xy, size_t n, int form, uint8_t* out32) {
+    if ((!xy || !out32) && n) return BZH_E_ARG;
+    if (!valid_curve(curve) || !valid_form(form)) return BZH_E_ARG;
+    switch (curve) {
+        case BZH_CURVE_VESTA: compress_host<FqParams>(xy, n, form, out32); break;
+        case BZH_CURVE_PALLAS: compress_host<FpParams>(xy, n, form, out32); break;
+        case BZH_CURVE_BN254: compress_host<BnFqParams>(xy, n, form, out32); break;
+    }
+    return BZH_OK;
+}
+
+int bzh_field_omega(int field, unsigned log_n, int form, uint64_t* out) {
+    if (!out || !valid_field(field) || !valid_form(form)) return BZH_E_ARG;
+    if (log_n > field_two_adicity(field)) return BZH_E_RANGE;
+    switch (field) {
+        case BZH_FIELD_FP: omega_host<FpParams>(32, 5, log_n, form, out); break;
+        case BZH_FIELD_FQ: omega_host<FqParams>(32, 5, log_n, form, out); break;
+        case BZH_FIELD_BN254_FR: omega_host<BnFrParams>(28, 7, log_n, form, out); break;
+        case BZH_FIELD_BN254_FQ: omega_host<BnFqParams>(1, 3, log_n, form, out); break;
+    }
+    return BZH_OK;
+}
+
+
+}  // extern "C"

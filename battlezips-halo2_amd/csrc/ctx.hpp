@@ -1,0 +1,102 @@
+// Context, workspace and timing plumbing behind the C ABI (include/bzh2.h).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/bzh2.h"
+
+struct bzh_bases {
+    int curve = 0;
+    size_t n = 0;
+    uint32_t* d_xy = nullptr;  // n x 16 u32: affine x||y, Montgomery form
+    int device = 0;
+};
+
+struct bzh_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::mutex mu;
+    std::string last_error;
+    // grow-only device workspaces (calls on a ctx are serialised and stream-ordered)
+    void* ws[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t ws_bytes[4] = {0, 0, 0, 0};
+    // profiling
+    bool profiling = false;
+    struct Span {
+        int cls;
+        hipEvent_t a, b;
+    };
+    std::vector<Span> spans;
+    std::vector<hipEvent_t> event_pool;
+    double acc_ms[BZH_T_COUNT] = {0};
+    uint64_t acc_n[BZH_T_COUNT] = {0};
+    int num_cu = 256;
+};
+
+#define BZH_HIP_TRY(ctx, expr)                                                                    \
+    do {                                                                                          \
+        hipError_t e__ = (expr);                                                                  \
+        if (e__ != hipSuccess) {                                                                  \
+            (ctx)->last_error = std::string(#expr) + ": " + hipGetErrorString(e__);               \
+            return (e__ == hipErrorOutOfMemory) ? BZH_E_OOM : BZH_E_HIP;                          \
+        }                                                                                         \
+    } while (0)
+
+namespace bzh {
+
+// grow-only workspace slot
+inline int ws_ensure(bzh_ctx* ctx, int slot, size_t bytes, void** out) {
+    if (ctx->ws_bytes[slot] < bytes) {
+        if (ctx->ws[slot]) {
+            BZH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            BZH_HIP_TRY(ctx, hipFree(ctx->ws[slot]));
+            ctx->ws[slot] = nullptr;
+            ctx->ws_bytes[slot] = 0;
+        }
+        size_t want = bytes + (bytes >> 3);
+        BZH_HIP_TRY(ctx, hipMalloc(&ctx->ws[slot], want));
+        ctx->ws_bytes[slot] = want;
+    }
+    *out = ctx->ws[slot];
+    return BZH_OK;
+}
+
+struct ScopedTimer {
+    bzh_ctx* ctx;
+    int cls;
+    hipEvent_t a = nullptr, b = nullptr;
+    ScopedTimer(bzh_ctx* c, int k) : ctx(c), cls(k) {
+        if (!ctx->profiling) return;
+        a = take();
+        b = take();
+        if (a && b) (void)hipEventRecord(a, ctx->stream);
+    }
+    ~ScopedTimer() {
+        if (!ctx->profiling || !a || !b) return;
+        (void)hipEventRecord(b, ctx->stream);
+        ctx->spans.push_back({cls, a, b});
+    }
+    hipEvent_t take() {
+        if (!ctx->event_pool.empty()) {
+            hipEvent_t e = ctx->event_pool.back();
+            ctx->event_pool.pop_back();
+            return e;
+        }
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        return e;
+    }
+};
+
+// implemented in msm.hip / ntt.hip
+int msm_run(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_scalars, size_t n, size_t batch, int form,
+            uint32_t* d_out_xyz);
+int ntt_run(bzh_ctx* ctx, int field, uint32_t* d_data, unsigned log_n, size_t batch, const uint64_t* omega,
+            const uint64_t* coset_shift, int inverse, int form);
+int bases_to_montgomery(bzh_ctx* ctx, int curve, uint32_t* d_xy, size_t n);
+
+}  // namespace bzh

@@ -1,0 +1,200 @@
+// Short-Weierstrass a = 0 curves (Vesta, Pallas, BN254 G1) in XYZZ coordinates
+// (x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2; identity <=> ZZ = 0).  XYZZ keeps the
+// bucket accumulator's mixed addition at 8M + 2S, the cheapest complete-enough
+// form for Pippenger's inner loop.
+//
+// Device counterpart of pasta_curves 0.4.1 group arithmetic (UPSTREAM,
+// un-vendored; Cargo.lock:567-570) as used by halo2_proofs::arithmetic::
+// best_multiexp; reference call sites: benches/shot.rs:68 (create_proof),
+// src/utils/pedersen.rs:27 (v*m + r*t).
+#pragma once
+#include "field.cuh"
+
+namespace bzh {
+
+struct VestaCurve {  // y^2 = x^3 + 5 over Fq, order p ; commitments of the IPA prover
+    using Base = FqParams;
+    static constexpr int id = 0;
+    static constexpr uint32_t b = 5;
+};
+struct PallasCurve {  // y^2 = x^3 + 5 over Fp, order q ; Pedersen commitment (src/utils/pedersen.rs)
+    using Base = FpParams;
+    static constexpr int id = 1;
+    static constexpr uint32_t b = 5;
+};
+struct Bn254Curve {  // y^2 = x^3 + 3 (config 5 microbench only; no reference)
+    using Base = BnFqParams;
+    static constexpr int id = 2;
+    static constexpr uint32_t b = 3;
+};
+
+template <class P>
+struct Affine {  // (0,0) <=> identity
+    Fe<P> x, y;
+};
+template <class P>
+struct Xyzz {
+    Fe<P> x, y, zz, zzz;
+};
+
+template <class P>
+BZH_HD bool aff_is_id(const Affine<P>& a) {
+    return fe_is_zero(a.x) && fe_is_zero(a.y);
+}
+template <class P>
+BZH_HD Xyzz<P> xyzz_identity() {
+    Xyzz<P> r;
+    r.x = fe_zero<P>();
+    r.y = fe_zero<P>();
+    r.zz = fe_zero<P>();
+    r.zzz = fe_zero<P>();
+    return r;
+}
+template <class P>
+BZH_HD bool xyzz_is_id(const Xyzz<P>& p) {
+    return fe_is_zero(p.zz);
+}
+template <class P>
+BZH_HD Xyzz<P> xyzz_from_affine(const Affine<P>& a) {
+    Xyzz<P> r;
+    if (aff_is_id(a)) return xyzz_identity<P>();
+    r.x = a.x;
+    r.y = a.y;
+    r.zz = fe_one<P>();
+    r.zzz = fe_one<P>();
+    return r;
+}
+
+// dbl-2008-s-1 (a = 0): 6M + 3S... written as 7M + 2S with shared products
+template <class P>
+BZH_HD Xyzz<P> xyzz_dbl(const Xyzz<P>& p) {
+    if (xyzz_is_id(p)) return p;
+    Fe<P> u = fe_dbl(p.y);
+    Fe<P> v = fe_sqr(u);
+    Fe<P> w = fe_mul(u, v);
+    Fe<P> s = fe_mul(p.x, v);
+    Fe<P> xx = fe_sqr(p.x);
+    Fe<P> m = fe_add(fe_dbl(xx), xx);
+    Xyzz<P> r;
+    r.x = fe_sub(fe_sqr(m), fe_dbl(s));
+    r.y = fe_sub(fe_mul(m, fe_sub(s, r.x)), fe_mul(w, p.y));
+    r.zz = fe_mul(v, p.zz);
+    r.zzz = fe_mul(w, p.zzz);
+    return r;
+}
+// doubling of an affine point into XYZZ (mdbl-2008-s-1)
+template <class P>
+BZH_HD Xyzz<P> xyzz_dbl_affine(const Affine<P>& a) {
+    Fe<P> u = fe_dbl(a.y);
+    Fe<P> v = fe_sqr(u);
+    Fe<P> w = fe_mul(u, v);
+    Fe<P> s = fe_mul(a.x, v);
+    Fe<P> xx = fe_sqr(a.x);
+    Fe<P> m = fe_add(fe_dbl(xx), xx);
+    Xyzz<P> r;
+    r.x = fe_sub(fe_sqr(m), fe_dbl(s));
+    r.y = fe_sub(fe_mul(m, fe_sub(s, r.x)), fe_mul(w, a.y));
+    r.zz = v;
+    r.zzz = w;
+    return r;
+}
+
+// acc += (qx, qy) affine, not the identity.  madd-2008-s: 8M + 2S.
+// Handles acc == identity, acc == q (doubling) and acc == -q (identity).
+template <class P>
+BZH_HD void xyzz_madd(Xyzz<P>& acc, const Affine<P>& q) {
+    if (xyzz_is_id(acc)) {
+        acc.x = q.x;
+        acc.y = q.y;
+        acc.zz = fe_one<P>();
+        acc.zzz = fe_one<P>();
+        return;
+    }
+    Fe<P> u2 = fe_mul(q.x, acc.zz);
+    Fe<P> s2 = fe_mul(q.y, acc.zzz);
+    Fe<P> pp_ = fe_sub(u2, acc.x);
+    Fe<P> r = fe_sub(s2, acc.y);
+    if (fe_is_zero(pp_)) {
+        if (fe_is_zero(r)) {
+            acc = xyzz_dbl_affine(q);
+        } else {
+            acc = xyzz_identity<P>();
+        }
+        return;
+    }
+    Fe<P> pp = fe_sqr(pp_);
+    Fe<P> ppp = fe_mul(pp_, pp);
+    Fe<P> qq = fe_mul(acc.x, pp);
+    Fe<P> x3 = fe_sub(fe_sub(fe_sqr(r), ppp), fe_dbl(qq));
+    Fe<P> y3 = fe_sub(fe_mul(r, fe_sub(qq, x3)), fe_mul(acc.y, ppp));
+    acc.x = x3;
+    acc.y = y3;
+    acc.zz = fe_mul(acc.zz, pp);
+    acc.zzz = fe_mul(acc.zzz, ppp);
+}
+
+// acc += q (both XYZZ).  add-2008-s: 12M + 2S, all special cases handled.
+template <class P>
+BZH_HD void xyzz_add(Xyzz<P>& acc, const Xyzz<P>& q) {
+    if (xyzz_is_id(q)) return;
+    if (xyzz_is_id(acc)) {
+        acc = q;
+        return;
+    }
+    Fe<P> u1 = fe_mul(acc.x, q.zz);
+    Fe<P> u2 = fe_mul(q.x, acc.zz);
+    Fe<P> s1 = fe_mul(acc.y, q.zzz);
+    Fe<P> s2 = fe_mul(q.y, acc.zzz);
+    Fe<P> pp_ = fe_sub(u2, u1);
+    Fe<P> r = fe_sub(s2, s1);
+    if (fe_is_zero(pp_)) {
+        if (fe_is_zero(r)) {
+            acc = xyzz_dbl(acc);
+        } else {
+            acc = xyzz_identity<P>();
+        }
+        return;
+    }
+    Fe<P> pp = fe_sqr(pp_);
+    Fe<P> ppp = fe_mul(pp_, pp);
+    Fe<P> qq = fe_mul(u1, pp);
+    Fe<P> x3 = fe_sub(fe_sub(fe_sqr(r), ppp), fe_dbl(qq));
+    Fe<P> y3 = fe_sub(fe_mul(r, fe_sub(qq, x3)), fe_mul(s1, ppp));
+    acc.x = x3;
+    acc.y = y3;
+    acc.zz = fe_mul(fe_mul(acc.zz, q.zz), pp);
+    acc.zzz = fe_mul(fe_mul(acc.zzz, q.zzz), ppp);
+}
+
+// XYZZ -> Jacobian (X:Y:Z) with x = X/Z^2, y = Y/Z^3: Z = ZZZ/ZZ would need an
+// inversion; instead scale: X' = X*ZZ... use (X*ZZZ^2... ) -- simplest exact
+// map without inversion: Z = ZZZ * ZZ^-1 is avoided by X' = X * ZZ, Y' = Y * ZZZ,
+// Z' = ZZ  since x = X/ZZ = X*ZZ/ZZ^2 and y = Y/ZZZ = Y*ZZZ/ZZZ^2 = Y*ZZZ/ZZ^3.
+template <class P>
+BZH_HD void xyzz_to_jacobian(const Xyzz<P>& p, Fe<P>& X, Fe<P>& Y, Fe<P>& Z) {
+    if (xyzz_is_id(p)) {
+        X = fe_zero<P>();
+        Y = fe_zero<P>();
+        Z = fe_zero<P>();
+        return;
+    }
+    X = fe_mul(p.x, p.zz);
+    Y = fe_mul(p.y, p.zzz);
+    Z = p.zz;
+}
+template <class P>
+BZH_HD Affine<P> xyzz_to_affine(const Xyzz<P>& p) {
+    Affine<P> r;
+    if (xyzz_is_id(p)) {
+        r.x = fe_zero<P>();
+        r.y = fe_zero<P>();
+        return r;
+    }
+    // 1/ZZZ, then 1/ZZ = ZZZ^-2 * ZZ^2 ... cheaper: i = (ZZ*ZZZ)^-1; 1/ZZ = i*ZZZ; 1/ZZZ = i*ZZ
+    Fe<P> i = fe_inv(fe_mul(p.zz, p.zzz));
+    r.x = fe_mul(p.x, fe_mul(i, p.zzz));
+    r.y = fe_mul(p.y, fe_mul(i, p.zz));
+    return r;
+}
+
+}  // namespace bzh

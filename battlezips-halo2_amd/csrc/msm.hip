@@ -1,0 +1,461 @@
+// Multi-scalar multiplication on gfx950: signed-digit Pippenger with the
+// per-(vector, chunk, window) counting sort and bucket lists staged in LDS.
+//
+// Replaces halo2_proofs 0.2.0 `arithmetic::best_multiexp` / `Params::commit*`
+// (UPSTREAM, un-vendored: Cargo.lock:382-385) on the create_proof path entered at
+// benches/shot.rs:68, benches/board.rs:61-68, src/circuits/shot.rs:921-928,
+// src/circuits/board.rs:913-920.  ~28 full-size MSMs per proof, all against the
+// same SRS bases, hence the batched entry point.
+//
+// Pipeline (all on the ctx's stream):
+//   k_msm_digits      scalars -> signed c-bit digits, u16 [vector][window][point]
+//   k_msm_accumulate  one workgroup per (chunk, window, vector): LDS histogram ->
+//                     LDS scan -> LDS scatter (bucket-sorted point list, u16) ->
+//                     thread-per-bucket XYZZ mixed additions, points gathered
+//                     from the HBM/L2-resident base table (64 B per point)
+//   k_msm_reduce      per segment: sum_m m*B_m via sliced running sums, an LDS
+//                     suffix scan and LDS tree sums
+//   k_msm_finalize    per vector: sum chunks per window, Horner over windows
+// Modular-integer work (v_mad_u64_u32), no MFMA.
+#include "ctx.hpp"
+#include "curve.cuh"
+
+namespace bzh {
+
+// ---------------------------------------------------------------------------
+// plan
+// ---------------------------------------------------------------------------
+struct MsmPlan {
+    int c;           // window bits
+    int nwin;        // ceil(256 / c)
+    int M;           // buckets per window = 2^(c-1), magnitudes 1..M
+    size_t chunk;    // points per chunk (<= 32768: u16 local index + sign bit)
+    size_t nchunks;
+    int threads;     // accumulate workgroup size
+};
+
+static constexpr size_t kMaxChunk = 32768;
+
+static MsmPlan plan_msm(size_t n) {
+    MsmPlan p;
+    p.chunk = n < kMaxChunk ? (n ? n : 1) : kMaxChunk;
+    p.nchunks = n ? (n + p.chunk - 1) / p.chunk : 1;
+    // cost model (units: field multiplications per segment): thread-per-bucket
+    // accumulation with Poisson imbalance over a 64-lane wave + 2 full additions
+    // per bucket in the reduction.
+    double best = 1e300;
+    int best_c = 4;
+    for (int c = 3; c <= 15; c++) {
+        int nwin = (256 + c - 1) / c;
+        double M = (double)(1u << (c - 1));
+        double lam = (double)p.chunk / M;
+        double eff = lam / (lam + 2.5 * sqrt(lam) + 1.0);
+        double cost = nwin * ((double)p.chunk * 10.0 / eff + M * 28.0 + 400.0);
+        if (cost < best) {
+            best = cost;
+            best_c = c;
+        }
+    }
+    p.c = best_c;
+    p.nwin = (256 + p.c - 1) / p.c;
+    p.M = 1 << (p.c - 1);
+    int t = p.M < 64 ? 64 : (p.M > 1024 ? 1024 : p.M);
+    p.threads = t;
+    return p;
+}
+
+struct DigitOffset {
+    uint32_t l[8];
+};
+
+// ---------------------------------------------------------------------------
+// k_msm_digits: one thread per scalar.  s' = s + sum_{w < nwin-1} 2^(c-1) 2^(cw);
+// digit_w = ((s' >> cw) & (2^c - 1)) - 2^(c-1) for w < nwin-1 and the top window
+// keeps the unsigned remainder (<= 2^(c-1) because c*nwin >= 256 > bits(s)).
+// u16 encoding: bit 15 = sign, bits 0..14 = magnitude (0 = skip).
+// ---------------------------------------------------------------------------
+template <class SF>
+__global__ void __launch_bounds__(256) k_msm_digits(const uint32_t* __restrict__ scalars, size_t n, size_t total,
+                                                      int form, int c, int nwin, DigitOffset off,
+                                                      uint16_t* __restrict__ digits) {
+    size_t gid = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    size_t b = gid / n, i = gid - b * n;
+    Fe<SF> s = fe_load<SF>(scalars + gid * 8);
+    if (form == BZH_FORM_MONTGOMERY) s = fe_from_mont(s);
+    uint32_t l[8];
+    uint64_t cy = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        cy += (uint64_t)s.l[k] + off.l[k];
+        l[k] = (uint32_t)cy;
+        cy >>= 32;
+    }
+    const uint32_t mask = (1u << c) - 1u, H = 1u << (c - 1);
+    uint16_t* out = digits + (b * (size_t)nwin) * n + i;
+    uint64_t acc = 0;
+    int bits = 0, w = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        acc |= (uint64_t)l[k] << bits;
+        bits += 32;
+        while (bits >= c && w < nwin - 1) {
+            int d = (int)((uint32_t)acc & mask) - (int)H;
+            uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
+            out[(size_t)w * n] = (uint16_t)(mag | (d < 0 ? 0x8000u : 0u));
+            acc >>= c;
+            bits -= c;
+            w++;
+        }
+    }
+    out[(size_t)w * n] = (uint16_t)((uint32_t)acc & 0x7fffu);  // top window, unsigned
+}
+
+// ---------------------------------------------------------------------------
+// LDS / global "plane" layout for XYZZ values: 8 planes of uint4 (x lo, x hi,
+// y lo, y hi, zz lo, zz hi, zzz lo, zzz hi); element t of plane p sits at
+// (p * stride + t) * 16 B, so a wave's access is 64 consecutive 16-byte slots
+// (conflict-free ds_*_b128, fully coalesced global dwordx4).
+// ---------------------------------------------------------------------------
+template <class P>
+__device__ __forceinline__ void planes_put(uint4* buf, size_t stride, size_t t, const Xyzz<P>& v) {
+    const Fe<P>* f[4] = {&v.x, &v.y, &v.zz, &v.zzz};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        buf[(2 * k) * stride + t] = make_uint4(f[k]->l[0], f[k]->l[1], f[k]->l[2], f[k]->l[3]);
+        buf[(2 * k + 1) * stride + t] = make_uint4(f[k]->l[4], f[k]->l[5], f[k]->l[6], f[k]->l[7]);
+    }
+}
+template <class P>
+__device__ __forceinline__ Xyzz<P> planes_get(const uint4* buf, size_t stride, size_t t) {
+    Xyzz<P> v;
+    Fe<P>* f[4] = {&v.x, &v.y, &v.zz, &v.zzz};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint4 a = buf[(2 * k) * stride + t], b = buf[(2 * k + 1) * stride + t];
+        f[k]->l[0] = a.x; f[k]->l[1] = a.y; f[k]->l[2] = a.z; f[k]->l[3] = a.w;
+        f[k]->l[4] = b.x; f[k]->l[5] = b.y; f[k]->l[6] = b.z; f[k]->l[7] = b.w;
+    }
+    return v;
+}
+
+template <class P>
+__device__ __forceinline__ Affine<P> affine_load(const uint32_t* p) {
+    Affine<P> a;
+    a.x = fe_load<P>(p);
+    a.y = fe_load<P>(p + 8);
+    return a;
+}
+
+// exclusive scan of a[0..len) in LDS by the whole workgroup; scratch >= 17 words
+__device__ __forceinline__ void block_exclusive_scan(uint32_t* a, int len, uint32_t* scratch) {
+    const int T = blockDim.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = (T + 63) >> 6;
+    const int per = (len + T - 1) / T;
+    const int lo = tid * per, hi = min(lo + per, len);
+    uint32_t sum = 0;
+    for (int k = lo; k < hi; k++) sum += a[k];
+    uint32_t incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t v = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += v;
+    }
+    if (lane == 63) scratch[wave] = incl;
+    __syncthreads();
+    if (wave == 0) {
+        uint32_t w = lane < nw ? scratch[lane] : 0u, wi = w;
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) {
+            uint32_t v = __shfl_up(wi, d, 64);
+            if (lane >= d) wi += v;
+        }
+        if (lane < nw) scratch[lane] = wi - w;
+    }
+    __syncthreads();
+    uint32_t base = scratch[wave] + incl - sum;
+    for (int k = lo; k < hi; k++) {
+        uint32_t v = a[k];
+        a[k] = base;
+        base += v;
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------
+// k_msm_accumulate: grid (nchunks, nwin, batch).  Dynamic LDS:
+//   cnt[M + 2] u32 | scratch[32] u32 | sorted[chunk] u16
+// ---------------------------------------------------------------------------
+template <class C>
+__global__ void __launch_bounds__(1024) k_msm_accumulate(const uint32_t* __restrict__ bases,
+                                                           const uint16_t* __restrict__ digits, size_t n, int nwin, int M,
+                                                           size_t chunk, uint4* __restrict__ buckets) {
+    using P = typename C::Base;
+    extern __shared__ __align__(16) uint32_t lds[];
+    uint32_t* cnt = lds;  // index m in [0, M]; cnt[0] stays 0
+    uint32_t* scratch = lds + (M + 2);
+    uint16_t* sorted = reinterpret_cast<uint16_t*>(scratch + 32);
+
+    const int tid = threadIdx.x, T = blockDim.x;
+    const size_t ck = blockIdx.x, w = blockIdx.y, b = blockIdx.z, nchunks = gridDim.x;
+    const size_t c0 = ck * chunk;
+    const int len = (int)min(chunk, n - c0);
+    const uint16_t* dg = digits + (b * (size_t)nwin + w) * n + c0;
+
+    for (int i = tid; i < M + 2; i += T) cnt[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < len; i += T) {
+        uint32_t m = dg[i] & 0x7fffu;
+        if (m) atomicAdd(&cnt[m], 1u);
+    }
+    __syncthreads();
+    block_exclusive_scan(cnt, M + 1, scratch);
+    for (int i = tid; i < len; i += T) {
+        uint32_t d = dg[i], m = d & 0x7fffu;
+        if (m) {
+            uint32_t pos = atomicAdd(&cnt[m], 1u);
+            sorted[pos] = (uint16_t)((uint32_t)i | (d & 0x8000u));
+        }
+    }
+    __syncthreads();
+    // now bucket m owns sorted[cnt[m-1] .. cnt[m])
+    uint4* seg = buckets + (((b * (size_t)nwin + w) * nchunks + ck) * (size_t)M) * 8;
+    const uint32_t* base0 = bases + c0 * 16;
+    for (int m = 1 + tid; m <= M; m += T) {
+        Xyzz<P> acc = xyzz_identity<P>();
+        const uint32_t lo = cnt[m - 1], hi = cnt[m];
+        for (uint32_t j = lo; j < hi; j++) {
+            uint32_t e = sorted[j];
+            Affine<P> q = affine_load<P>(base0 + (size_t)(e & 0x7fffu) * 16);
+            if (aff_is_id(q)) continue;
+            if (e & 0x8000u) q.y = fe_neg(q.y);
+            xyzz_madd(acc, q);
+        }
+        planes_put(seg, (size_t)M, (size_t)(m - 1), acc);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_msm_reduce: one workgroup per segment computes sum_{m=1..M} m * B_m.
+// Thread t owns slice (tL, (t+1)L]: S_t = sum B_m, W_t = sum (m - tL) B_m by a
+// downward running sum.  Then total = sum_t W_t + L * sum_{t>=1} Suffix_t with
+// Suffix_t = sum_{u>=t} S_u (Hillis-Steele suffix scan in LDS, tree sums).
+// Dynamic LDS: 2 * T * 128 B.
+// ---------------------------------------------------------------------------
+template <class P>
+__device__ __forceinline__ Xyzz<P> block_tree_sum(Xyzz<P> v, uint4* buf, int T) {
+    const int tid = threadIdx.x;
+    for (int s = T >> 1; s >= 1; s >>= 1) {
+        __syncthreads();
+        if (tid >= s && tid < 2 * s) planes_put(buf, (size_t)T, (size_t)tid, v);
+        __syncthreads();
+        if (tid < s) {
+            Xyzz<P> o = planes_get<P>(buf, (size_t)T, (size_t)(tid + s));
+            xyzz_add(v, o);
+        }
+    }
+    return v;  // valid in thread 0
+}
+
+template <class C>
+__global__ void __launch_bounds__(256) k_msm_reduce(const uint4* __restrict__ buckets, int M, uint4* __restrict__ winsums) {
+    using P = typename C::Base;
+    extern __shared__ __align__(16) uint32_t lds[];
+    uint4* bufA = reinterpret_cast<uint4*>(lds);
+    const int T = blockDim.x, tid = threadIdx.x;
+    uint4* bufB = bufA + (size_t)T * 8;
+    const size_t segi = blockIdx.x;
+    const uint4* seg = buckets + segi * (size_t)M * 8;
+    const int L = M / T;  // host guarantees T <= M, both powers of two
+
+    Xyzz<P> S = xyzz_identity<P>(), W = xyzz_identity<P>();
+    for (int k = L; k >= 1; k--) {
+        Xyzz<P> bkt = planes_get<P>(seg, (size_t)M, (size_t)(tid * L + k - 1));
+        xyzz_add(S, bkt);
+        xyzz_add(W, S);
+    }
+    // suffix scan of S over threads
+    Xyzz<P> suf = S;
+    uint4* cur = bufA;
+    uint4* nxt = bufB;
+    for (int d = 1; d < T; d <<= 1) {
+        planes_put(cur, (size_t)T, (size_t)tid, suf);
+        __syncthreads();
+        if (tid + d < T) {
+            Xyzz<P> o = planes_get<P>(cur, (size_t)T, (size_t)(tid + d));
+            xyzz_add(suf, o);
+        }
+        uint4* tmp = cur;
+        cur = nxt;
+        nxt = tmp;
+    }
+    if (tid == 0) suf = xyzz_identity<P>();  // only t >= 1 contribute t * S_t
+    Xyzz<P> hi = block_tree_sum(suf, bufA, T);
+    Xyzz<P> lo = block_tree_sum(W, bufA, T);
+    if (tid == 0) {
+        for (int k = L; k > 1; k >>= 1) hi = xyzz_dbl(hi);
+        xyzz_add(lo, hi);
+        planes_put(winsums, (size_t)gridDim.x, segi, lo);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_msm_finalize: one wave per vector.  winsums planes are indexed by
+// seg = (b * nwin + w) * nchunks + ck with stride nseg.
+// ---------------------------------------------------------------------------
+template <class C>
+__global__ void __launch_bounds__(64) k_msm_finalize(const uint4* __restrict__ winsums, size_t nseg, int nwin,
+                                                       size_t nchunks, int c, int form, uint32_t* __restrict__ out_xyz) {
+    using P = typename C::Base;
+    __shared__ __align__(16) uint4 buf[64 * 8];
+    __shared__ __align__(16) uint4 wbuf[64 * 8];  // per-window sums, nwin <= 64
+    const int lane = threadIdx.x;
+    const size_t b = blockIdx.x;
+    for (int w = 0; w < nwin; w++) {
+        Xyzz<P> acc = xyzz_identity<P>();
+        for (size_t ck = lane; ck < nchunks; ck += 64) {
+            Xyzz<P> v = planes_get<P>(winsums, nseg, (b * (size_t)nwin + w) * nchunks + ck);
+            xyzz_add(acc, v);
+        }
+        if (nchunks > 1) acc = block_tree_sum(acc, buf, 64);
+        if (lane == 0) planes_put(wbuf, 64, (size_t)w, acc);
+    }
+    __syncthreads();
+    if (lane == 0) {
+        Xyzz<P> acc = xyzz_identity<P>();
+        for (int w = nwin - 1; w >= 0; w--) {
+            for (int k = 0; k < c; k++) acc = xyzz_dbl(acc);
+            Xyzz<P> v = planes_get<P>(wbuf, 64, (size_t)w);
+            xyzz_add(acc, v);
+        }
+        Fe<P> X, Y, Z;
+        xyzz_to_jacobian(acc, X, Y, Z);
+        if (form == BZH_FORM_CANONICAL) {
+            X = fe_from_mont(X);
+            Y = fe_from_mont(Y);
+            Z = fe_from_mont(Z);
+        }
+        uint32_t* o = out_xyz + b * 24;
+        fe_store(o, X);
+        fe_store(o + 8, Y);
+        fe_store(o + 16, Z);
+    }
+}
+
+template <class P>
+__global__ void __launch_bounds__(256) k_to_montgomery(uint32_t* data, size_t count) {
+    size_t gid = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (gid >= count) return;
+    Fe<P> v = fe_load<P>(data + gid * 8);
+    fe_store(data + gid * 8, fe_to_mont(v));
+}
+
+// ---------------------------------------------------------------------------
+// host driver
+// ---------------------------------------------------------------------------
+template <class C, class SF>
+static int msm_run_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_scalars, size_t n, size_t batch, int form,
+                     uint32_t* d_out) {
+    if (n == 0) {
+        BZH_HIP_TRY(ctx, hipMemsetAsync(d_out, 0, batch * 96, ctx->stream));
+        return BZH_OK;
+    }
+    const MsmPlan p = plan_msm(n);
+    // slice the batch so the bucket workspace stays bounded
+    const size_t seg_bytes = (size_t)p.M * 128;
+    const size_t segs_per_vec = (size_t)p.nwin * p.nchunks;
+    const size_t budget = (size_t)2 << 30;
+    size_t slice = budget / (segs_per_vec * seg_bytes);
+    if (slice < 1) slice = 1;
+    if (slice > batch) slice = batch;
+    if (slice > 65535) slice = 65535;  // gridDim.z
+
+    DigitOffset off;
+    for (int k = 0; k < 8; k++) off.l[k] = 0;
+    for (int w = 0; w < p.nwin - 1; w++) {
+        int pos = p.c * w + (p.c - 1);
+        off.l[pos >> 5] |= 1u << (pos & 31);
+    }
+
+    void *d_digits = nullptr, *d_buckets = nullptr, *d_winsums = nullptr;
+    int rc;
+    if ((rc = ws_ensure(ctx, 0, slice * (size_t)p.nwin * n * sizeof(uint16_t), &d_digits))) return rc;
+    if ((rc = ws_ensure(ctx, 1, slice * segs_per_vec * seg_bytes, &d_buckets))) return rc;
+    if ((rc = ws_ensure(ctx, 2, slice * segs_per_vec * 128, &d_winsums))) return rc;
+
+    const size_t acc_lds = ((size_t)p.M + 2 + 32) * 4 + p.chunk * 2 + 16;
+    int red_threads = p.M < 256 ? p.M : 256;
+    const size_t red_lds = (size_t)red_threads * 128 * 2;
+    static bool attr_set[3] = {false, false, false};
+    if (!attr_set[C::id]) {
+        BZH_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msm_accumulate<C>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        BZH_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msm_reduce<C>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        attr_set[C::id] = true;
+    }
+
+    for (size_t b0 = 0; b0 < batch; b0 += slice) {
+        const size_t nb = (batch - b0 < slice) ? batch - b0 : slice;
+        const size_t total = nb * n;
+        {
+            ScopedTimer t(ctx, BZH_T_MSM_DIGITS);
+            hipLaunchKernelGGL((k_msm_digits<SF>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
+                               d_scalars + b0 * n * 8, n, total, form, p.c, p.nwin, off, (uint16_t*)d_digits);
+        }
+        {
+            ScopedTimer t(ctx, BZH_T_MSM_ACCUMULATE);
+            hipLaunchKernelGGL((k_msm_accumulate<C>), dim3((unsigned)p.nchunks, (unsigned)p.nwin, (unsigned)nb),
+                               dim3(p.threads), acc_lds, ctx->stream, bases->d_xy, (const uint16_t*)d_digits, n, p.nwin,
+                               p.M, p.chunk, (uint4*)d_buckets);
+        }
+        const size_t nseg = nb * segs_per_vec;
+        {
+            ScopedTimer t(ctx, BZH_T_MSM_REDUCE);
+            hipLaunchKernelGGL((k_msm_reduce<C>), dim3((unsigned)nseg), dim3(red_threads), red_lds, ctx->stream,
+                               (const uint4*)d_buckets, p.M, (uint4*)d_winsums);
+        }
+        {
+            ScopedTimer t(ctx, BZH_T_MSM_FINALIZE);
+            hipLaunchKernelGGL((k_msm_finalize<C>), dim3((unsigned)nb), dim3(64), 0, ctx->stream,
+                               (const uint4*)d_winsums, nseg, p.nwin, p.nchunks, p.c, form, d_out + b0 * 24);
+        }
+        BZH_HIP_TRY(ctx, hipGetLastError());
+    }
+    return BZH_OK;
+}
+
+int msm_run(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_scalars, size_t n, size_t batch, int form,
+            uint32_t* d_out_xyz) {
+    switch (bases->curve) {
+        case BZH_CURVE_VESTA:
+            return msm_run_t<VestaCurve, FpParams>(ctx, bases, d_scalars, n, batch, form, d_out_xyz);
+        case BZH_CURVE_PALLAS:
+            return msm_run_t<PallasCurve, FqParams>(ctx, bases, d_scalars, n, batch, form, d_out_xyz);
+        case BZH_CURVE_BN254:
+            return msm_run_t<Bn254Curve, BnFrParams>(ctx, bases, d_scalars, n, batch, form, d_out_xyz);
+    }
+    return BZH_E_ARG;
+}
+
+int bases_to_montgomery(bzh_ctx* ctx, int curve, uint32_t* d_xy, size_t n) {
+    const size_t count = n * 2;
+    if (count == 0) return BZH_OK;
+    dim3 grid((unsigned)((count + 255) / 256)), block(256);
+    switch (curve) {
+        case BZH_CURVE_VESTA:
+            hipLaunchKernelGGL((k_to_montgomery<FqParams>), grid, block, 0, ctx->stream, d_xy, count);
+            break;
+        case BZH_CURVE_PALLAS:
+            hipLaunchKernelGGL((k_to_montgomery<FpParams>), grid, block, 0, ctx->stream, d_xy, count);
+            break;
+        case BZH_CURVE_BN254:
+            hipLaunchKernelGGL((k_to_montgomery<BnFqParams>), grid, block, 0, ctx->stream, d_xy, count);
+            break;
+        default:
+            return BZH_E_ARG;
+    }
+    BZH_HIP_TRY(ctx, hipGetLastError());
+    return BZH_OK;
+}
+
+}  // namespace bzh

@@ -1,0 +1,386 @@
+// Radix-2 NTT / iNTT / coset NTT on gfx950, multi-pass with LDS-resident tiles.
+//
+// Replaces halo2_proofs 0.2.0 `arithmetic::best_fft` and the EvaluationDomain
+// wrappers `ifft`, `coeff_to_extended`, `extended_to_coeff` (UPSTREAM,
+// un-vendored: Cargo.lock:382-385) on the create_proof path entered at
+// benches/shot.rs:68 / benches/board.rs:61-68: ~17 iNTT(n) + ~18 coset NTT(8n)
+// + 1 extended iNTT per proof.
+//
+// N = 2^k is factored as A * R * B per pass (A = radices already done, R = this
+// pass, B = radices still to do).  In place, element (a, r, j) lives at
+// a*R*B + r*B + j.  Pass p transforms the r axis inside an LDS tile of R x W
+// elements (W adjacent j, i.e. W*32-byte contiguous runs), multiplies by the
+// inter-pass twiddle omega_N^(A*k_r*j) and writes back in place.  The last pass
+// (B = 1) reads W rows whose digit-reversed indices are consecutive and writes
+// X[digitrev(a) + A*k_r], which makes the final order natural with W*32-byte
+// contiguous runs on both sides.  Modular-integer work, no MFMA.
+#include <cstring>
+#include <vector>
+
+#include "ctx.hpp"
+#include "field.cuh"
+
+namespace bzh {
+
+int field_convert(bzh_ctx* ctx, int field, uint32_t* d, size_t count, int to_mont);
+
+static constexpr int kTileElems = 2048;  // 64 KiB of LDS per workgroup
+static constexpr int kNttThreads = 256;
+
+struct NttPassArgs {
+    const uint32_t* src;  // pass input  (same index map as dst)
+    uint32_t* dst;        // pass output: passes before the last may run in place (each tile rewrites
+                          // exactly what it read); the last pass transposes and must not.
+    unsigned log_n;
+    int r;      // log2 R
+    int logA;   // log2 A
+    int logB;   // log2 B
+    int logW;   // log2 W
+    int last;
+    int nprev;
+    int prev_bits[4];
+    const uint32_t* sub_tw;  // omega_R^j, j < R/2
+    const uint32_t* tw_lo;   // omega_N^e, e < 2^h
+    const uint32_t* tw_hi;   // omega_N^(e << h)
+    int h;
+    const uint32_t* pre_lo;  // first pass: element n *= pre(n)   (coset shift^n)
+    const uint32_t* pre_hi;
+    const uint32_t* post_lo;  // last pass: output k *= post(k)    (n^-1 * shift^-k)
+    const uint32_t* post_hi;
+};
+
+template <class P>
+__device__ __forceinline__ Fe<P> tile_get(const uint4* t, int idx) {
+    uint4 a = t[idx], b = t[kTileElems + idx];
+    Fe<P> r;
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+    return r;
+}
+template <class P>
+__device__ __forceinline__ void tile_put(uint4* t, int idx, const Fe<P>& v) {
+    t[idx] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+    t[kTileElems + idx] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+}
+template <class P>
+__device__ __forceinline__ Fe<P> pow_table(const uint32_t* lo, const uint32_t* hi, int h, size_t e) {
+    Fe<P> a = fe_load<P>(lo + (e & (((size_t)1 << h) - 1)) * 8);
+    Fe<P> b = fe_load<P>(hi + (e >> h) * 8);
+    return fe_mul(a, b);
+}
+__device__ __forceinline__ uint32_t bitrev(uint32_t x, int bits) { return bits ? (__brev(x) >> (32 - bits)) : 0u; }
+
+template <class P>
+__global__ void __launch_bounds__(kNttThreads) k_ntt_pass(NttPassArgs g) {
+    __shared__ __align__(16) uint4 tile[2 * kTileElems];
+    const int tid = threadIdx.x, T = kNttThreads;
+    const int r = g.r, R = 1 << r, logW = g.logW, W = 1 << logW;
+    const size_t N = (size_t)1 << g.log_n;
+    const uint32_t* vin = g.src + (size_t)blockIdx.y * N * 8;
+    uint32_t* vec = g.dst + (size_t)blockIdx.y * N * 8;
+    const size_t tile_id = blockIdx.x;
+    const int items = R << logW;
+
+    if (!g.last) {
+        const size_t B = (size_t)1 << g.logB;
+        const size_t tiles_per_a = B >> logW;
+        const size_t a = tile_id / tiles_per_a, j0 = (tile_id - a * tiles_per_a) << logW;
+        const uint32_t* base = vin + ((a << (r + g.logB)) + j0) * 8;
+        for (int it = tid; it < items; it += T) {
+            const int col = it & (W - 1), row = it >> logW;
+            Fe<P> v = fe_load<P>(base + ((size_t)row * B + col) * 8);
+            if (g.pre_lo) v = fe_mul(v, pow_table<P>(g.pre_lo, g.pre_hi, g.h, (size_t)row * B + j0 + col));
+            tile_put(tile, (int)(bitrev((uint32_t)row, r) << logW) + col, v);
+        }
+    } else {
+        // rows: d = tile_id*W + i  ->  a = digit-unreversed(d); element (a, rr) at a*R + rr
+        for (int it = tid; it < items; it += T) {
+            const int rr = it & (R - 1), i = it >> r;
+            size_t d = (tile_id << logW) + i, a = 0;
+            for (int q = 0; q < g.nprev; q++) {
+                a = (a << g.prev_bits[q]) | (d & (((size_t)1 << g.prev_bits[q]) - 1));
+                d >>= g.prev_bits[q];
+            }
+            Fe<P> v = fe_load<P>(vin + ((a << r) + rr) * 8);
+            if (g.pre_lo) v = fe_mul(v, pow_table<P>(g.pre_lo, g.pre_hi, g.h, (size_t)rr));  // single-pass only
+            tile_put(tile, (int)(bitrev((uint32_t)rr, r) << logW) + i, v);
+        }
+    }
+    // radix-2 DIT stages over the tile rows
+    const int nbf = items >> 1;
+    for (int s = 0; s < r; s++) {
+        __syncthreads();
+        const int half = 1 << s;
+        for (int it = tid; it < nbf; it += T) {
+            const int col = it & (W - 1), bf = it >> logW;
+            const int j = bf & (half - 1), grp = bf >> s;
+            const int top = (((grp << (s + 1)) + j) << logW) + col, bot = top + (half << logW);
+            Fe<P> u = tile_get<P>(tile, top), v = tile_get<P>(tile, bot);
+            if (s > 0) v = fe_mul(v, fe_load<P>(g.sub_tw + ((size_t)j << (r - 1 - s)) * 8));
+            tile_put(tile, top, fe_add(u, v));
+            tile_put(tile, bot, fe_sub(u, v));
+        }
+    }
+    __syncthreads();
+    if (!g.last) {
+        const size_t B = (size_t)1 << g.logB;
+        const size_t tiles_per_a = B >> logW;
+        const size_t a = tile_id / tiles_per_a, j0 = (tile_id - a * tiles_per_a) << logW;
+        uint32_t* base = vec + ((a << (r + g.logB)) + j0) * 8;
+        for (int it = tid; it < items; it += T) {
+            const int col = it & (W - 1), row = it >> logW;
+            Fe<P> v = tile_get<P>(tile, it);
+            const size_t e = ((size_t)row * (j0 + col)) << g.logA;
+            if (e) v = fe_mul(v, pow_table<P>(g.tw_lo, g.tw_hi, g.h, e));
+            fe_store(base + ((size_t)row * B + col) * 8, v);
+        }
+    } else {
+        for (int it = tid; it < items; it += T) {
+            const int i = it & (W - 1), kr = it >> logW;
+            Fe<P> v = tile_get<P>(tile, it);
+            const size_t k = ((size_t)kr << g.logA) + (tile_id << logW) + i;
+            if (g.post_lo) v = fe_mul(v, pow_table<P>(g.post_lo, g.post_hi, g.h, k));
+            fe_store(vec + k * 8, v);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host: domain tables (cached per ctx) and pass planning
+// ---------------------------------------------------------------------------
+struct NttDomain {
+    int field;
+    unsigned log_n;
+    int inverse;
+    int has_shift;
+    uint32_t omega[8];  // Montgomery, as given (before inversion)
+    uint32_t shift[8];
+    int h;
+    uint32_t* d_tables = nullptr;  // one allocation
+    size_t off_tw_lo, off_tw_hi, off_sc_lo, off_sc_hi;
+    size_t off_sub[12];  // sub-NTT twiddles for radix bits 1..11
+};
+
+struct NttCache {
+    std::vector<NttDomain> doms;
+};
+static std::mutex g_cache_mu;
+static std::vector<std::pair<bzh_ctx*, NttCache*>> g_caches;
+
+static NttCache* cache_for(bzh_ctx* ctx) {
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    for (auto& p : g_caches)
+        if (p.first == ctx) return p.second;
+    g_caches.emplace_back(ctx, new NttCache());
+    return g_caches.back().second;
+}
+void ntt_cache_drop(bzh_ctx* ctx) {
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    for (size_t i = 0; i < g_caches.size(); i++)
+        if (g_caches[i].first == ctx) {
+            for (auto& d : g_caches[i].second->doms)
+                if (d.d_tables) (void)hipFree(d.d_tables);
+            delete g_caches[i].second;
+            g_caches.erase(g_caches.begin() + i);
+            return;
+        }
+}
+
+template <class P>
+static void fill_pows(std::vector<uint32_t>& out, size_t off, const Fe<P>& base, const Fe<P>& first, size_t count) {
+    Fe<P> acc = first;
+    for (size_t i = 0; i < count; i++) {
+        for (int k = 0; k < 8; k++) out[off + i * 8 + k] = acc.l[k];
+        acc = fe_mul(acc, base);
+    }
+}
+template <class P>
+static Fe<P> pow2k(Fe<P> x, int k) {
+    for (int i = 0; i < k; i++) x = fe_sqr(x);
+    return x;
+}
+
+template <class P>
+static int build_domain(bzh_ctx* ctx, NttDomain& d, const Fe<P>& omega_m, const Fe<P>* shift_m) {
+    const unsigned k = d.log_n;
+    const size_t N = (size_t)1 << k;
+    d.h = (int)((k + 1) / 2);
+    const size_t nlo = (size_t)1 << d.h, nhi = (size_t)1 << (k - d.h);
+    Fe<P> w = d.inverse ? fe_inv(omega_m) : omega_m;
+    size_t words = 0;
+    d.off_tw_lo = words; words += nlo * 8;
+    d.off_tw_hi = words; words += nhi * 8;
+    d.off_sc_lo = words; words += nlo * 8;
+    d.off_sc_hi = words; words += nhi * 8;
+    for (int rb = 1; rb <= 11; rb++) {
+        d.off_sub[rb] = words;
+        if ((unsigned)rb <= k) words += ((size_t)1 << (rb - 1)) * 8;
+    }
+    std::vector<uint32_t> host(words, 0u);
+    fill_pows<P>(host, d.off_tw_lo, w, fe_one<P>(), nlo);
+    fill_pows<P>(host, d.off_tw_hi, pow2k(w, d.h), fe_one<P>(), nhi);
+    // scale tables: forward = shift^n ; inverse = n^-1 * shift^-k (or n^-1 alone)
+    Fe<P> sbase = fe_one<P>(), first_hi = fe_one<P>();
+    if (d.has_shift) sbase = d.inverse ? fe_inv(*shift_m) : *shift_m;
+    if (d.inverse) {
+        Fe<P> nn = fe_zero<P>();
+        nn.l[0] = (uint32_t)(N & 0xffffffffu);
+        nn.l[1] = (uint32_t)((uint64_t)N >> 32);
+        first_hi = fe_inv(fe_to_mont(nn));
+    }
+    fill_pows<P>(host, d.off_sc_lo, sbase, fe_one<P>(), nlo);
+    fill_pows<P>(host, d.off_sc_hi, pow2k(sbase, d.h), first_hi, nhi);
+    for (int rb = 1; rb <= 11 && (unsigned)rb <= k; rb++) {
+        Fe<P> wr = pow2k(w, (int)k - rb);  // omega_N^(N/R)
+        fill_pows<P>(host, d.off_sub[rb], wr, fe_one<P>(), (size_t)1 << (rb - 1));
+    }
+    BZH_HIP_TRY(ctx, hipMalloc((void**)&d.d_tables, words * 4));
+    BZH_HIP_TRY(ctx, hipMemcpyAsync(d.d_tables, host.data(), words * 4, hipMemcpyHostToDevice, ctx->stream));
+    BZH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // host vector goes out of scope
+    return BZH_OK;
+}
+
+template <class P>
+static int ntt_run_t(bzh_ctx* ctx, uint32_t* d_data, unsigned log_n, size_t batch, const uint64_t* omega,
+                     const uint64_t* coset_shift, int inverse, int form) {
+    if (log_n == 0) return BZH_OK;  // size-1 transform is the identity (n^-1 = 1, shift^0 = 1)
+    Fe<P> w, sh = fe_one<P>();
+    for (int i = 0; i < 4; i++) {
+        w.l[2 * i] = (uint32_t)omega[i];
+        w.l[2 * i + 1] = (uint32_t)(omega[i] >> 32);
+        if (coset_shift) {
+            sh.l[2 * i] = (uint32_t)coset_shift[i];
+            sh.l[2 * i + 1] = (uint32_t)(coset_shift[i] >> 32);
+        }
+    }
+    if (form == BZH_FORM_CANONICAL) {
+        w = fe_to_mont(w);
+        if (coset_shift) sh = fe_to_mont(sh);
+    }
+    NttCache* cache = cache_for(ctx);
+    NttDomain* dom = nullptr;
+    for (auto& d : cache->doms) {
+        if (d.field == P::id && d.log_n == log_n && d.inverse == (inverse != 0) && d.has_shift == (coset_shift != nullptr) &&
+            memcmp(d.omega, w.l, 32) == 0 && (!coset_shift || memcmp(d.shift, sh.l, 32) == 0)) {
+            dom = &d;
+            break;
+        }
+    }
+    if (!dom) {
+        NttDomain d;
+        d.field = P::id;
+        d.log_n = log_n;
+        d.inverse = inverse != 0;
+        d.has_shift = coset_shift != nullptr;
+        memcpy(d.omega, w.l, 32);
+        memcpy(d.shift, sh.l, 32);
+        int rc = build_domain<P>(ctx, d, w, coset_shift ? &sh : nullptr);
+        if (rc) return rc;
+        cache->doms.push_back(d);
+        dom = &cache->doms.back();
+    }
+    // canonical input -> Montgomery (and back at the end)
+    const size_t total = batch << log_n;
+    if (form == BZH_FORM_CANONICAL) {
+        int rc = field_convert(ctx, P::id, d_data, total, 1);
+        if (rc) return rc;
+    }
+    // plan passes
+    int bits[5], np;
+    if (log_n <= 11) {
+        np = 1;
+        bits[0] = (int)log_n;
+    } else {
+        np = (int)((log_n + 8) / 9);
+        int base = (int)log_n / np, extra = (int)log_n % np;
+        for (int i = 0; i < np; i++) bits[i] = base + (i < extra ? 1 : 0);
+    }
+    // np >= 2: pass 0 data -> scratch, middle passes in scratch, last pass scratch -> data
+    uint32_t* d_scratch = nullptr;
+    if (np >= 2) {
+        void* sp = nullptr;
+        int rc = ws_ensure(ctx, 0, total * 32, &sp);
+        if (rc) return rc;
+        d_scratch = (uint32_t*)sp;
+    }
+    const bool pre = (!inverse && coset_shift);
+    const bool post = (inverse != 0);
+    int logA = 0;
+    for (int p = 0; p < np; p++) {
+        NttPassArgs a;
+        a.src = (p == 0) ? d_data : d_scratch;
+        a.dst = (p == np - 1) ? d_data : d_scratch;
+        a.log_n = log_n;
+        a.r = bits[p];
+        a.logA = logA;
+        a.logB = (int)log_n - logA - bits[p];
+        a.last = (p == np - 1);
+        int logW = 11 - a.r;  // R * W = 2048
+        if (!a.last && logW > a.logB) logW = a.logB;
+        if (a.last && logW > logA) logW = logA;
+        a.logW = logW;
+        a.nprev = p;
+        for (int q = 0; q < 4; q++) a.prev_bits[q] = q < p ? bits[q] : 0;
+        a.sub_tw = dom->d_tables + dom->off_sub[a.r];
+        a.tw_lo = dom->d_tables + dom->off_tw_lo;
+        a.tw_hi = dom->d_tables + dom->off_tw_hi;
+        a.h = dom->h;
+        a.pre_lo = (pre && p == 0) ? dom->d_tables + dom->off_sc_lo : nullptr;
+        a.pre_hi = dom->d_tables + dom->off_sc_hi;
+        a.post_lo = (post && a.last) ? dom->d_tables + dom->off_sc_lo : nullptr;
+        a.post_hi = dom->d_tables + dom->off_sc_hi;
+        const size_t tiles = ((size_t)1 << log_n) >> (a.r + logW);
+        {
+            ScopedTimer t(ctx, BZH_T_NTT);
+            for (size_t b0 = 0; b0 < batch; b0 += 65535) {
+                size_t nb = batch - b0 < 65535 ? batch - b0 : 65535;
+                NttPassArgs aa = a;
+                aa.src = a.src + (b0 << log_n) * 8;
+                aa.dst = a.dst + (b0 << log_n) * 8;
+                hipLaunchKernelGGL((k_ntt_pass<P>), dim3((unsigned)tiles, (unsigned)nb), dim3(kNttThreads), 0, ctx->stream, aa);
+            }
+        }
+        BZH_HIP_TRY(ctx, hipGetLastError());
+        logA += bits[p];
+    }
+    if (form == BZH_FORM_CANONICAL) {
+        int rc = field_convert(ctx, P::id, d_data, total, 0);
+        if (rc) return rc;
+    }
+    return BZH_OK;
+}
+
+template <class P>
+__global__ void __launch_bounds__(256) k_field_convert(uint32_t* data, size_t count, int to_mont) {
+    size_t gid = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (gid >= count) return;
+    Fe<P> v = fe_load<P>(data + gid * 8);
+    fe_store(data + gid * 8, to_mont ? fe_to_mont(v) : fe_from_mont(v));
+}
+
+int field_convert(bzh_ctx* ctx, int field, uint32_t* d, size_t count, int to_mont) {
+    if (!count) return BZH_OK;
+    dim3 grid((unsigned)((count + 255) / 256)), block(256);
+    switch (field) {
+        case BZH_FIELD_FP: hipLaunchKernelGGL((k_field_convert<FpParams>), grid, block, 0, ctx->stream, d, count, to_mont); break;
+        case BZH_FIELD_FQ: hipLaunchKernelGGL((k_field_convert<FqParams>), grid, block, 0, ctx->stream, d, count, to_mont); break;
+        case BZH_FIELD_BN254_FR: hipLaunchKernelGGL((k_field_convert<BnFrParams>), grid, block, 0, ctx->stream, d, count, to_mont); break;
+        case BZH_FIELD_BN254_FQ: hipLaunchKernelGGL((k_field_convert<BnFqParams>), grid, block, 0, ctx->stream, d, count, to_mont); break;
+        default: return BZH_E_ARG;
+    }
+    BZH_HIP_TRY(ctx, hipGetLastError());
+    return BZH_OK;
+}
+
+int ntt_run(bzh_ctx* ctx, int field, uint32_t* d_data, unsigned log_n, size_t batch, const uint64_t* omega,
+            const uint64_t* coset_shift, int inverse, int form) {
+    switch (field) {
+        case BZH_FIELD_FP: return ntt_run_t<FpParams>(ctx, d_data, log_n, batch, omega, coset_shift, inverse, form);
+        case BZH_FIELD_FQ: return ntt_run_t<FqParams>(ctx, d_data, log_n, batch, omega, coset_shift, inverse, form);
+        case BZH_FIELD_BN254_FR: return ntt_run_t<BnFrParams>(ctx, d_data, log_n, batch, omega, coset_shift, inverse, form);
+        case BZH_FIELD_BN254_FQ: return ntt_run_t<BnFqParams>(ctx, d_data, log_n, batch, omega, coset_shift, inverse, form);
+    }
+    return BZH_E_ARG;
+}
+
+}  // namespace bzh

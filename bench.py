@@ -1,0 +1,279 @@
+#!/usr/bin/env python3
+"""bench.py -- the create_proof commit/evaluate hot path on MI355X through libbzh2.so.
+
+One "step" = the MSM + NTT schedule of ONE BoardCircuit proof at k=14 over
+IPA/Pasta (Vesta commitments, Fp polynomials), SURVEY.md section 3.1:
+    28 MSMs of n = 2^14 against one SRS table (one batched bzh_msm call)
+    17 iNTT(n)            lagrange_to_coeff of every committed column
+    18 coset NTT(8n)      coeff_to_extended
+     1 extended iNTT(8n)  extended_to_coeff of h(X)
+Inputs are synthetic (seeded random field elements in pasta_curves' Montgomery
+form; bases are random multiples of the Vesta generator produced by the HIP MSM
+itself) and are resident in HBM before the timed region starts.
+
+What is NOT yet in the step (and so not in the number): witness synthesis, the
+quotient evaluation, permutation/lookup grand products, multiopen/IPA folding
+and the transcript -- i.e. this is the proof's MSM+NTT workload, not a complete
+proof; `config.stages` says so in the JSON line.
+
+Other workloads (config 5 microbenches): --workload msm24 | ntt22 | shot_k11_batch.
+
+Multi-GPU: one process per GPU (torchrun); proofs are independent, so every rank
+runs the same per-GPU workload (weak scaling) and the only collective is one
+RCCL all_gather of the ranks' commitment outputs at the end of the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "battlezips-halo2_amd"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import bzh2  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="board_k14",
+                    choices=["board_k14", "board_k12", "shot_k11", "board_k17", "shot_k11_batch", "msm24", "msm20", "ntt22"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def rand_field(shape_elems, gen, device):
+    """Random 253-bit values as (.., 4) int64 limbs: valid Montgomery representatives for every field here."""
+    t = torch.randint(-(1 << 63), (1 << 63) - 1, (*shape_elems, 4), dtype=torch.int64, device=device, generator=gen)
+    t[..., 3] &= (1 << 61) - 1
+    return t
+
+
+def make_bases(ctx, curve, n, seed):
+    """n random multiples of the curve generator (-1, 2) [(1, 2) on BN254], made with the product's own
+    MSM (n single-point MSMs), normalised on the host."""
+    F = {0: 0x40000000000000000000000000000000224698fc0994a8dd8c46eb2100000001,
+         1: 0x40000000000000000000000000000000224698fc094cf91b992d30ed00000001}
+    gx = 1 if curve == bzh2.CURVE_BN254 else F[curve] - 1
+    g = np.concatenate([bzh2.int_to_limbs(gx), bzh2.int_to_limbs(2)]).reshape(1, 8)
+    hb = ctx.upload_bases(curve, g)
+    rng = np.random.default_rng(seed)
+    out = np.zeros((n, 8), dtype=np.uint64)
+    step = 1 << 16
+    for i0 in range(0, n, step):
+        m = min(step, n - i0)
+        sc = np.frombuffer(rng.bytes(m * 32), dtype=np.uint64).reshape(m, 1, 4).copy()
+        sc[:, :, 3] &= (1 << 61) - 1
+        jac = ctx.msm(hb, sc)
+        out[i0:i0 + m] = bzh2.jacobian_to_affine(curve, jac)
+    hb.free()
+    return out
+
+
+class Workload:
+    """Device-resident inputs + the list of library calls that make one step."""
+
+    def __init__(self, name, ctx, device, seed):
+        self.name, self.ctx = name, ctx
+        gen = torch.Generator(device=device)
+        gen.manual_seed(seed)
+        self.calls = []
+        self.curve, self.field = bzh2.CURVE_VESTA, bzh2.FIELD_FP
+        self.alg_bytes_msm_launch = 0
+        self.units_per_step = 1
+        self.desc = {}
+        proof_shapes = {"board_k14": 14, "board_k12": 12, "shot_k11": 11, "board_k17": 17}
+        if name in proof_shapes or name == "shot_k11_batch":
+            k = 11 if name == "shot_k11_batch" else proof_shapes[name]
+            proofs = 64 if name == "shot_k11_batch" else 1
+            n, ext = 1 << k, 1 << (k + 3)
+            self.k = k
+            self.units_per_step = proofs
+            self.bases = ctx.upload_bases(self.curve, make_bases(ctx, self.curve, n, seed + 1))
+            self.msm_scalars = rand_field((28 * proofs, n), gen, device)
+            self.msm_out = torch.zeros((28 * proofs, 12), dtype=torch.int64, device=device)
+            self.cols = rand_field((17 * proofs, n), gen, device)
+            self.ext = rand_field((18 * proofs, ext), gen, device)
+            self.hx = rand_field((proofs, ext), gen, device)
+            self.w_n = bzh2.field_omega(self.field, k, bzh2.FORM_MONTGOMERY)
+            self.w_ext = bzh2.field_omega(self.field, k + 3, bzh2.FORM_MONTGOMERY)
+            # halo2's extended coset generator is ZETA, a primitive cube root of unity: 5^((p-1)/3)
+            p = 0x40000000000000000000000000000000224698fc094cf91b992d30ed00000001
+            zeta = pow(5, (p - 1) // 3, p)
+            self.zeta = bzh2.int_to_limbs(zeta * pow(2, 256, p) % p)
+            self.calls = [
+                ("msm", lambda: ctx.msm_device(self.bases, self.msm_scalars.data_ptr(), n, 28 * proofs, self.msm_out.data_ptr())),
+                ("intt_n", lambda: ctx.ntt_device(self.field, self.cols.data_ptr(), k, 17 * proofs, self.w_n, None, True)),
+                ("coset_ntt_8n", lambda: ctx.ntt_device(self.field, self.ext.data_ptr(), k + 3, 18 * proofs, self.w_ext, self.zeta, False)),
+                ("ext_intt_8n", lambda: ctx.ntt_device(self.field, self.hx.data_ptr(), k + 3, proofs, self.w_ext, self.zeta, True)),
+            ]
+            self.alg_bytes_msm_launch = 28 * proofs * n * 32 + n * 64
+            self.alg_bytes_step = self.alg_bytes_msm_launch + 64 * (17 * n + 19 * ext) * proofs
+            self.desc = {"k": k, "proofs_per_step": proofs, "msm": "%dx2^%d vesta" % (28 * proofs, k),
+                         "ntt": "%dx iNTT 2^%d + %dx coset NTT 2^%d + %dx coset iNTT 2^%d (Fp)" % (17 * proofs, k, 18 * proofs, k + 3, proofs, k + 3)}
+            self.result = self.msm_out
+        elif name in ("msm24", "msm20"):
+            k = 24 if name == "msm24" else 20
+            n = 1 << k
+            self.k = k
+            self.bases = ctx.upload_bases(self.curve, make_bases(ctx, self.curve, n, seed + 1))
+            self.msm_scalars = rand_field((1, n), gen, device)
+            self.msm_out = torch.zeros((1, 12), dtype=torch.int64, device=device)
+            self.calls = [("msm", lambda: ctx.msm_device(self.bases, self.msm_scalars.data_ptr(), n, 1, self.msm_out.data_ptr()))]
+            self.alg_bytes_msm_launch = n * 96
+            self.alg_bytes_step = n * 96
+            self.desc = {"msm": "1x2^%d vesta" % k}
+            self.result = self.msm_out
+        elif name == "ntt22":
+            k = 22
+            self.k = k
+            self.data = rand_field((1, 1 << k), gen, device)
+            self.w = bzh2.field_omega(self.field, k, bzh2.FORM_MONTGOMERY)
+            self.calls = [("ntt", lambda: ctx.ntt_device(self.field, self.data.data_ptr(), k, 1, self.w, None, False))]
+            self.alg_bytes_step = 64 << k
+            self.desc = {"ntt": "1x NTT 2^22 (Fp)"}
+            self.result = self.data[:, :4].contiguous().view(1, 16)[:, :12].contiguous()
+        else:
+            raise ValueError(name)
+
+    def step(self):
+        for _, fn in self.calls:
+            fn()
+
+
+def cpu_baseline(workload_name, k):
+    """Time the C oracle ("port": CPU restatement, not the Rust crate) on one full step's worth of
+    MSM+NTT work for the proof workloads, all host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import coracle as C
+    import pasta as O
+    import random
+    cores = os.cpu_count() or 1
+    n, ext = 1 << k, 1 << (k + 3)
+    rng = np.random.default_rng(99)
+
+    def rnd(m):
+        a = np.frombuffer(rng.bytes(m * 32), dtype=np.uint64).reshape(m, 4).copy()
+        a[:, 3] &= (1 << 61) - 1
+        return a
+
+    g = O.VESTA.random_point(random.Random(1))
+    bases = C.point_walk(0, C.points_to_array([g])[0], n)
+    n_msm, n_intt, n_cntt = 2, 2, 2
+    t0 = time.perf_counter()
+    for _ in range(n_msm):
+        C.msm(0, rnd(n), bases, cores)
+    t_msm = (time.perf_counter() - t0) / n_msm
+    a = rnd(n)
+    t0 = time.perf_counter()
+    for _ in range(n_intt):
+        C.ntt(0, a, O.FP.omega(k), inverse=True, threads=cores)
+    t_intt = (time.perf_counter() - t0) / n_intt
+    e = rnd(ext)
+    t0 = time.perf_counter()
+    for _ in range(n_cntt):
+        C.ntt(0, e, O.FP.omega(k + 3), coset_shift=O.FP.g, threads=cores)
+    t_cntt = (time.perf_counter() - t0) / n_cntt
+    per_step = 28 * t_msm + 17 * t_intt + 19 * t_cntt
+    return {"value": 1.0 / per_step, "unit": "proof-workloads/s", "cores": cores, "kind": "port",
+            "sample": "C oracle (liboracle.so, halo2-style chunked Pippenger + radix-2 FFT): %d MSM 2^%d, %d iNTT 2^%d, "
+                      "%d coset NTT 2^%d timed, scaled to 28/17/19 per step" % (n_msm, k, n_intt, k, n_cntt, k + 3),
+            "seconds_per_step": per_step}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    stream = torch.cuda.current_stream(device)
+    ctx = bzh2.Context(local_rank, stream=stream.cuda_stream)
+    wl = Workload(args.workload, ctx, device, seed=1234 + rank)
+
+    def barrier():
+        torch.cuda.synchronize(device)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        wl.step()
+    barrier()
+    ctx.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wl.step()
+    if dist is not None:  # the one collective: gather every rank's commitments (fixed-stride records)
+        gathered = [torch.empty_like(wl.result) for _ in range(world)]
+        dist.all_gather(gathered, wl.result)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    timings = ctx.timings()
+    ctx.profile(False)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        units = wl.units_per_step * args.steps * world
+        is_proof = args.workload.startswith(("board", "shot"))
+        acc = timings["msm_accumulate"]
+        nt = timings["ntt"]
+        if args.workload == "ntt22":
+            dom_ms = nt["ms"] / max(nt["launches"], 1) * (nt["launches"] / max(args.steps, 1))  # all passes of one NTT
+            alg = wl.alg_bytes_step
+            dom_name = "k_ntt_pass (all passes of one 2^22 NTT)"
+        else:
+            dom_ms = acc["ms"] / max(acc["launches"], 1)
+            alg = wl.alg_bytes_msm_launch
+            dom_name = "k_msm_accumulate"
+        achieved = alg / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        line = {
+            "metric": ("%s proof MSM+NTT workloads per second" % args.workload) if is_proof else ("%s runs per second" % args.workload),
+            "value": units / elapsed,
+            "unit": "proof-workloads/s" if is_proof else "runs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32x8 (255-bit modular integer, Montgomery)", "data": "synthetic",
+            "config": dict({"workload": args.workload, "curve": "vesta/Fp (IPA over Pasta, the reference's locked build)",
+                            "stages": "MSM commits + NTT/iNTT/coset-NTT of one proof; NOT included: synthesis, quotient, "
+                                      "grand products, multiopen/IPA, transcript",
+                            "form": "montgomery", "parallelism": "independent proofs per GPU (dp%d)" % world,
+                            "algorithmic_GB_per_step": wl.alg_bytes_step / 1e9,
+                            "whole_step_GBps": wl.alg_bytes_step * args.steps / elapsed / 1e9}, **wl.desc),
+            "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg, "avg_launch_ms": dom_ms},
+            "kernel_ms": {kname: v for kname, v in timings.items() if v["launches"]},
+        }
+        if world == 1 and is_proof and not args.no_cpu_baseline and args.workload != "shot_k11_batch":
+            line["cpu_baseline"] = cpu_baseline(args.workload, wl.k)
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,144 @@
+/*
+ * bzh2 -- MI355X (gfx950) prover-backend primitives for the BattleZips Halo2
+ * circuits, flat C ABI.  This is the drop-in boundary: the entry points are
+ * what an FFI shim inside `halo2_proofs` (the crate the reference calls into)
+ * would bind for the create_proof hot path.  See INTEGRATION.md for the Rust
+ * `extern "C"` block and the three call sites it replaces.
+ *
+ * The reference itself contains no prover arithmetic: its
+ * hot path is the call
+ *     create_proof(&params, &pk, &[circuit], &[&[&instances]], OsRng, &mut transcript)
+ *   benches/shot.rs:68, benches/board.rs:61-68,
+ *   src/circuits/shot.rs:921-928, src/circuits/board.rs:913-920,
+ *   src/wasm/circuit_wasm.rs:66-73,151-158
+ * which funnels into halo2_proofs 0.2.0 (Cargo.lock:382-385, un-vendored):
+ *     arithmetic::best_multiexp(&[Scalar], &[Affine]) -> Curve      -> bzh_msm
+ *     Params::{commit, commit_lagrange}                              -> bzh_bases_upload + bzh_msm
+ *     arithmetic::best_fft(&mut [Scalar], omega, log_n)              -> bzh_ntt
+ *     EvaluationDomain::{ifft, coeff_to_extended, extended_to_coeff} -> bzh_ntt (inverse / coset_shift)
+ *
+ * Data conventions
+ *   field element : 4 x uint64 little-endian limbs (32 bytes).
+ *                   form = BZH_FORM_MONTGOMERY  (x*2^256 mod p; pasta_curves' in-memory form,
+ *                          so `&[Fp]` crosses the boundary without repacking) or
+ *                   form = BZH_FORM_CANONICAL   (ff::PrimeField::to_repr, src/utils/binary.rs:36).
+ *   affine point  : x || y (64 bytes, 8 limbs); (0,0) is the identity.
+ *   Jacobian point: X || Y || Z (96 bytes, 12 limbs), x = X/Z^2, y = Y/Z^3, Z = 0 identity.
+ *   mem           : BZH_MEM_HOST   - pointer is host memory, the call copies in/out and
+ *                                    returns when the result is in the caller's buffer;
+ *                   BZH_MEM_DEVICE - pointer is HBM on the ctx's device; the call only
+ *                                    enqueues work on the ctx's stream (use bzh_ctx_sync).
+ *
+ * Ownership / errors / threading
+ *   The caller owns every buffer; the library never keeps a host pointer past
+ *   return.  Device tables are explicit handles (bzh_bases).  Every function
+ *   returns 0 (BZH_OK) or a negative bzh_status and never throws or aborts
+ *   across the boundary (halo2's callers `assert_eq!(coeffs.len(), bases.len())`
+ *   and panic: a shim maps nonzero to panic!/Error::Synthesis).  One ctx = one
+ *   device + one HIP stream; calls on one ctx are serialised by an internal
+ *   mutex, several ctxs may be used from several threads.
+ */
+#ifndef BZH2_H
+#define BZH2_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bzh_ctx bzh_ctx;
+typedef struct bzh_bases bzh_bases;
+
+typedef enum {
+    BZH_OK = 0,
+    BZH_E_ARG = -1,    /* null pointer, bad enum, size mismatch               */
+    BZH_E_OOM = -2,    /* hipMalloc / host allocation failed                  */
+    BZH_E_HIP = -3,    /* a HIP runtime call failed (see bzh_last_error)      */
+    BZH_E_RANGE = -4,  /* log_n beyond the field's 2-adicity, n too large ... */
+    BZH_E_NOGPU = -5   /* no usable gfx950 device                             */
+} bzh_status;
+
+typedef enum { BZH_CURVE_VESTA = 0, BZH_CURVE_PALLAS = 1, BZH_CURVE_BN254 = 2 } bzh_curve;
+typedef enum { BZH_FIELD_FP = 0, BZH_FIELD_FQ = 1, BZH_FIELD_BN254_FR = 2, BZH_FIELD_BN254_FQ = 3 } bzh_field;
+typedef enum { BZH_FORM_CANONICAL = 0, BZH_FORM_MONTGOMERY = 1 } bzh_form;
+typedef enum { BZH_MEM_HOST = 0, BZH_MEM_DEVICE = 1 } bzh_mem;
+
+/* kernel classes timed by bzh_ctx_profile (indices into bzh_ctx_timings) */
+typedef enum {
+    BZH_T_MSM_DIGITS = 0,
+    BZH_T_MSM_ACCUMULATE = 1,
+    BZH_T_MSM_REDUCE = 2,
+    BZH_T_MSM_FINALIZE = 3,
+    BZH_T_NTT = 4,
+    BZH_T_COUNT = 8
+} bzh_timer;
+
+/* ---- library / context -------------------------------------------------- */
+const char* bzh_version(void);
+const char* bzh_strerror(int status);
+/* number of HIP devices visible (0 when there is no GPU); never fails */
+int bzh_device_count(void);
+
+/* One ctx = one device + one stream owned by the ctx. */
+int bzh_ctx_create(int device, bzh_ctx** out);
+/* Same, but work is enqueued on a caller-owned hipStream_t (e.g. the stream a
+ * host framework already uses).  The stream must outlive the ctx. */
+int bzh_ctx_create_on_stream(int device, void* hip_stream, bzh_ctx** out);
+int bzh_ctx_destroy(bzh_ctx* ctx);
+int bzh_ctx_sync(bzh_ctx* ctx);
+/* text of the last HIP error seen on this ctx ("" if none) */
+const char* bzh_last_error(const bzh_ctx* ctx);
+
+/* Per-kernel-class timing with HIP events on the ctx's stream.  enable != 0
+ * starts collecting (and clears the accumulators); bzh_ctx_timings syncs the
+ * stream and returns, per class, accumulated milliseconds and launch counts
+ * since enabling.  ms / launches must each hold BZH_T_COUNT entries. */
+int bzh_ctx_profile(bzh_ctx* ctx, int enable);
+int bzh_ctx_timings(bzh_ctx* ctx, double* ms, uint64_t* launches);
+
+/* ---- commitment bases (Params.g / Params.g_lagrange of halo2's IPA params) -
+ * Replaces the `bases: &[C]` argument of best_multiexp for tables that live
+ * across many MSMs: n affine points are copied to HBM once (converted to
+ * Montgomery form if needed) and referenced by handle afterwards. */
+int bzh_bases_upload(bzh_ctx* ctx, int curve, const uint64_t* xy, size_t n, int form, int mem, bzh_bases** out);
+int bzh_bases_free(bzh_ctx* ctx, bzh_bases* bases);
+size_t bzh_bases_len(const bzh_bases* bases);
+
+/* ---- multi-scalar multiplication  (halo2_proofs arithmetic::best_multiexp) -
+ * out[b] = sum_{i<n} scalars[b*n + i] * bases[i]   for b < batch.
+ * scalars: batch*n field elements of the curve's scalar field (`form`).
+ * n may be smaller than the table (prefix is used, as Params::commit does for
+ * short polynomials).  out: batch Jacobian points (12 limbs each) in `form`.
+ * `mem` applies to both scalars and out. */
+int bzh_msm(bzh_ctx* ctx, const bzh_bases* bases, const uint64_t* scalars, size_t n, size_t batch, int form, int mem,
+            uint64_t* out_xyz);
+
+/* ---- NTT  (halo2_proofs arithmetic::best_fft + EvaluationDomain) ----------
+ * In place over `batch` contiguous vectors of 2^log_n elements; natural order
+ * in and out.
+ *   inverse == 0 : a_i <- sum_j a_j * omega^(ij); if coset_shift != NULL element j is
+ *                  first multiplied by shift^j (coeff_to_extended's zeta powers).
+ *   inverse != 0 : uses omega^-1, multiplies by n^-1 (EvaluationDomain::ifft); if
+ *                  coset_shift != NULL result i is multiplied by shift^-i
+ *                  (extended_to_coeff).
+ * omega must be a primitive 2^log_n-th root of unity; omega and coset_shift are
+ * host pointers to 4 limbs in `form`. */
+int bzh_ntt(bzh_ctx* ctx, int field, uint64_t* data, unsigned log_n, size_t batch, const uint64_t* omega,
+            const uint64_t* coset_shift, int inverse, int form, int mem);
+
+/* ---- host helpers (CPU, no device needed): what `.to_affine()` / `to_bytes()`
+ * do on the Rust side; used by tests and benches to compare canonical bytes. */
+int bzh_jacobian_to_affine(int curve, const uint64_t* xyz, size_t n, int form, uint64_t* out_xy);
+/* pasta_curves to_bytes: x little-endian, bit 255 = parity of canonical y, identity = 32 zero bytes.
+ * xy in `form`; out: n * 32 bytes. */
+int bzh_affine_compress(int curve, const uint64_t* xy, size_t n, int form, uint8_t* out32);
+/* root of unity of order 2^log_n used by halo2's EvaluationDomain for this field
+ * (ROOT_OF_UNITY^(2^(S-log_n))); out: 4 limbs in `form`. */
+int bzh_field_omega(int field, unsigned log_n, int form, uint64_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BZH2_H */

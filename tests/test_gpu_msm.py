@@ -1,0 +1,146 @@
+"""GPU parity: bzh_msm (HIP, through the C ABI) vs the CPU oracle, bit-exact
+on canonical compressed points.  Reference seam: halo2_proofs best_multiexp as
+reached from create_proof (benches/shot.rs:68, src/circuits/board.rs:913-920)."""
+import random
+
+import numpy as np
+import pytest
+
+import coracle as C
+import pasta as O
+
+pytestmark = pytest.mark.gpu
+
+
+def rand_scalars(rng, n, modulus):
+    a = np.frombuffer(rng.bytes(n * 32), dtype=np.uint64).reshape(n, 4).copy()
+    a[:, 3] &= (1 << 61) - 1          # < 2^253 < every modulus used here
+    return a
+
+
+def walk_bases(cid, n, seed):
+    cv = O.CURVE_BY_ID[cid]
+    g = cv.random_point(random.Random(seed))
+    return C.point_walk(cid, C.points_to_array([g])[0], n)
+
+
+def gpu_msm_compressed(bzh2, ctx, cid, bases_np, scalars_np, form=0):
+    b = ctx.upload_bases(cid, bases_np)
+    try:
+        jac = ctx.msm(b, scalars_np, form=form)
+    finally:
+        b.free()
+    aff = bzh2.jacobian_to_affine(cid, jac, form)
+    return bzh2.affine_compress(cid, aff, form)
+
+
+def oracle_compressed(cid, bases_np, scalars_np, threads=8):
+    cv = O.CURVE_BY_ID[cid]
+    out = []
+    s = scalars_np if scalars_np.ndim == 3 else scalars_np.reshape(1, *scalars_np.shape)
+    for v in s:
+        out.append(cv.compress(C.array_to_point(C.msm(cid, np.ascontiguousarray(v), bases_np[: v.shape[0]], threads))))
+    return out
+
+
+@pytest.mark.parametrize("cid", [0, 1, 2])
+@pytest.mark.parametrize("n", [1, 2, 3, 31, 64, 257, 2048])
+def test_msm_matches_oracle(gpu_ctx, oracle_c, cid, n):
+    import bzh2
+    rng = np.random.default_rng(1000 * cid + n)
+    bases = walk_bases(cid, n, seed=cid)
+    sc = rand_scalars(rng, n, None)
+    assert gpu_msm_compressed(bzh2, gpu_ctx, cid, bases, sc) == oracle_compressed(cid, bases, sc)
+
+
+@pytest.mark.parametrize("cid", [0, 1])
+def test_msm_edge_cases(gpu_ctx, oracle_c, cid):
+    """zeros, ones, r-1, repeated points, P and -P, identity bases."""
+    import bzh2
+    cv = O.CURVE_BY_ID[cid]
+    r = cv.scalar.p
+    rng = random.Random(77 + cid)
+    pts = [cv.random_point(rng) for _ in range(24)]
+    pts += [pts[0], pts[0], cv.neg(pts[1]), None, pts[2]]
+    sc = [rng.randrange(r) for _ in pts]
+    sc[0], sc[24], sc[25] = 5, 5, r - 10          # same point thrice, scalars summing to 0 mod r
+    sc[1], sc[26] = 9, 9                           # P and -P with equal scalars cancel
+    sc[3], sc[4], sc[5], sc[6] = 0, 1, r - 1, 2
+    sc[27] = 12345                                 # scalar on the identity base
+    want = cv.compress(cv.msm_naive(sc, pts))
+    got = gpu_msm_compressed(bzh2, gpu_ctx, cid, C.points_to_array(pts), C.ints_to_array(sc))
+    assert got == [want]
+    # all-zero scalars -> identity (32 zero bytes); all-equal scalars hit a single bucket per window
+    z = np.zeros((len(pts), 4), dtype=np.uint64)
+    assert gpu_msm_compressed(bzh2, gpu_ctx, cid, C.points_to_array(pts), z) == [bytes(32)]
+    eq = C.ints_to_array([r - 1] * len(pts))
+    assert gpu_msm_compressed(bzh2, gpu_ctx, cid, C.points_to_array(pts), eq) == \
+        [cv.compress(cv.msm_naive([r - 1] * len(pts), pts))]
+
+
+def test_msm_empty_and_prefix(gpu_ctx, oracle_c):
+    import bzh2
+    bases = walk_bases(0, 64, seed=3)
+    b = gpu_ctx.upload_bases(0, bases)
+    try:
+        out = gpu_ctx.msm(b, np.zeros((0, 4), dtype=np.uint64))
+        assert (out == 0).all()                     # empty sum = identity (Z = 0)
+        rng = np.random.default_rng(4)
+        sc = rand_scalars(rng, 40, None)            # shorter than the table: prefix, like Params::commit
+        jac = gpu_ctx.msm(b, sc)
+        got = bzh2.affine_compress(0, bzh2.jacobian_to_affine(0, jac))
+        assert got == oracle_compressed(0, bases, sc)
+        with pytest.raises(bzh2.BzhError):          # longer than the table: upstream asserts
+            gpu_ctx.msm(b, rand_scalars(rng, 65, None))
+    finally:
+        b.free()
+
+
+def test_msm_batched_shared_bases_and_montgomery(gpu_ctx, oracle_c):
+    """28 scalar vectors against one table (the per-proof commit set), Montgomery in/out."""
+    import bzh2
+    n, batch = 2048, 28
+    rng = np.random.default_rng(5)
+    bases = walk_bases(0, n, seed=9)
+    sc = rand_scalars(rng, n * batch, None).reshape(batch, n, 4)
+    want = oracle_compressed(0, bases, sc)
+    assert gpu_msm_compressed(bzh2, gpu_ctx, 0, bases, sc) == want
+    R, p = O.FP.R, O.FP.p
+    sc_m = C.ints_to_array([x * R % p for x in C.array_to_ints(sc.reshape(-1, 4))]).reshape(batch, n, 4)
+    assert gpu_msm_compressed(bzh2, gpu_ctx, 0, bases, sc_m, form=bzh2.FORM_MONTGOMERY) == \
+        gpu_msm_compressed(bzh2, gpu_ctx, 0, bases, sc)  # same points (different coordinate form in, same bytes out)
+
+
+@pytest.mark.parametrize("log_n", [14, 16])
+def test_msm_medium_matches_oracle(gpu_ctx, oracle_c, log_n):
+    import bzh2
+    n = 1 << log_n
+    rng = np.random.default_rng(log_n)
+    bases = walk_bases(0, n, seed=log_n)
+    sc = rand_scalars(rng, n, None)
+    assert gpu_msm_compressed(bzh2, gpu_ctx, 0, bases, sc) == oracle_compressed(0, bases, sc)
+
+
+def test_msm_large_linearity(gpu_ctx, oracle_c):
+    """2^18 points (multi-chunk path): MSM(a) + MSM(b) == MSM(a+b) and chunk-wise additivity;
+    one half-size MSM is also checked against the oracle directly."""
+    import bzh2
+    n = 1 << 18
+    cv = O.VESTA
+    rng = np.random.default_rng(18)
+    bases = walk_bases(0, n, seed=18)
+    a = rand_scalars(rng, n, None)
+    b = rand_scalars(rng, n, None)
+    ai, bi = C.array_to_ints(a), C.array_to_ints(b)
+    ab = C.ints_to_array([(x + y) % O.P for x, y in zip(ai, bi)])
+    hb = gpu_ctx.upload_bases(0, bases)
+    try:
+        jac = gpu_ctx.msm(hb, np.stack([a, b, ab]))
+    finally:
+        hb.free()
+    pa, pb, pab = [C.array_to_point(x) for x in bzh2.jacobian_to_affine(0, jac)]
+    assert cv.add(pa, pb) == pab
+    half = n // 2
+    assert cv.compress(pa) != bytes(32)
+    lo = gpu_msm_compressed(bzh2, gpu_ctx, 0, bases[:half], a[:half])
+    assert lo == oracle_compressed(0, bases[:half], a[:half])
