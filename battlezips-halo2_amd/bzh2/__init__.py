@@ -40,7 +40,7 @@ CURVE_SCALAR_FIELD = {CURVE_VESTA: FIELD_FP, CURVE_PALLAS: FIELD_FQ, CURVE_BN254
 EXPORTS = [
     "bzh_version", "bzh_strerror", "bzh_device_count", "bzh_ctx_create", "bzh_ctx_create_on_stream",
     "bzh_ctx_destroy", "bzh_ctx_sync", "bzh_last_error", "bzh_ctx_profile", "bzh_ctx_timings",
-    "bzh_bases_upload", "bzh_bases_free", "bzh_bases_len", "bzh_msm", "bzh_ntt",
+    "bzh_bases_upload", "bzh_bases_precompute", "bzh_bases_free", "bzh_bases_len", "bzh_msm", "bzh_ntt",
     "bzh_jacobian_to_affine", "bzh_affine_compress", "bzh_field_omega",
 ]
 
@@ -81,6 +81,7 @@ def load():
     L.bzh_ctx_profile.argtypes = [vp, ctypes.c_int]
     L.bzh_ctx_timings.argtypes = [vp, ctypes.POINTER(ctypes.c_double), u64p]
     L.bzh_bases_upload.argtypes = [vp, ctypes.c_int, vp, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.POINTER(vp)]
+    L.bzh_bases_precompute.argtypes = [vp, vp, ctypes.c_int]
     L.bzh_bases_free.argtypes = [vp, vp]
     L.bzh_bases_len.argtypes = [vp]
     L.bzh_bases_len.restype = ctypes.c_size_t
@@ -123,6 +124,11 @@ class Bases:
 
     def __init__(self, ctx: "Context", handle, curve: int, n: int):
         self.ctx, self.handle, self.curve, self.n = ctx, handle, curve, n
+
+    def precompute(self, window_bits: int = 0):
+        """Expand into the fixed-base window table (bzh_bases_precompute)."""
+        self.ctx._check(load().bzh_bases_precompute(self.ctx.handle, self.handle, window_bits), "bzh_bases_precompute")
+        return self
 
     def free(self):
         if self.handle is not None:

@@ -269,6 +269,14 @@ int bzh_bases_free(bzh_ctx* ctx, bzh_bases* bases) {
 
 size_t bzh_bases_len(const bzh_bases* bases) { return bases ? bases->n : 0; }
 
+int bzh_bases_precompute(bzh_ctx* ctx, bzh_bases* bases, int window_bits) {
+    if (!ctx || !bases || window_bits < 0) return BZH_E_ARG;
+    if (bases->device != ctx->device) return BZH_E_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    BZH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return bases_precompute(ctx, bases, window_bits);
+}
+
 int bzh_msm(bzh_ctx* ctx, const bzh_bases* bases, const uint64_t* scalars, size_t n, size_t batch, int form, int mem,
             uint64_t* out_xyz) {
     if (!ctx || !bases || !out_xyz || (!scalars && n && batch) || !valid_form(form) || !valid_mem(mem)) return BZH_E_ARG;

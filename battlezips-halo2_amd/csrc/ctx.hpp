@@ -11,8 +11,10 @@
 struct bzh_bases {
     int curve = 0;
     size_t n = 0;
-    uint32_t* d_xy = nullptr;  // n x 16 u32: affine x||y, Montgomery form
+    uint32_t* d_xy = nullptr;  // affine x||y, Montgomery form: n points, or pre_nwin rows of n
     int device = 0;
+    int pre_c = 0;     // != 0: d_xy holds the window table, row w = 2^(pre_c * w) * G_i
+    int pre_nwin = 0;
 };
 
 struct bzh_ctx {
@@ -98,5 +100,6 @@ int msm_run(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_scalars, siz
 int ntt_run(bzh_ctx* ctx, int field, uint32_t* d_data, unsigned log_n, size_t batch, const uint64_t* omega,
             const uint64_t* coset_shift, int inverse, int form);
 int bases_to_montgomery(bzh_ctx* ctx, int curve, uint32_t* d_xy, size_t n);
+int bases_precompute(bzh_ctx* ctx, bzh_bases* bases, int window_bits);
 
 }  // namespace bzh

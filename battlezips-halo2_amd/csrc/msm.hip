@@ -35,22 +35,39 @@ struct MsmPlan {
 };
 
 static constexpr size_t kMaxChunk = 32768;
+static constexpr int kAccThreadsPlan = 256;
+
+// window size for a precomputed table of n points: every window becomes a separate
+// row of the table (2^(cw) G_i), so one MSM is a single-window problem over nwin*n points.
+static int plan_precompute_c(size_t n) {
+    double best = 1e300;
+    int best_c = 9;
+    for (int c = 6; c <= 13; c++) {
+        int nwin = (256 + c - 1) / c;
+        double E = (double)nwin * (double)n, M = (double)(1u << (c - 1));
+        double chunks = ceil(E / (double)kMaxChunk);
+        double cost = E * 10.0 + chunks * (M * 38.0 + 3000.0);
+        if (cost < best) {
+            best = cost;
+            best_c = c;
+        }
+    }
+    return best_c;
+}
 
 static MsmPlan plan_msm(size_t n) {
     MsmPlan p;
     p.chunk = n < kMaxChunk ? (n ? n : 1) : kMaxChunk;
     p.nchunks = n ? (n + p.chunk - 1) / p.chunk : 1;
-    // cost model (units: field multiplications per segment): thread-per-bucket
-    // accumulation with Poisson imbalance over a 64-lane wave + 2 full additions
-    // per bucket in the reduction.
+    // cost model (units: field multiplications per segment): balanced accumulation
+    // (10 per point, one lost slot per bucket start) + 2 full additions per bucket in
+    // the reduction + fixed per-segment overhead (sort, stitch, tree sums).
     double best = 1e300;
     int best_c = 4;
     for (int c = 3; c <= 15; c++) {
         int nwin = (256 + c - 1) / c;
         double M = (double)(1u << (c - 1));
-        double lam = (double)p.chunk / M;
-        double eff = lam / (lam + 2.5 * sqrt(lam) + 1.0);
-        double cost = nwin * ((double)p.chunk * 10.0 / eff + M * 28.0 + 400.0);
+        double cost = nwin * ((double)p.chunk * 10.0 + M * (10.0 + 28.0) + 3000.0);
         if (cost < best) {
             best = cost;
             best_c = c;
@@ -59,8 +76,7 @@ static MsmPlan plan_msm(size_t n) {
     p.c = best_c;
     p.nwin = (256 + p.c - 1) / p.c;
     p.M = 1 << (p.c - 1);
-    int t = p.M < 64 ? 64 : (p.M > 1024 ? 1024 : p.M);
-    p.threads = t;
+    p.threads = kAccThreadsPlan;
     return p;
 }
 
@@ -182,32 +198,54 @@ __device__ __forceinline__ void block_exclusive_scan(uint32_t* a, int len, uint3
 }
 
 // ---------------------------------------------------------------------------
-// k_msm_accumulate: grid (nchunks, nwin, batch).  Dynamic LDS:
-//   cnt[M + 2] u32 | scratch[32] u32 | sorted[chunk] u16
+// k_msm_accumulate: grid (nchunks, nwin, batch), kAccThreads threads.  Dynamic LDS:
+//   cnt[M + 2] u32 | scratch[32] u32 | idB[T] u32 | sorted[chunk] u16
+//
+// After the LDS counting sort the bucket-sorted point list is cut into T equal slices, one
+// per thread, whatever the bucket boundaries are: every lane performs the same number of
+// mixed additions, so skewed digits (the top window holds only 0/1/2, adversarial inputs put
+// every point in one bucket) cost nothing extra.  A bucket that lies inside one slice is
+// summed and stored by that thread.  A bucket cut by slice boundaries leaves per-thread
+// partial sums: the thread where it starts keeps a tail partial A, every later thread a head
+// partial B; B is suffix-reduced per bucket across threads (Hillis-Steele over a global
+// scratch pair, log2(span) steps) and the starting thread stores A + B'.
 // ---------------------------------------------------------------------------
+static constexpr int kAccThreads = 256;
+
 template <class C>
-__global__ void __launch_bounds__(1024) k_msm_accumulate(const uint32_t* __restrict__ bases,
-                                                           const uint16_t* __restrict__ digits, size_t n, int nwin, int M,
-                                                           size_t chunk, uint4* __restrict__ buckets) {
+__global__ void __launch_bounds__(kAccThreads) k_msm_accumulate(const uint32_t* __restrict__ bases,
+                                                                  const uint16_t* __restrict__ digits, size_t n, int nwin,
+                                                                  int M, size_t chunk, uint4* __restrict__ buckets,
+                                                                  uint4* __restrict__ partials, size_t row_len,
+                                                                  size_t row_stride) {
     using P = typename C::Base;
+    constexpr int T = kAccThreads;
     extern __shared__ __align__(16) uint32_t lds[];
     uint32_t* cnt = lds;  // index m in [0, M]; cnt[0] stays 0
     uint32_t* scratch = lds + (M + 2);
-    uint16_t* sorted = reinterpret_cast<uint16_t*>(scratch + 32);
+    uint32_t* idB = scratch + 32;
+    uint16_t* sorted = reinterpret_cast<uint16_t*>(idB + T);
 
-    const int tid = threadIdx.x, T = blockDim.x;
+    const int tid = threadIdx.x;
     const size_t ck = blockIdx.x, w = blockIdx.y, b = blockIdx.z, nchunks = gridDim.x;
     const size_t c0 = ck * chunk;
     const int len = (int)min(chunk, n - c0);
     const uint16_t* dg = digits + (b * (size_t)nwin + w) * n + c0;
 
     for (int i = tid; i < M + 2; i += T) cnt[i] = 0;
+    if (tid == 0) scratch[31] = 0;  // max bucket population
     __syncthreads();
     for (int i = tid; i < len; i += T) {
         uint32_t m = dg[i] & 0x7fffu;
         if (m) atomicAdd(&cnt[m], 1u);
     }
     __syncthreads();
+    {
+        uint32_t mx = 0;
+        for (int i = 1 + tid; i <= M; i += T) mx = max(mx, cnt[i]);
+        for (int d = 32; d >= 1; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
+        if ((tid & 63) == 0) atomicMax(&scratch[31], mx);
+    }
     block_exclusive_scan(cnt, M + 1, scratch);
     for (int i = tid; i < len; i += T) {
         uint32_t d = dg[i], m = d & 0x7fffu;
@@ -217,20 +255,105 @@ __global__ void __launch_bounds__(1024) k_msm_accumulate(const uint32_t* __restr
         }
     }
     __syncthreads();
-    // now bucket m owns sorted[cnt[m-1] .. cnt[m])
-    uint4* seg = buckets + (((b * (size_t)nwin + w) * nchunks + ck) * (size_t)M) * 8;
+    // bucket m owns sorted[cnt[m-1] .. cnt[m]); cnt[M] = number of non-zero digits
+    const size_t segi = (b * (size_t)nwin + w) * nchunks + ck;
+    uint4* seg = buckets + segi * (size_t)M * 8;
+    uint4* pbuf0 = partials + segi * (size_t)(2 * T) * 8;
+    uint4* pbuf1 = pbuf0 + (size_t)T * 8;
+    // Precomputed tables: item e of the flattened [window][point] digit array addresses row
+    // e / row_len, column e % row_len of a table whose rows are row_stride points apart
+    // (row_len < row_stride when a prefix of the table is used).  row_len == 0: plain bases.
+    const bool remap = row_len != 0 && row_len != row_stride;
     const uint32_t* base0 = bases + c0 * 16;
-    for (int m = 1 + tid; m <= M; m += T) {
-        Xyzz<P> acc = xyzz_identity<P>();
-        const uint32_t lo = cnt[m - 1], hi = cnt[m];
-        for (uint32_t j = lo; j < hi; j++) {
-            uint32_t e = sorted[j];
-            Affine<P> q = affine_load<P>(base0 + (size_t)(e & 0x7fffu) * 16);
-            if (aff_is_id(q)) continue;
-            if (e & 0x8000u) q.y = fe_neg(q.y);
-            xyzz_madd(acc, q);
+    const uint32_t total = cnt[M], maxpop = scratch[31];
+    const uint32_t L = (total + T - 1) / T;
+    const uint32_t start = min((uint32_t)tid * L, total), end = min(start + L, total);
+
+    // empty buckets are the identity
+    for (int m = 1 + tid; m <= M; m += T)
+        if (cnt[m] == cnt[m - 1]) planes_put(seg, (size_t)M, (size_t)(m - 1), xyzz_identity<P>());
+
+    Xyzz<P> acc = xyzz_identity<P>();
+    Xyzz<P> headv = xyzz_identity<P>();
+    uint32_t head_id = 0, tail_id = 0;  // tail_id: bucket whose sum continues in later threads (acc = A)
+    bool tail_through = false;          // ... and that had also begun before this slice (A is the identity)
+    if (start < end) {
+        // first bucket with cnt[m] > start
+        uint32_t lo = 1, hi = (uint32_t)M;
+        while (lo < hi) {
+            uint32_t mid = (lo + hi) >> 1;
+            if (cnt[mid] > start) hi = mid; else lo = mid + 1;
         }
-        planes_put(seg, (size_t)M, (size_t)(m - 1), acc);
+        uint32_t m = lo, bbeg = cnt[m - 1], bend = cnt[m];
+        for (uint32_t j = start; j < end; j++) {
+            if (j == bend) {  // bucket m ended inside this slice
+                if (bbeg < start) {
+                    headv = acc;
+                    head_id = m;
+                } else {
+                    planes_put(seg, (size_t)M, (size_t)(m - 1), acc);
+                }
+                acc = xyzz_identity<P>();
+                do { m++; } while (cnt[m] <= j);
+                bbeg = cnt[m - 1];
+                bend = cnt[m];
+            }
+            const uint32_t e = sorted[j];
+            size_t pidx = (size_t)(e & 0x7fffu);
+            if (remap) {
+                const size_t g = c0 + pidx, row = g / row_len;
+                pidx = row * row_stride + (g - row * row_len) - c0;
+            }
+            Affine<P> q = affine_load<P>(base0 + pidx * 16);
+            if (!aff_is_id(q)) {
+                if (e & 0x8000u) q.y = fe_neg(q.y);
+                xyzz_madd(acc, q);
+            }
+        }
+        // last segment of the slice: bucket m, items [max(bbeg,start), min(bend,end))
+        if (bend > end) {
+            tail_id = m;
+            if (bbeg < start) {  // neither begins nor ends here
+                headv = acc;
+                head_id = m;
+                acc = xyzz_identity<P>();
+                tail_through = true;
+            }
+        } else if (bbeg < start) {
+            headv = acc;
+            head_id = m;
+        } else {
+            planes_put(seg, (size_t)M, (size_t)(m - 1), acc);
+        }
+    }
+    // ---- stitch buckets cut by slice boundaries (uniform control flow from here) ----
+    idB[tid] = head_id;
+    __syncthreads();
+    uint32_t span = L ? (maxpop + L - 1) / L + 1 : 1;  // a bucket touches at most this many slices
+    if (span > (uint32_t)T) span = (uint32_t)T;
+    if (span > 1) {
+        uint4* cur = pbuf0;
+        uint4* nxt = pbuf1;
+        planes_put(cur, (size_t)T, (size_t)tid, headv);
+        for (uint32_t d = 1; d < span; d <<= 1) {
+            __syncthreads();
+            if (head_id && tid + d < (uint32_t)T && idB[tid + d] == head_id) {
+                Xyzz<P> o = planes_get<P>(cur, (size_t)T, (size_t)(tid + d));
+                xyzz_add(headv, o);
+            }
+            planes_put(nxt, (size_t)T, (size_t)tid, headv);
+            uint4* tmp = cur;
+            cur = nxt;
+            nxt = tmp;
+        }
+        __syncthreads();
+        if (tail_id && !tail_through) {  // this thread holds the start of a cut bucket: finish it
+            if (tid + 1 < T && idB[tid + 1] == tail_id) {
+                Xyzz<P> o = planes_get<P>(cur, (size_t)T, (size_t)(tid + 1));
+                xyzz_add(acc, o);
+            }
+            planes_put(seg, (size_t)M, (size_t)(tail_id - 1), acc);
+        }
     }
 }
 
@@ -350,6 +473,28 @@ __global__ void __launch_bounds__(256) k_to_montgomery(uint32_t* data, size_t co
 }
 
 // ---------------------------------------------------------------------------
+// k_expand_bases: table[w*n + i] = 2^(c*w) * G_i, affine, for w = 1..nwin-1 (row 0 is the
+// input).  One thread per point walks the rows: c doublings in XYZZ, then back to affine.
+// ---------------------------------------------------------------------------
+template <class C>
+__global__ void __launch_bounds__(256) k_expand_bases(uint32_t* __restrict__ table, size_t n, int c, int nwin) {
+    using P = typename C::Base;
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Affine<P> p = affine_load<P>(table + i * 16);
+    for (int w = 1; w < nwin; w++) {
+        if (!aff_is_id(p)) {
+            Xyzz<P> q = xyzz_dbl_affine(p);
+            for (int k = 1; k < c; k++) q = xyzz_dbl(q);
+            p = xyzz_to_affine(q);
+        }
+        uint32_t* o = table + ((size_t)w * n + i) * 16;
+        fe_store(o, p.x);
+        fe_store(o + 8, p.y);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // host driver
 // ---------------------------------------------------------------------------
 template <class C, class SF>
@@ -359,12 +504,26 @@ static int msm_run_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_sca
         BZH_HIP_TRY(ctx, hipMemsetAsync(d_out, 0, batch * 96, ctx->stream));
         return BZH_OK;
     }
-    const MsmPlan p = plan_msm(n);
+    MsmPlan p = plan_msm(n);
+    const bool pre = bases->pre_c != 0;
+    size_t n_eff = n, row_len = 0, row_stride = 0;
+    int acc_nwin = 0;
+    if (pre) {  // one window over the flattened [window][point] item space
+        p.c = bases->pre_c;
+        p.nwin = bases->pre_nwin;
+        p.M = 1 << (p.c - 1);
+        n_eff = (size_t)p.nwin * n;
+        p.chunk = n_eff < kMaxChunk ? n_eff : kMaxChunk;
+        p.nchunks = (n_eff + p.chunk - 1) / p.chunk;
+        row_len = n;
+        row_stride = bases->n;
+    }
+    acc_nwin = pre ? 1 : p.nwin;
     // slice the batch so the bucket workspace stays bounded
     const size_t seg_bytes = (size_t)p.M * 128;
-    const size_t segs_per_vec = (size_t)p.nwin * p.nchunks;
+    const size_t segs_per_vec = (size_t)acc_nwin * p.nchunks;
     const size_t budget = (size_t)2 << 30;
-    size_t slice = budget / (segs_per_vec * seg_bytes);
+    size_t slice = budget / (segs_per_vec * (seg_bytes + (size_t)2 * 256 * 128));
     if (slice < 1) slice = 1;
     if (slice > batch) slice = batch;
     if (slice > 65535) slice = 65535;  // gridDim.z
@@ -377,12 +536,14 @@ static int msm_run_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_sca
     }
 
     void *d_digits = nullptr, *d_buckets = nullptr, *d_winsums = nullptr;
+    const size_t part_bytes = (size_t)2 * kAccThreads * 128;  // per segment: two stitch buffers
     int rc;
     if ((rc = ws_ensure(ctx, 0, slice * (size_t)p.nwin * n * sizeof(uint16_t), &d_digits))) return rc;
-    if ((rc = ws_ensure(ctx, 1, slice * segs_per_vec * seg_bytes, &d_buckets))) return rc;
+    if ((rc = ws_ensure(ctx, 1, slice * segs_per_vec * (seg_bytes + part_bytes), &d_buckets))) return rc;
+    uint4* d_partials = (uint4*)((char*)d_buckets + slice * segs_per_vec * seg_bytes);
     if ((rc = ws_ensure(ctx, 2, slice * segs_per_vec * 128, &d_winsums))) return rc;
 
-    const size_t acc_lds = ((size_t)p.M + 2 + 32) * 4 + p.chunk * 2 + 16;
+    const size_t acc_lds = ((size_t)p.M + 2 + 32 + kAccThreads) * 4 + p.chunk * 2 + 16;
     int red_threads = p.M < 256 ? p.M : 256;
     const size_t red_lds = (size_t)red_threads * 128 * 2;
     static bool attr_set[3] = {false, false, false};
@@ -404,9 +565,9 @@ static int msm_run_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_sca
         }
         {
             ScopedTimer t(ctx, BZH_T_MSM_ACCUMULATE);
-            hipLaunchKernelGGL((k_msm_accumulate<C>), dim3((unsigned)p.nchunks, (unsigned)p.nwin, (unsigned)nb),
-                               dim3(p.threads), acc_lds, ctx->stream, bases->d_xy, (const uint16_t*)d_digits, n, p.nwin,
-                               p.M, p.chunk, (uint4*)d_buckets);
+            hipLaunchKernelGGL((k_msm_accumulate<C>), dim3((unsigned)p.nchunks, (unsigned)acc_nwin, (unsigned)nb),
+                               dim3(p.threads), acc_lds, ctx->stream, bases->d_xy, (const uint16_t*)d_digits, n_eff,
+                               acc_nwin, p.M, p.chunk, (uint4*)d_buckets, d_partials, row_len, row_stride);
         }
         const size_t nseg = nb * segs_per_vec;
         {
@@ -417,7 +578,7 @@ static int msm_run_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_sca
         {
             ScopedTimer t(ctx, BZH_T_MSM_FINALIZE);
             hipLaunchKernelGGL((k_msm_finalize<C>), dim3((unsigned)nb), dim3(64), 0, ctx->stream,
-                               (const uint4*)d_winsums, nseg, p.nwin, p.nchunks, p.c, form, d_out + b0 * 24);
+                               (const uint4*)d_winsums, nseg, acc_nwin, p.nchunks, pre ? 0 : p.c, form, d_out + b0 * 24);
         }
         BZH_HIP_TRY(ctx, hipGetLastError());
     }
@@ -433,6 +594,35 @@ int msm_run(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_scalars, siz
             return msm_run_t<PallasCurve, FqParams>(ctx, bases, d_scalars, n, batch, form, d_out_xyz);
         case BZH_CURVE_BN254:
             return msm_run_t<Bn254Curve, BnFrParams>(ctx, bases, d_scalars, n, batch, form, d_out_xyz);
+    }
+    return BZH_E_ARG;
+}
+
+template <class C>
+static int bases_precompute_t(bzh_ctx* ctx, bzh_bases* b, int c) {
+    const int nwin = (256 + c - 1) / c;
+    uint32_t* table = nullptr;
+    BZH_HIP_TRY(ctx, hipMalloc((void**)&table, (size_t)nwin * b->n * 64));
+    BZH_HIP_TRY(ctx, hipMemcpyAsync(table, b->d_xy, b->n * 64, hipMemcpyDeviceToDevice, ctx->stream));
+    hipLaunchKernelGGL((k_expand_bases<C>), dim3((unsigned)((b->n + 255) / 256)), dim3(256), 0, ctx->stream, table, b->n, c,
+                       nwin);
+    BZH_HIP_TRY(ctx, hipGetLastError());
+    BZH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    BZH_HIP_TRY(ctx, hipFree(b->d_xy));
+    b->d_xy = table;
+    b->pre_c = c;
+    b->pre_nwin = nwin;
+    return BZH_OK;
+}
+
+int bases_precompute(bzh_ctx* ctx, bzh_bases* b, int window_bits) {
+    if (b->pre_c != 0 || b->n == 0) return BZH_OK;
+    int c = window_bits ? window_bits : plan_precompute_c(b->n);
+    if (c < 4 || c > 15) return BZH_E_RANGE;
+    switch (b->curve) {
+        case BZH_CURVE_VESTA: return bases_precompute_t<VestaCurve>(ctx, b, c);
+        case BZH_CURVE_PALLAS: return bases_precompute_t<PallasCurve>(ctx, b, c);
+        case BZH_CURVE_BN254: return bases_precompute_t<Bn254Curve>(ctx, b, c);
     }
     return BZH_E_ARG;
 }

@@ -103,6 +103,12 @@ int bzh_ctx_timings(bzh_ctx* ctx, double* ms, uint64_t* launches);
  * across many MSMs: n affine points are copied to HBM once (converted to
  * Montgomery form if needed) and referenced by handle afterwards. */
 int bzh_bases_upload(bzh_ctx* ctx, int curve, const uint64_t* xy, size_t n, int form, int mem, bzh_bases** out);
+/* Expand a table in place into the fixed-base window table  row w = 2^(c*w) * G_i  (w < ceil(256/c)),
+ * c = window_bits or 0 for the library's choice.  Worth it for tables that serve many MSMs (the SRS:
+ * every commitment of every proof uses Params.g or Params.g_lagrange): all windows of an MSM then
+ * share one bucket set and the final doubling chain disappears.  Costs ceil(256/c) x the table's HBM
+ * (k=14: 25 MB) and a one-time build; results are identical with or without it. */
+int bzh_bases_precompute(bzh_ctx* ctx, bzh_bases* bases, int window_bits);
 int bzh_bases_free(bzh_ctx* ctx, bzh_bases* bases);
 size_t bzh_bases_len(const bzh_bases* bases);
 

@@ -24,8 +24,10 @@ def walk_bases(cid, n, seed):
     return C.point_walk(cid, C.points_to_array([g])[0], n)
 
 
-def gpu_msm_compressed(bzh2, ctx, cid, bases_np, scalars_np, form=0):
+def gpu_msm_compressed(bzh2, ctx, cid, bases_np, scalars_np, form=0, precompute=None):
     b = ctx.upload_bases(cid, bases_np)
+    if precompute is not None:
+        b.precompute(precompute)
     try:
         jac = ctx.msm(b, scalars_np, form=form)
     finally:
@@ -144,3 +146,53 @@ def test_msm_large_linearity(gpu_ctx, oracle_c):
     assert cv.compress(pa) != bytes(32)
     lo = gpu_msm_compressed(bzh2, gpu_ctx, 0, bases[:half], a[:half])
     assert lo == oracle_compressed(0, bases[:half], a[:half])
+
+
+@pytest.mark.parametrize("cid", [0, 1, 2])
+@pytest.mark.parametrize("n,c", [(1, 0), (3, 5), (257, 0), (2048, 0), (2048, 8), (5000, 11)])
+def test_msm_precomputed_table_matches_oracle(gpu_ctx, oracle_c, cid, n, c):
+    """bzh_bases_precompute (fixed-base window table) must not change a single byte."""
+    import bzh2
+    rng = np.random.default_rng(7000 * cid + n + c)
+    bases = walk_bases(cid, n, seed=40 + cid)
+    sc = rand_scalars(rng, n, None)
+    want = oracle_compressed(cid, bases, sc)
+    assert gpu_msm_compressed(bzh2, gpu_ctx, cid, bases, sc, precompute=c) == want
+
+
+def test_msm_precomputed_prefix_batch_and_edges(gpu_ctx, oracle_c):
+    """Window table + (a) MSMs over a prefix of the table, (b) a batch, (c) skewed digits:
+    all-equal scalars, r-1, 0, 1, and the identity as a base."""
+    import bzh2
+    cv = O.VESTA
+    r = cv.scalar.p
+    n = 3000
+    rng = np.random.default_rng(99)
+    bases = walk_bases(0, n, seed=77)
+    bases[17] = 0                                   # identity base
+    hb = gpu_ctx.upload_bases(0, bases).precompute()
+    try:
+        for m in (1, 2, 1000, 2999, 3000):          # prefixes (row_len != row_stride)
+            sc = rand_scalars(rng, m, None)
+            jac = gpu_ctx.msm(hb, sc)
+            got = bzh2.affine_compress(0, bzh2.jacobian_to_affine(0, jac))
+            assert got == oracle_compressed(0, bases, sc), m
+        batch = np.stack([rand_scalars(rng, n, None) for _ in range(5)])
+        batch[1] = C.ints_to_array([r - 1] * n)     # every digit identical: one bucket per window
+        batch[2] = 0
+        batch[3] = C.ints_to_array([1] * n)
+        jac = gpu_ctx.msm(hb, batch)
+        got = bzh2.affine_compress(0, bzh2.jacobian_to_affine(0, jac))
+        assert got == oracle_compressed(0, bases, batch)
+        assert got[2] == bytes(32)
+    finally:
+        hb.free()
+
+
+def test_msm_precomputed_2_16_matches_oracle(gpu_ctx, oracle_c):
+    import bzh2
+    n = 1 << 16
+    rng = np.random.default_rng(16)
+    bases = walk_bases(0, n, seed=16)
+    sc = rand_scalars(rng, n, None)
+    assert gpu_msm_compressed(bzh2, gpu_ctx, 0, bases, sc, precompute=0) == oracle_compressed(0, bases, sc)
