@@ -198,7 +198,7 @@ __device__ __forceinline__ void block_exclusive_scan(uint32_t* a, int len, uint3
 }
 
 // ---------------------------------------------------------------------------
-// k_msm_accumulate: grid (nchunks, nwin, batch), kAccThreads threads.  Dynamic LDS:
+// k_msm_accumulate: grid (nchunks, nwin, batch), T threads.  Dynamic LDS:
 //   cnt[M + 2] u32 | scratch[32] u32 | idB[T] u32 | sorted[chunk] u16
 //
 // After the LDS counting sort the bucket-sorted point list is cut into T equal slices, one
@@ -210,16 +210,13 @@ __device__ __forceinline__ void block_exclusive_scan(uint32_t* a, int len, uint3
 // partial B; B is suffix-reduced per bucket across threads (Hillis-Steele over a global
 // scratch pair, log2(span) steps) and the starting thread stores A + B'.
 // ---------------------------------------------------------------------------
-static constexpr int kAccThreads = 256;
-
-template <class C>
-__global__ void __launch_bounds__(kAccThreads) k_msm_accumulate(const uint32_t* __restrict__ bases,
+template <class C, int T>
+__global__ void __launch_bounds__(T) k_msm_accumulate(const uint32_t* __restrict__ bases,
                                                                   const uint16_t* __restrict__ digits, size_t n, int nwin,
                                                                   int M, size_t chunk, uint4* __restrict__ buckets,
                                                                   uint4* __restrict__ partials, size_t row_len,
                                                                   size_t row_stride) {
     using P = typename C::Base;
-    constexpr int T = kAccThreads;
     extern __shared__ __align__(16) uint32_t lds[];
     uint32_t* cnt = lds;  // index m in [0, M]; cnt[0] stays 0
     uint32_t* scratch = lds + (M + 2);
@@ -274,7 +271,6 @@ __global__ void __launch_bounds__(kAccThreads) k_msm_accumulate(const uint32_t* 
         if (cnt[m] == cnt[m - 1]) planes_put(seg, (size_t)M, (size_t)(m - 1), xyzz_identity<P>());
 
     Xyzz<P> acc = xyzz_identity<P>();
-    Xyzz<P> headv = xyzz_identity<P>();
     uint32_t head_id = 0, tail_id = 0;  // tail_id: bucket whose sum continues in later threads (acc = A)
     bool tail_through = false;          // ... and that had also begun before this slice (A is the identity)
     if (start < end) {
@@ -287,8 +283,8 @@ __global__ void __launch_bounds__(kAccThreads) k_msm_accumulate(const uint32_t* 
         uint32_t m = lo, bbeg = cnt[m - 1], bend = cnt[m];
         for (uint32_t j = start; j < end; j++) {
             if (j == bend) {  // bucket m ended inside this slice
-                if (bbeg < start) {
-                    headv = acc;
+                if (bbeg < start) {  // head partial: parked in the stitch buffer, not in registers
+                    planes_put(pbuf0, (size_t)T, (size_t)tid, acc);
                     head_id = m;
                 } else {
                     planes_put(seg, (size_t)M, (size_t)(m - 1), acc);
@@ -314,13 +310,13 @@ __global__ void __launch_bounds__(kAccThreads) k_msm_accumulate(const uint32_t* 
         if (bend > end) {
             tail_id = m;
             if (bbeg < start) {  // neither begins nor ends here
-                headv = acc;
+                planes_put(pbuf0, (size_t)T, (size_t)tid, acc);
                 head_id = m;
                 acc = xyzz_identity<P>();
                 tail_through = true;
             }
         } else if (bbeg < start) {
-            headv = acc;
+            planes_put(pbuf0, (size_t)T, (size_t)tid, acc);
             head_id = m;
         } else {
             planes_put(seg, (size_t)M, (size_t)(m - 1), acc);
@@ -334,7 +330,8 @@ __global__ void __launch_bounds__(kAccThreads) k_msm_accumulate(const uint32_t* 
     if (span > 1) {
         uint4* cur = pbuf0;
         uint4* nxt = pbuf1;
-        planes_put(cur, (size_t)T, (size_t)tid, headv);
+        Xyzz<P> headv = xyzz_identity<P>();
+        if (head_id) headv = planes_get<P>(cur, (size_t)T, (size_t)tid);  // own store, same thread
         for (uint32_t d = 1; d < span; d <<= 1) {
             __syncthreads();
             if (head_id && tid + d < (uint32_t)T && idB[tid + d] == head_id) {
@@ -513,7 +510,25 @@ static int msm_run_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_sca
         p.nwin = bases->pre_nwin;
         p.M = 1 << (p.c - 1);
         n_eff = (size_t)p.nwin * n;
-        p.chunk = n_eff < kMaxChunk ? n_eff : kMaxChunk;
+        // Chunk count: at least ceil(n_eff / 32768) (u16 local index), more when that fills the chip's
+        // CUs more evenly -- the launch's makespan is ceil(workgroups / CUs) rounds of `chunk` additions
+        // plus, per extra chunk, one more bucket set to reduce (2 full additions per bucket).
+        const size_t cmin = (n_eff + kMaxChunk - 1) / kMaxChunk;
+        const double cus = (double)(ctx->num_cu > 0 ? ctx->num_cu : 256);
+        double best = 1e300;
+        size_t best_nc = cmin;
+        for (size_t nc = cmin; nc <= cmin * 8 && nc <= n_eff; nc++) {
+            const double chunk = ceil((double)n_eff / (double)nc);
+            const double rounds = ceil((double)(nc * batch) / cus);
+            const double t = rounds * (chunk * 10.0 + (double)p.M * 38.0 + 6000.0);
+            if (t < best * 0.999) {
+                best = t;
+                best_nc = nc;
+            }
+        }
+        p.nchunks = best_nc;
+        p.chunk = (n_eff + p.nchunks - 1) / p.nchunks;
+        p.chunk = (p.chunk + 63) & ~(size_t)63;
         p.nchunks = (n_eff + p.chunk - 1) / p.chunk;
         row_len = n;
         row_stride = bases->n;
@@ -523,7 +538,7 @@ static int msm_run_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_sca
     const size_t seg_bytes = (size_t)p.M * 128;
     const size_t segs_per_vec = (size_t)acc_nwin * p.nchunks;
     const size_t budget = (size_t)2 << 30;
-    size_t slice = budget / (segs_per_vec * (seg_bytes + (size_t)2 * 256 * 128));
+    size_t slice = budget / (segs_per_vec * (seg_bytes + (size_t)2 * 1024 * 128));
     if (slice < 1) slice = 1;
     if (slice > batch) slice = batch;
     if (slice > 65535) slice = 65535;  // gridDim.z
@@ -536,19 +551,28 @@ static int msm_run_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_sca
     }
 
     void *d_digits = nullptr, *d_buckets = nullptr, *d_winsums = nullptr;
-    const size_t part_bytes = (size_t)2 * kAccThreads * 128;  // per segment: two stitch buffers
+    // more threads per segment when there are few segments (occupancy), fewer when there are many
+    const size_t est_wgs = segs_per_vec * slice;
+    (void)est_wgs;
+    // ~200 VGPRs per lane: 2 waves/SIMD, so 512 threads = one workgroup per CU; 1024 would spill
+    const int acc_threads = p.chunk >= 8192 ? 512 : 256;
+    const size_t part_bytes = (size_t)2 * acc_threads * 128;  // per segment: two stitch buffers
     int rc;
     if ((rc = ws_ensure(ctx, 0, slice * (size_t)p.nwin * n * sizeof(uint16_t), &d_digits))) return rc;
     if ((rc = ws_ensure(ctx, 1, slice * segs_per_vec * (seg_bytes + part_bytes), &d_buckets))) return rc;
     uint4* d_partials = (uint4*)((char*)d_buckets + slice * segs_per_vec * seg_bytes);
     if ((rc = ws_ensure(ctx, 2, slice * segs_per_vec * 128, &d_winsums))) return rc;
 
-    const size_t acc_lds = ((size_t)p.M + 2 + 32 + kAccThreads) * 4 + p.chunk * 2 + 16;
+    const size_t acc_lds = ((size_t)p.M + 2 + 32 + acc_threads) * 4 + p.chunk * 2 + 16;
     int red_threads = p.M < 256 ? p.M : 256;
     const size_t red_lds = (size_t)red_threads * 128 * 2;
     static bool attr_set[3] = {false, false, false};
     if (!attr_set[C::id]) {
-        BZH_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msm_accumulate<C>),
+        BZH_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msm_accumulate<C, 256>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        BZH_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msm_accumulate<C, 512>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        BZH_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msm_accumulate<C, 1024>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         BZH_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msm_reduce<C>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
@@ -565,9 +589,15 @@ static int msm_run_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_sca
         }
         {
             ScopedTimer t(ctx, BZH_T_MSM_ACCUMULATE);
-            hipLaunchKernelGGL((k_msm_accumulate<C>), dim3((unsigned)p.nchunks, (unsigned)acc_nwin, (unsigned)nb),
-                               dim3(p.threads), acc_lds, ctx->stream, bases->d_xy, (const uint16_t*)d_digits, n_eff,
-                               acc_nwin, p.M, p.chunk, (uint4*)d_buckets, d_partials, row_len, row_stride);
+            const dim3 grid((unsigned)p.nchunks, (unsigned)acc_nwin, (unsigned)nb);
+#define BZH_LAUNCH_ACC(TT)                                                                                              \
+    hipLaunchKernelGGL((k_msm_accumulate<C, TT>), grid, dim3(TT), acc_lds, ctx->stream, bases->d_xy,                      \
+                       (const uint16_t*)d_digits, n_eff, acc_nwin, p.M, p.chunk, (uint4*)d_buckets, d_partials, row_len, \
+                       row_stride)
+            if (acc_threads == 1024) BZH_LAUNCH_ACC(1024);
+            else if (acc_threads == 512) BZH_LAUNCH_ACC(512);
+            else BZH_LAUNCH_ACC(256);
+#undef BZH_LAUNCH_ACC
         }
         const size_t nseg = nb * segs_per_vec;
         {

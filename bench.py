@@ -161,7 +161,11 @@ def cpu_baseline(workload_name, k):
     import coracle as C
     import pasta as O
     import random
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))  # the 1-GPU box's CPU share; more threads only shrink the per-thread windows
     n, ext = 1 << k, 1 << (k + 3)
     rng = np.random.default_rng(99)
 
@@ -227,8 +231,8 @@ def main():
     for _ in range(args.steps):
         wl.step()
     if dist is not None:  # the one collective: gather every rank's commitments (fixed-stride records)
-        gathered = [torch.empty_like(wl.result) for _ in range(world)]
-        dist.all_gather(gathered, wl.result)
+        from bzh2.shard import gather_records
+        gathered = gather_records(wl.result, [wl.result.shape[0]] * world, dist)
     barrier()
     elapsed = time.perf_counter() - t0
     timings = ctx.timings()
