@@ -265,3 +265,96 @@ def field_omega(field: int, log_n: int, form: int = FORM_CANONICAL) -> np.ndarra
     if rc != OK:
         raise BzhError(rc, "bzh_field_omega")
     return out
+
+
+# ---- prover-stage vector primitives (host-buffer forms; see include/bzh2.h) --------------------
+def _vp(a: np.ndarray):
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+def _bind_poly(L):
+    vp = ctypes.c_void_p
+    L.bzh_batch_invert.argtypes = [vp, ctypes.c_int, vp, ctypes.c_size_t, ctypes.c_int, ctypes.c_int]
+    L.bzh_prefix_product.argtypes = [vp, ctypes.c_int, vp, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_int]
+    L.bzh_eval_polynomial.argtypes = [vp, ctypes.c_int, vp, ctypes.c_size_t, ctypes.c_size_t, vp, ctypes.c_size_t, ctypes.c_int,
+                                      ctypes.c_int, vp]
+    L.bzh_inner_product.argtypes = [vp, ctypes.c_int, vp, vp, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, vp]
+    L.bzh_fold.argtypes = [vp, ctypes.c_int, vp, ctypes.c_size_t, ctypes.c_size_t, vp, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, vp]
+    L.bzh_vec_mul.argtypes = [vp, ctypes.c_int, vp, vp, ctypes.c_size_t, ctypes.c_int, ctypes.c_int]
+
+
+EXPORTS += ["bzh_batch_invert", "bzh_prefix_product", "bzh_eval_polynomial", "bzh_inner_product", "bzh_fold", "bzh_vec_mul"]
+TIMER_NAMES[5] = "poly"
+
+
+def _as_elems(a):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    assert a.shape[-1] == 4
+    return a
+
+
+def _ctx_batch_invert(self, field: int, data, form: int = FORM_CANONICAL) -> np.ndarray:
+    a = _as_elems(data).copy()
+    _bind_poly(load())
+    self._check(load().bzh_batch_invert(self.handle, field, _vp(a), a.size // 4, form, MEM_HOST), "bzh_batch_invert")
+    return a
+
+
+def _ctx_prefix_product(self, field: int, data, form: int = FORM_CANONICAL) -> np.ndarray:
+    a = _as_elems(data).copy()
+    n = a.shape[-2]
+    batch = a.size // 4 // n if n else 0
+    _bind_poly(load())
+    self._check(load().bzh_prefix_product(self.handle, field, _vp(a), n, batch, form, MEM_HOST), "bzh_prefix_product")
+    return a
+
+
+def _ctx_eval_polynomial(self, field: int, coeffs, xs, form: int = FORM_CANONICAL) -> np.ndarray:
+    c = _as_elems(coeffs)
+    if c.ndim == 2:
+        c = c.reshape(1, *c.shape)
+    x = _as_elems(xs).reshape(-1, 4)
+    out = np.zeros((c.shape[0], 4), dtype=np.uint64)
+    _bind_poly(load())
+    rc = load().bzh_eval_polynomial(self.handle, field, _vp(c), c.shape[1], c.shape[0], _vp(x), x.shape[0], form, MEM_HOST, _vp(out))
+    self._check(rc, "bzh_eval_polynomial")
+    return out
+
+
+def _ctx_inner_product(self, field: int, a, b, form: int = FORM_CANONICAL) -> np.ndarray:
+    a, b = _as_elems(a), _as_elems(b)
+    if a.ndim == 2:
+        a, b = a.reshape(1, *a.shape), b.reshape(1, *b.shape)
+    out = np.zeros((a.shape[0], 4), dtype=np.uint64)
+    _bind_poly(load())
+    rc = load().bzh_inner_product(self.handle, field, _vp(a), _vp(b), a.shape[1], a.shape[0], form, MEM_HOST, _vp(out))
+    self._check(rc, "bzh_inner_product")
+    return out
+
+
+def _ctx_fold(self, field: int, v, u, form: int = FORM_CANONICAL) -> np.ndarray:
+    v = _as_elems(v)
+    if v.ndim == 2:
+        v = v.reshape(1, *v.shape)
+    u = _as_elems(u).reshape(-1, 4)
+    half = v.shape[1] // 2
+    out = np.zeros((v.shape[0], half, 4), dtype=np.uint64)
+    _bind_poly(load())
+    rc = load().bzh_fold(self.handle, field, _vp(v), half, v.shape[0], _vp(u), u.shape[0], form, MEM_HOST, _vp(out))
+    self._check(rc, "bzh_fold")
+    return out
+
+
+def _ctx_vec_mul(self, field: int, a, b, form: int = FORM_CANONICAL) -> np.ndarray:
+    a, b = _as_elems(a).copy(), _as_elems(b)
+    _bind_poly(load())
+    self._check(load().bzh_vec_mul(self.handle, field, _vp(a), _vp(b), a.size // 4, form, MEM_HOST), "bzh_vec_mul")
+    return a
+
+
+Context.batch_invert = _ctx_batch_invert
+Context.prefix_product = _ctx_prefix_product
+Context.eval_polynomial = _ctx_eval_polynomial
+Context.inner_product = _ctx_inner_product
+Context.fold = _ctx_fold
+Context.vec_mul = _ctx_vec_mul

@@ -21,6 +21,42 @@ static unsigned field_two_adicity(int f) { return f == BZH_FIELD_BN254_FR ? 28u 
 
 // ---- host helpers (CPU build of the same field templates) ------------------
 namespace {
+// Staging for BZH_MEM_HOST calls: carve device buffers out of workspace slot 3, copy in, and
+// (canonical form) convert to Montgomery on the device.
+struct Stager {
+    bzh_ctx* ctx;
+    int field, form;
+    char* cur = nullptr;
+    int begin(size_t total_bytes) {
+        void* p = nullptr;
+        int rc = ws_ensure(ctx, 3, total_bytes + 256, &p);
+        cur = (char*)p;
+        return rc;
+    }
+    uint32_t* carve(size_t bytes) {
+        uint32_t* p = (uint32_t*)cur;
+        cur += (bytes + 63) & ~(size_t)63;
+        return p;
+    }
+    int in(const void* host, size_t elems, uint32_t** dev) {
+        *dev = carve(elems * 32);
+        if (!elems) return BZH_OK;
+        BZH_HIP_TRY(ctx, hipMemcpyAsync(*dev, host, elems * 32, hipMemcpyHostToDevice, ctx->stream));
+        if (form == BZH_FORM_CANONICAL) return field_convert(ctx, field, *dev, elems, 1);
+        return BZH_OK;
+    }
+    int out(void* host, uint32_t* dev, size_t elems) {
+        if (!elems) return BZH_OK;
+        if (form == BZH_FORM_CANONICAL) {
+            int rc = field_convert(ctx, field, dev, elems, 0);
+            if (rc) return rc;
+        }
+        BZH_HIP_TRY(ctx, hipMemcpyAsync(host, dev, elems * 32, hipMemcpyDeviceToHost, ctx->stream));
+        BZH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return BZH_OK;
+    }
+};
+
 template <class P>
 static Fe<P> load_host(const uint64_t* p, int form) {
     Fe<P> v;
@@ -318,6 +354,122 @@ int bzh_ntt(bzh_ctx* ctx, int field, uint64_t* data, unsigned log_n, size_t batc
     BZH_HIP_TRY(ctx, hipMemcpyAsync(data, stage, bytes, hipMemcpyDeviceToHost, ctx->stream));
     BZH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return BZH_OK;
+}
+
+#define BZH_POLY_PROLOGUE(cond_args)                                                            \
+    if (!ctx || !valid_field(field) || !valid_form(form) || !valid_mem(mem) || (cond_args)) return BZH_E_ARG; \
+    std::lock_guard<std::mutex> lk(ctx->mu);                                                    \
+    BZH_HIP_TRY(ctx, hipSetDevice(ctx->device));                                                \
+    int rc = BZH_OK;                                                                            \
+    (void)rc
+
+int bzh_batch_invert(bzh_ctx* ctx, int field, uint64_t* data, size_t count, int form, int mem) {
+    BZH_POLY_PROLOGUE(!data && count);
+    if (!count) return BZH_OK;
+    if (mem == BZH_MEM_DEVICE) {
+        uint32_t* d = (uint32_t*)data;
+        if (form == BZH_FORM_CANONICAL && (rc = field_convert(ctx, field, d, count, 1))) return rc;
+        if ((rc = poly_batch_invert(ctx, field, d, count))) return rc;
+        if (form == BZH_FORM_CANONICAL) rc = field_convert(ctx, field, d, count, 0);
+        return rc;
+    }
+    Stager s{ctx, field, form};
+    uint32_t* d;
+    if ((rc = s.begin(count * 32))) return rc;
+    if ((rc = s.in(data, count, &d))) return rc;
+    if ((rc = poly_batch_invert(ctx, field, d, count))) return rc;
+    return s.out(data, d, count);
+}
+
+int bzh_prefix_product(bzh_ctx* ctx, int field, uint64_t* data, size_t n, size_t batch, int form, int mem) {
+    BZH_POLY_PROLOGUE(!data && n && batch);
+    const size_t count = n * batch;
+    if (!count) return BZH_OK;
+    if (mem == BZH_MEM_DEVICE) {
+        uint32_t* d = (uint32_t*)data;
+        if (form == BZH_FORM_CANONICAL && (rc = field_convert(ctx, field, d, count, 1))) return rc;
+        if ((rc = poly_prefix_product(ctx, field, d, n, batch))) return rc;
+        if (form == BZH_FORM_CANONICAL) rc = field_convert(ctx, field, d, count, 0);
+        return rc;
+    }
+    Stager s{ctx, field, form};
+    uint32_t* d;
+    if ((rc = s.begin(count * 32))) return rc;
+    if ((rc = s.in(data, count, &d))) return rc;
+    if ((rc = poly_prefix_product(ctx, field, d, n, batch))) return rc;
+    return s.out(data, d, count);
+}
+
+int bzh_eval_polynomial(bzh_ctx* ctx, int field, const uint64_t* coeffs, size_t n, size_t batch, const uint64_t* xs, size_t nx,
+                        int form, int mem, uint64_t* out) {
+    BZH_POLY_PROLOGUE(!coeffs || !xs || !out || !n || (nx != 1 && nx != batch));
+    if (!batch) return BZH_OK;
+    const size_t stride = nx == 1 ? 0 : 1;
+    if (mem == BZH_MEM_DEVICE) {
+        if (form != BZH_FORM_MONTGOMERY) return BZH_E_ARG;
+        return poly_eval(ctx, field, (const uint32_t*)coeffs, n, batch, (const uint32_t*)xs, stride, (uint32_t*)out);
+    }
+    Stager s{ctx, field, form};
+    uint32_t *dc, *dx;
+    if ((rc = s.begin((n * batch + nx + batch) * 32 + 256))) return rc;
+    if ((rc = s.in(coeffs, n * batch, &dc))) return rc;
+    if ((rc = s.in(xs, nx, &dx))) return rc;
+    uint32_t* dout = s.carve(batch * 32);
+    if ((rc = poly_eval(ctx, field, dc, n, batch, dx, stride, dout))) return rc;
+    return s.out(out, dout, batch);
+}
+
+int bzh_inner_product(bzh_ctx* ctx, int field, const uint64_t* a, const uint64_t* b, size_t n, size_t batch, int form, int mem,
+                      uint64_t* out) {
+    BZH_POLY_PROLOGUE(!a || !b || !out || !n);
+    if (!batch) return BZH_OK;
+    if (mem == BZH_MEM_DEVICE) {
+        if (form != BZH_FORM_MONTGOMERY) return BZH_E_ARG;
+        return poly_inner_product(ctx, field, (const uint32_t*)a, (const uint32_t*)b, n, batch, (uint32_t*)out);
+    }
+    Stager s{ctx, field, form};
+    uint32_t *da, *db;
+    if ((rc = s.begin((2 * n * batch + batch) * 32 + 256))) return rc;
+    if ((rc = s.in(a, n * batch, &da))) return rc;
+    if ((rc = s.in(b, n * batch, &db))) return rc;
+    uint32_t* dout = s.carve(batch * 32);
+    if ((rc = poly_inner_product(ctx, field, da, db, n, batch, dout))) return rc;
+    return s.out(out, dout, batch);
+}
+
+int bzh_fold(bzh_ctx* ctx, int field, const uint64_t* in, size_t half, size_t batch, const uint64_t* u, size_t nu, int form,
+             int mem, uint64_t* out) {
+    BZH_POLY_PROLOGUE(!in || !u || !out || (nu != 1 && nu != batch));
+    if (!batch || !half) return BZH_OK;
+    const size_t stride = nu == 1 ? 0 : 1;
+    if (mem == BZH_MEM_DEVICE) {
+        if (form != BZH_FORM_MONTGOMERY) return BZH_E_ARG;
+        return poly_fold(ctx, field, (const uint32_t*)in, half, batch, (const uint32_t*)u, stride, (uint32_t*)out);
+    }
+    Stager s{ctx, field, form};
+    uint32_t *din, *du;
+    if ((rc = s.begin((3 * half * batch + nu) * 32 + 256))) return rc;
+    if ((rc = s.in(in, 2 * half * batch, &din))) return rc;
+    if ((rc = s.in(u, nu, &du))) return rc;
+    uint32_t* dout = s.carve(half * batch * 32);
+    if ((rc = poly_fold(ctx, field, din, half, batch, du, stride, dout))) return rc;
+    return s.out(out, dout, half * batch);
+}
+
+int bzh_vec_mul(bzh_ctx* ctx, int field, uint64_t* a, const uint64_t* b, size_t count, int form, int mem) {
+    BZH_POLY_PROLOGUE((!a || !b) && count);
+    if (!count) return BZH_OK;
+    if (mem == BZH_MEM_DEVICE) {
+        if (form != BZH_FORM_MONTGOMERY) return BZH_E_ARG;
+        return poly_vec_mul(ctx, field, (uint32_t*)a, (const uint32_t*)b, count);
+    }
+    Stager s{ctx, field, form};
+    uint32_t *da, *db;
+    if ((rc = s.begin(2 * count * 32 + 256))) return rc;
+    if ((rc = s.in(a, count, &da))) return rc;
+    if ((rc = s.in(b, count, &db))) return rc;
+    if ((rc = poly_vec_mul(ctx, field, da, db, count))) return rc;
+    return s.out(a, da, count);
 }
 
 int bzh_jacobian_to_affine(int curve, const uint64_t* xyz, size_t n, int form, uint64_t* out_xy) {

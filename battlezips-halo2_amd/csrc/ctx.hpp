@@ -101,5 +101,15 @@ int ntt_run(bzh_ctx* ctx, int field, uint32_t* d_data, unsigned log_n, size_t ba
             const uint64_t* coset_shift, int inverse, int form);
 int bases_to_montgomery(bzh_ctx* ctx, int curve, uint32_t* d_xy, size_t n);
 int bases_precompute(bzh_ctx* ctx, bzh_bases* bases, int window_bits);
+// polyops.hip (device pointers, Montgomery form)
+int field_convert(bzh_ctx* ctx, int field, uint32_t* d, size_t count, int to_mont);
+int poly_batch_invert(bzh_ctx* ctx, int field, uint32_t* d, size_t count);
+int poly_prefix_product(bzh_ctx* ctx, int field, uint32_t* d, size_t n, size_t batch);
+int poly_eval(bzh_ctx* ctx, int field, const uint32_t* coeffs, size_t n, size_t batch, const uint32_t* xs, size_t x_stride,
+              uint32_t* out);
+int poly_inner_product(bzh_ctx* ctx, int field, const uint32_t* a, const uint32_t* b, size_t n, size_t batch, uint32_t* out);
+int poly_fold(bzh_ctx* ctx, int field, const uint32_t* in, size_t half, size_t batch, const uint32_t* u, size_t u_stride,
+              uint32_t* out);
+int poly_vec_mul(bzh_ctx* ctx, int field, uint32_t* a, const uint32_t* b, size_t count);
 
 }  // namespace bzh

@@ -22,8 +22,6 @@
 
 namespace bzh {
 
-int field_convert(bzh_ctx* ctx, int field, uint32_t* d, size_t count, int to_mont);
-
 static constexpr int kTileElems = 2048;  // 64 KiB of LDS per workgroup
 static constexpr int kNttThreads = 256;
 

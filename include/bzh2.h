@@ -72,6 +72,7 @@ typedef enum {
     BZH_T_MSM_REDUCE = 2,
     BZH_T_MSM_FINALIZE = 3,
     BZH_T_NTT = 4,
+    BZH_T_POLY = 5,
     BZH_T_COUNT = 8
 } bzh_timer;
 
@@ -133,6 +134,29 @@ int bzh_msm(bzh_ctx* ctx, const bzh_bases* bases, const uint64_t* scalars, size_
  * host pointers to 4 limbs in `form`. */
 int bzh_ntt(bzh_ctx* ctx, int field, uint64_t* data, unsigned log_n, size_t batch, const uint64_t* omega,
             const uint64_t* coset_shift, int inverse, int form, int mem);
+
+/* ---- prover-stage vector primitives (N4, N5, N6) ------------
+ * Field elements in `form`; `mem` applies to every pointer of the call.  With BZH_MEM_DEVICE the
+ * read-only inputs must already be in Montgomery form (the library does not write to them).
+ *
+ * bzh_batch_invert     ff::BatchInvert: data[i] <- data[i]^-1, zeros stay zero (grand-product denominators)
+ * bzh_prefix_product   in place, per vector of n: out[0] = 1, out[i] = prod_{j<i} in[j]
+ *                      (the running products z(X) of permutation::Argument::commit / lookup commit_product)
+ * bzh_eval_polynomial  arithmetic::eval_polynomial: out[b] = sum_i coeffs[b][i] * x_b^i;
+ *                      nx = 1 (one point for every polynomial) or nx = batch
+ * bzh_inner_product    arithmetic::compute_inner_product per vector pair
+ * bzh_fold             IPA round fold: out[b][i] = in[b][i] + u_b * in[b][half + i], i < half; nu = 1 or batch
+ * bzh_vec_mul          a[i] <- a[i] * b[i]
+ */
+int bzh_batch_invert(bzh_ctx* ctx, int field, uint64_t* data, size_t count, int form, int mem);
+int bzh_prefix_product(bzh_ctx* ctx, int field, uint64_t* data, size_t n, size_t batch, int form, int mem);
+int bzh_eval_polynomial(bzh_ctx* ctx, int field, const uint64_t* coeffs, size_t n, size_t batch, const uint64_t* xs, size_t nx,
+                        int form, int mem, uint64_t* out);
+int bzh_inner_product(bzh_ctx* ctx, int field, const uint64_t* a, const uint64_t* b, size_t n, size_t batch, int form, int mem,
+                      uint64_t* out);
+int bzh_fold(bzh_ctx* ctx, int field, const uint64_t* in, size_t half, size_t batch, const uint64_t* u, size_t nu, int form,
+             int mem, uint64_t* out);
+int bzh_vec_mul(bzh_ctx* ctx, int field, uint64_t* a, const uint64_t* b, size_t count, int form, int mem);
 
 /* ---- host helpers (CPU, no device needed): what `.to_affine()` / `to_bytes()`
  * do on the Rust side; used by tests and benches to compare canonical bytes. */

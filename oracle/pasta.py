@@ -467,3 +467,84 @@ def eval_polynomial(coeffs, x: int, field: FieldSpec) -> int:
     for c in reversed(coeffs):
         acc = (acc * x + c) % field.p
     return acc
+
+
+# --------------------------------------------------------------------------
+# Prover-stage vector primitives (halo2_proofs 0.2.0, UPSTREAM/unvendored),
+# restated from their published definitions; call chain: create_proof
+# (benches/shot.rs:68) -> permutation/lookup/vanishing/multiopen provers.
+# --------------------------------------------------------------------------
+def batch_invert(vals, field: FieldSpec):
+    """ff::BatchInvert semantics: every non-zero element is inverted, zeros stay zero."""
+    return [0 if v % field.p == 0 else field.inv(v) for v in vals]
+
+
+def prefix_product(vals, field: FieldSpec):
+    """Exclusive running product: out[0] = 1, out[i] = prod_{j<i} vals[j]  (the z(X) grand
+    products of permutation::Argument::commit / lookup commit_product start at 1)."""
+    out, acc = [], 1
+    for v in vals:
+        out.append(acc)
+        acc = acc * v % field.p
+    return out
+
+
+def inner_product(a, b, field: FieldSpec) -> int:
+    """arithmetic::compute_inner_product."""
+    return sum(x * y for x, y in zip(a, b)) % field.p
+
+
+def fold_scalars(v, u: int, field: FieldSpec):
+    """IPA round fold of a scalar vector: lo + u * hi  (commitment::prover, p' and b)."""
+    h = len(v) // 2
+    return [(v[i] + u * v[i + h]) % field.p for i in range(h)]
+
+
+def fold_bases(curve: "Curve", g, u: int):
+    """parallel_generator_collapse: g_lo[i] + [u] g_hi[i], affine."""
+    h = len(g) // 2
+    return [curve.add(g[i], curve.mul(u, g[i + h])) for i in range(h)]
+
+
+def kate_division(coeffs, x: int, field: FieldSpec):
+    """arithmetic::kate_division: quotient of p(X) by (X - x), remainder dropped; len = len(coeffs)-1."""
+    p = field.p
+    q = [0] * (len(coeffs) - 1)
+    tmp = 0
+    for i in range(len(coeffs) - 1, 0, -1):
+        tmp = (coeffs[i] + tmp * x) % p
+        q[i - 1] = tmp
+    return q
+
+
+# --------------------------------------------------------------------------
+# Transcript (halo2_proofs 0.2.0 transcript.rs, UPSTREAM/unvendored; SURVEY App. A.2):
+# Blake2b-512 with personal "Halo2-Transcript"; point = 0x01? no: prefixes are
+# BLAKE2B_PREFIX_CHALLENGE = 0, _POINT = 1, _SCALAR = 2; a challenge hashes the
+# running state + [0] and reduces the 64-byte digest as a 512-bit LE integer.
+# --------------------------------------------------------------------------
+class Blake2bTranscript:
+    def __init__(self, field: FieldSpec = FP):
+        self.field = field
+        self.state = hashlib.blake2b(digest_size=64, person=b"Halo2-Transcript")
+        self.proof = bytearray()
+
+    def common_point(self, curve: "Curve", pt):
+        x, y = (0, 0) if pt is None else pt
+        self.state.update(b"\x01" + to_repr(x) + to_repr(y))
+
+    def common_scalar(self, s: int):
+        self.state.update(b"\x02" + to_repr(s))
+
+    def write_point(self, curve: "Curve", pt):
+        self.common_point(curve, pt)
+        self.proof += curve.compress(pt)
+
+    def write_scalar(self, s: int):
+        self.common_scalar(s)
+        self.proof += to_repr(s)
+
+    def squeeze_challenge(self) -> int:
+        self.state.update(b"\x00")
+        digest = self.state.copy().digest()
+        return int.from_bytes(digest, "little") % self.field.p
