@@ -358,3 +358,72 @@ Context.eval_polynomial = _ctx_eval_polynomial
 Context.inner_product = _ctx_inner_product
 Context.fold = _ctx_fold
 Context.vec_mul = _ctx_vec_mul
+
+
+# ---- transcript (host) ---------------------------------------------------------------------------
+EXPORTS += ["bzh_transcript_new", "bzh_transcript_free", "bzh_transcript_common_point", "bzh_transcript_common_scalar",
+            "bzh_transcript_write_point", "bzh_transcript_write_scalar", "bzh_transcript_squeeze_challenge",
+            "bzh_transcript_proof"]
+
+
+class Transcript:
+    """Blake2bWrite + Challenge255 (bzh_transcript_*); ints in, ints out."""
+
+    def __init__(self, challenge_field: int = FIELD_FP):
+        L = load()
+        vp = ctypes.c_void_p
+        L.bzh_transcript_new.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
+        for f in ("bzh_transcript_free",):
+            getattr(L, f).argtypes = [vp]
+        for f in ("bzh_transcript_common_point", "bzh_transcript_common_scalar", "bzh_transcript_write_scalar",
+                  "bzh_transcript_squeeze_challenge"):
+            getattr(L, f).argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
+        L.bzh_transcript_write_point.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]
+        L.bzh_transcript_proof.argtypes = [vp, ctypes.POINTER(ctypes.POINTER(ctypes.c_uint8)), ctypes.POINTER(ctypes.c_size_t)]
+        self.h = vp()
+        rc = L.bzh_transcript_new(challenge_field, ctypes.byref(self.h))
+        if rc != OK:
+            raise BzhError(rc, "bzh_transcript_new")
+
+    @staticmethod
+    def _pt(pt):
+        x, y = (0, 0) if pt is None else pt
+        return np.concatenate([int_to_limbs(x), int_to_limbs(y)])
+
+    def common_point(self, pt):
+        rc = load().bzh_transcript_common_point(self.h, _u64(self._pt(pt)))
+        if rc != OK:
+            raise BzhError(rc, "bzh_transcript_common_point")
+
+    def common_scalar(self, s: int):
+        rc = load().bzh_transcript_common_scalar(self.h, _u64(int_to_limbs(s)))
+        if rc != OK:
+            raise BzhError(rc, "bzh_transcript_common_scalar")
+
+    def write_point(self, curve: int, pt):
+        rc = load().bzh_transcript_write_point(self.h, curve, _u64(self._pt(pt)))
+        if rc != OK:
+            raise BzhError(rc, "bzh_transcript_write_point")
+
+    def write_scalar(self, s: int):
+        rc = load().bzh_transcript_write_scalar(self.h, _u64(int_to_limbs(s)))
+        if rc != OK:
+            raise BzhError(rc, "bzh_transcript_write_scalar")
+
+    def squeeze_challenge(self) -> int:
+        out = np.zeros(4, dtype=np.uint64)
+        rc = load().bzh_transcript_squeeze_challenge(self.h, _u64(out))
+        if rc != OK:
+            raise BzhError(rc, "bzh_transcript_squeeze_challenge")
+        return limbs_to_int(out)
+
+    def proof(self) -> bytes:
+        p = ctypes.POINTER(ctypes.c_uint8)()
+        n = ctypes.c_size_t()
+        load().bzh_transcript_proof(self.h, ctypes.byref(p), ctypes.byref(n))
+        return bytes(ctypes.string_at(p, n.value)) if n.value else b""
+
+    def close(self):
+        if self.h is not None:
+            load().bzh_transcript_free(self.h)
+            self.h = None

@@ -158,6 +158,23 @@ int bzh_fold(bzh_ctx* ctx, int field, const uint64_t* in, size_t half, size_t ba
              int mem, uint64_t* out);
 int bzh_vec_mul(bzh_ctx* ctx, int field, uint64_t* a, const uint64_t* b, size_t count, int form, int mem);
 
+/* ---- Fiat-Shamir transcript (host; halo2_proofs transcript::{Blake2bWrite, Challenge255}) --
+ * What every create_proof caller builds first (benches/shot.rs:66-67, src/circuits/board.rs:911-912:
+ * `Blake2bWrite::<_, vesta::Affine, Challenge255<_>>::init(vec![])`).  Blake2b-512, personal
+ * "Halo2-Transcript"; points and scalars are passed in canonical form (8 / 4 limbs).
+ *   common_*  absorb only;  write_*  absorb and append to the proof bytes (compressed point / repr);
+ *   squeeze_challenge  absorbs 0x00 and returns the digest reduced as a 512-bit LE integer mod the
+ *   challenge field (4 canonical limbs);  proof  borrows the bytes written so far (finalize()). */
+typedef struct bzh_transcript bzh_transcript;
+int bzh_transcript_new(int challenge_field, bzh_transcript** out);
+int bzh_transcript_free(bzh_transcript* t);
+int bzh_transcript_common_point(bzh_transcript* t, const uint64_t* xy_canonical);
+int bzh_transcript_common_scalar(bzh_transcript* t, const uint64_t* s_canonical);
+int bzh_transcript_write_point(bzh_transcript* t, int curve, const uint64_t* xy_canonical);
+int bzh_transcript_write_scalar(bzh_transcript* t, const uint64_t* s_canonical);
+int bzh_transcript_squeeze_challenge(bzh_transcript* t, uint64_t* out_canonical);
+int bzh_transcript_proof(const bzh_transcript* t, const uint8_t** data, size_t* len);
+
 /* ---- host helpers (CPU, no device needed): what `.to_affine()` / `to_bytes()`
  * do on the Rust side; used by tests and benches to compare canonical bytes. */
 int bzh_jacobian_to_affine(int curve, const uint64_t* xyz, size_t n, int form, uint64_t* out_xy);
