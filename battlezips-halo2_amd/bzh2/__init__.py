@@ -427,3 +427,44 @@ class Transcript:
         if self.h is not None:
             load().bzh_transcript_free(self.h)
             self.h = None
+
+
+# ---- IPA opening --------------------------------------------------------------------------------
+EXPORTS += ["bzh_ipa_open", "bzh_ipa_verify"]
+E_VERIFY = -6
+
+
+def _ctx_ipa_open(self, bases: Bases, poly, blind: int, x3: int, rng_bytes: bytes, transcript: "Transcript",
+                  form: int = FORM_CANONICAL) -> int:
+    """poly::commitment::create_proof: appends S, (L_j, R_j)*, c, f to `transcript`; returns v = p(x3)."""
+    L = load()
+    vp = ctypes.c_void_p
+    L.bzh_ipa_open.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64),
+                               ctypes.POINTER(ctypes.c_uint64), ctypes.c_char_p, ctypes.c_size_t, vp,
+                               ctypes.POINTER(ctypes.c_uint64)]
+    p = _as_elems(poly)
+    out = np.zeros(4, dtype=np.uint64)
+    rc = L.bzh_ipa_open(self.handle, bases.handle, _vp(p), form, MEM_HOST, _u64(int_to_limbs(blind)), _u64(int_to_limbs(x3)),
+                        rng_bytes, len(rng_bytes), transcript.h, _u64(out))
+    self._check(rc, "bzh_ipa_open")
+    return limbs_to_int(out)
+
+
+def _ctx_ipa_verify(self, bases: Bases, commitment, x3: int, v: int, proof: bytes, transcript: "Transcript", g0_u_w) -> bool:
+    """True iff the opening proof verifies (bzh_ipa_verify); raises on any other error."""
+    L = load()
+    vp = ctypes.c_void_p
+    u64p = ctypes.POINTER(ctypes.c_uint64)
+    L.bzh_ipa_verify.argtypes = [vp, vp, u64p, u64p, u64p, ctypes.c_char_p, ctypes.c_size_t, vp, u64p]
+    cm = Transcript._pt(commitment)
+    trip = np.concatenate([Transcript._pt(p) for p in g0_u_w])
+    rc = L.bzh_ipa_verify(self.handle, bases.handle, _u64(cm), _u64(int_to_limbs(x3)), _u64(int_to_limbs(v)), proof, len(proof),
+                          transcript.h, _u64(trip))
+    if rc == E_VERIFY:
+        return False
+    self._check(rc, "bzh_ipa_verify")
+    return True
+
+
+Context.ipa_open = _ctx_ipa_open
+Context.ipa_verify = _ctx_ipa_verify

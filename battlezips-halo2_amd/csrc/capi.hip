@@ -151,6 +151,7 @@ const char* bzh_strerror(int status) {
         case BZH_E_HIP: return "HIP runtime error";
         case BZH_E_RANGE: return "value out of range";
         case BZH_E_NOGPU: return "no usable GPU";
+        case BZH_E_VERIFY: return "proof does not verify";
     }
     return "unknown status";
 }
@@ -470,6 +471,44 @@ int bzh_vec_mul(bzh_ctx* ctx, int field, uint64_t* a, const uint64_t* b, size_t 
     if ((rc = s.in(b, count, &db))) return rc;
     if ((rc = poly_vec_mul(ctx, field, da, db, count))) return rc;
     return s.out(a, da, count);
+}
+
+int bzh_ipa_open(bzh_ctx* ctx, const bzh_bases* bases, const uint64_t* poly, int form, int mem, const uint64_t* blind,
+                 const uint64_t* x3, const uint8_t* rng, size_t rng_len, bzh_transcript* transcript, uint64_t* out_v) {
+    if (!ctx || !bases || !poly || !blind || !x3 || !rng || !transcript || !out_v || !valid_form(form) || !valid_mem(mem))
+        return BZH_E_ARG;
+    if (bases->n < 3 || bases->device != ctx->device) return BZH_E_ARG;
+    const size_t n = bases->n - 2;
+    if (n & (n - 1)) return BZH_E_ARG;
+    unsigned k = 0;
+    while (((size_t)1 << k) < n) k++;
+    if (rng_len < 64 * (n + 1 + 2 * (size_t)k)) return BZH_E_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    BZH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int field = bases->curve == BZH_CURVE_VESTA ? BZH_FIELD_FP : (bases->curve == BZH_CURVE_PALLAS ? BZH_FIELD_FQ : BZH_FIELD_BN254_FR);
+    if (mem == BZH_MEM_DEVICE) {
+        if (form != BZH_FORM_MONTGOMERY) return BZH_E_ARG;
+        return ipa_open(ctx, bases, (const uint32_t*)poly, blind, x3, rng, transcript, out_v);
+    }
+    // stage the polynomial in its own allocation (ipa_open uses workspace slot 3 itself)
+    uint32_t* d_poly = nullptr;
+    BZH_HIP_TRY(ctx, hipMalloc((void**)&d_poly, n * 32));
+    int rc = BZH_OK;
+    if (hipMemcpyAsync(d_poly, poly, n * 32, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = BZH_E_HIP;
+    if (!rc && form == BZH_FORM_CANONICAL) rc = field_convert(ctx, field, d_poly, n, 1);
+    if (!rc) rc = ipa_open(ctx, bases, d_poly, blind, x3, rng, transcript, out_v);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_poly);
+    return rc;
+}
+
+int bzh_ipa_verify(bzh_ctx* ctx, const bzh_bases* bases, const uint64_t* commitment_xy, const uint64_t* x3, const uint64_t* v,
+                   const uint8_t* proof, size_t proof_len, bzh_transcript* transcript, const uint64_t* g0_u_w) {
+    if (!ctx || !bases || !commitment_xy || !x3 || !v || !proof || !transcript || !g0_u_w) return BZH_E_ARG;
+    if (bases->n < 3 || bases->device != ctx->device) return BZH_E_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    BZH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return ipa_verify(ctx, bases, commitment_xy, x3, v, proof, proof_len, transcript, g0_u_w);
 }
 
 int bzh_jacobian_to_affine(int curve, const uint64_t* xyz, size_t n, int form, uint64_t* out_xy) {

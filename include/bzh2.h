@@ -50,6 +50,7 @@ extern "C" {
 
 typedef struct bzh_ctx bzh_ctx;
 typedef struct bzh_bases bzh_bases;
+typedef struct bzh_transcript bzh_transcript;
 
 typedef enum {
     BZH_OK = 0,
@@ -57,7 +58,8 @@ typedef enum {
     BZH_E_OOM = -2,    /* hipMalloc / host allocation failed                  */
     BZH_E_HIP = -3,    /* a HIP runtime call failed (see bzh_last_error)      */
     BZH_E_RANGE = -4,  /* log_n beyond the field's 2-adicity, n too large ... */
-    BZH_E_NOGPU = -5   /* no usable gfx950 device                             */
+    BZH_E_NOGPU = -5,  /* no usable gfx950 device                             */
+    BZH_E_VERIFY = -6  /* bzh_ipa_verify: the proof does not verify           */
 } bzh_status;
 
 typedef enum { BZH_CURVE_VESTA = 0, BZH_CURVE_PALLAS = 1, BZH_CURVE_BN254 = 2 } bzh_curve;
@@ -174,6 +176,22 @@ int bzh_transcript_write_point(bzh_transcript* t, int curve, const uint64_t* xy_
 int bzh_transcript_write_scalar(bzh_transcript* t, const uint64_t* s_canonical);
 int bzh_transcript_squeeze_challenge(bzh_transcript* t, uint64_t* out_canonical);
 int bzh_transcript_proof(const bzh_transcript* t, const uint8_t** data, size_t* len);
+
+/* ---- inner-product-argument opening (halo2_proofs poly::commitment::{create_proof, verify_proof}) --
+ * Step 9 of plonk::create_proof and the heart of verify_proof (benches/board.rs:80-86).
+ * `bases` must hold n + 2 points: the n = 2^k SRS generators followed by U and W (Params.u, Params.w);
+ * a window table (bzh_bases_precompute) is recommended: every round is two MSMs against it.
+ * bzh_ipa_open   writes S, (L_j, R_j) for j < k, then the scalars c and f to the transcript, exactly
+ *                the upstream message order.  poly: n coefficients (`form`, `mem`); blind, x3: 4 canonical
+ *                limbs (host); rng: 64 bytes of RNG output per drawn scalar in upstream's draw order
+ *                (n for s(X), 1 for its blind, 2 per round) = 64 * (n + 1 + 2k) bytes; out_v = p(x3).
+ * bzh_ipa_verify checks  sum_j (u_j^-1 L_j + u_j R_j) + P - [v]G_0 + [xi]S == [c]G'_0 + [c b_0 z]U + [f]W
+ *                against a transcript in the same state the prover's was before bzh_ipa_open;
+ *                g0_u_w: G_0, U, W as 3 canonical affine points.  Returns BZH_OK or BZH_E_VERIFY. */
+int bzh_ipa_open(bzh_ctx* ctx, const bzh_bases* bases, const uint64_t* poly, int form, int mem, const uint64_t* blind,
+                 const uint64_t* x3, const uint8_t* rng, size_t rng_len, bzh_transcript* transcript, uint64_t* out_v);
+int bzh_ipa_verify(bzh_ctx* ctx, const bzh_bases* bases, const uint64_t* commitment_xy, const uint64_t* x3, const uint64_t* v,
+                   const uint8_t* proof, size_t proof_len, bzh_transcript* transcript, const uint64_t* g0_u_w);
 
 /* ---- host helpers (CPU, no device needed): what `.to_affine()` / `to_bytes()`
  * do on the Rust side; used by tests and benches to compare canonical bytes. */

@@ -548,3 +548,105 @@ class Blake2bTranscript:
         self.state.update(b"\x00")
         digest = self.state.copy().digest()
         return int.from_bytes(digest, "little") % self.field.p
+
+
+# --------------------------------------------------------------------------
+# Inner-product-argument opening (halo2_proofs 0.2.0 poly/commitment/prover.rs
+# `create_proof` and the matching verification equation, UPSTREAM/unvendored;
+# reached from plonk::create_proof step 9).  Straight
+# restatement WITH the generator collapse, used to pin the GPU prover (which
+# never collapses generators) byte for byte under a shared randomness stream.
+# --------------------------------------------------------------------------
+def ipa_open(curve: "Curve", g, w, u, poly, blind: int, x3: int, rand_scalars, transcript: "Blake2bTranscript"):
+    """g: n affine bases, w/u: blinding / inner-product bases, poly: n coefficients.
+    rand_scalars: iterator of field elements in upstream draw order
+    (n for s(X), 1 s_blind, then l_j, r_j per round).  Writes S, (L_j, R_j)*, c, f."""
+    F = curve.scalar
+    p = F.p
+    n = len(poly)
+    k = n.bit_length() - 1
+    assert 1 << k == n == len(g)
+    rnd = iter(rand_scalars)
+    s_poly = [next(rnd) for _ in range(n)]
+    s_poly[0] = (s_poly[0] - eval_polynomial(s_poly, x3, F)) % p
+    s_blind = next(rnd)
+    S = curve.add(curve.msm_naive(s_poly, g), curve.mul(s_blind, w))
+    transcript.write_point(curve, S)
+    xi = transcript.squeeze_challenge()
+    z = transcript.squeeze_challenge()
+    pp = [(a * xi + b) % p for a, b in zip(s_poly, poly)]
+    v = eval_polynomial(pp, x3, F)
+    pp[0] = (pp[0] - v) % p
+    f = (s_blind * xi + blind) % p
+    b = [pow(x3, i, p) for i in range(n)]
+    gp = list(g)
+    for j in range(k):
+        half = 1 << (k - j - 1)
+        l_pt = curve.msm_naive(pp[half:], gp[:half])
+        r_pt = curve.msm_naive(pp[:half], gp[half:])
+        vl = inner_product(pp[half:], b[:half], F)
+        vr = inner_product(pp[:half], b[half:], F)
+        lr, rr = next(rnd), next(rnd)
+        l_pt = curve.add(l_pt, curve.add(curve.mul(vl * z % p, u), curve.mul(lr, w)))
+        r_pt = curve.add(r_pt, curve.add(curve.mul(vr * z % p, u), curve.mul(rr, w)))
+        transcript.write_point(curve, l_pt)
+        transcript.write_point(curve, r_pt)
+        uj = transcript.squeeze_challenge()
+        uj_inv = F.inv(uj)
+        pp = [(pp[i] + pp[i + half] * uj_inv) % p for i in range(half)]
+        b = [(b[i] + b[i + half] * uj) % p for i in range(half)]
+        gp = fold_bases(curve, gp, uj)
+        f = (f + lr * uj_inv + rr * uj) % p
+    transcript.write_scalar(pp[0])
+    transcript.write_scalar(f)
+    return v
+
+
+def ipa_verify(curve: "Curve", g, w, u, commitment, x3: int, v: int, proof: bytes, transcript: "Blake2bTranscript") -> bool:
+    """sum_j (u_j^-1 L_j + u_j R_j) + P - [v]G_0 + [xi]S == [c]G'_0 + [c b_0 z]U + [f]W."""
+    F = curve.scalar
+    p = F.p
+    n = len(g)
+    k = n.bit_length() - 1
+
+    def read_point(off):
+        raw = bytearray(proof[off:off + 32])
+        ysign = raw[31] >> 7
+        raw[31] &= 0x7f
+        x = int.from_bytes(raw, "little")
+        if x == 0 and ysign == 0:
+            return None
+        y = curve.base.sqrt((x * x * x + curve.a * x + curve.b) % curve.p)
+        if y is None:
+            raise ValueError("not on curve")
+        if (y & 1) != ysign:
+            y = curve.p - y
+        return (x, y)
+
+    off = 0
+    S = read_point(off); off += 32
+    transcript.common_point(curve, S)
+    xi = transcript.squeeze_challenge()
+    z = transcript.squeeze_challenge()
+    acc = curve.add(curve.add(commitment, curve.neg(curve.mul(v, g[0]))), curve.mul(xi, S))
+    us = []
+    for _ in range(k):
+        L = read_point(off); R = read_point(off + 32); off += 64
+        transcript.common_point(curve, L)
+        transcript.common_point(curve, R)
+        uj = transcript.squeeze_challenge()
+        us.append(uj)
+        acc = curve.add(acc, curve.add(curve.mul(F.inv(uj), L), curve.mul(uj, R)))
+    c = int.from_bytes(proof[off:off + 32], "little"); off += 32
+    f = int.from_bytes(proof[off:off + 32], "little"); off += 32
+    if off != len(proof) or c >= p or f >= p:
+        return False
+    s = [1]
+    for uj in us:                                   # s^{(j+1)}[2t + beta] = s^{(j)}[t] * u_j^beta
+        s = [x * (uj if beta else 1) % p for x in s for beta in (0, 1)]
+    g0 = curve.msm_naive(s, g)
+    b0 = 1
+    for j, uj in enumerate(us):
+        b0 = b0 * (1 + uj * pow(x3, 1 << (k - 1 - j), p)) % p
+    rhs = curve.add(curve.mul(c, g0), curve.add(curve.mul(c * b0 % p * z % p, u), curve.mul(f, w)))
+    return acc == rhs
