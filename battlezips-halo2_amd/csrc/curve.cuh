@@ -65,9 +65,17 @@ BZH_HD Xyzz<P> xyzz_from_affine(const Affine<P>& a) {
     return r;
 }
 
+// The rarely-executed group operations stay out of line on the device (the field multiply is
+// inlined into them): the bucket loop's hot path is then xyzz_madd's main branch alone.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BZH_COLD __host__ __device__ __noinline__
+#else
+#define BZH_COLD BZH_HD
+#endif
+
 // dbl-2008-s-1 (a = 0): 6M + 3S... written as 7M + 2S with shared products
 template <class P>
-BZH_HD Xyzz<P> xyzz_dbl(const Xyzz<P>& p) {
+BZH_COLD Xyzz<P> xyzz_dbl(const Xyzz<P> p) {
     if (xyzz_is_id(p)) return p;
     Fe<P> u = fe_dbl(p.y);
     Fe<P> v = fe_sqr(u);
@@ -84,7 +92,7 @@ BZH_HD Xyzz<P> xyzz_dbl(const Xyzz<P>& p) {
 }
 // doubling of an affine point into XYZZ (mdbl-2008-s-1)
 template <class P>
-BZH_HD Xyzz<P> xyzz_dbl_affine(const Affine<P>& a) {
+BZH_COLD Xyzz<P> xyzz_dbl_affine(const Affine<P> a) {
     Fe<P> u = fe_dbl(a.y);
     Fe<P> v = fe_sqr(u);
     Fe<P> w = fe_mul(u, v);
@@ -135,12 +143,18 @@ BZH_HD void xyzz_madd(Xyzz<P>& acc, const Affine<P>& q) {
 
 // acc += q (both XYZZ).  add-2008-s: 12M + 2S, all special cases handled.
 template <class P>
+BZH_COLD Xyzz<P> xyzz_add_impl(Xyzz<P> acc, const Xyzz<P> q);
+template <class P>
 BZH_HD void xyzz_add(Xyzz<P>& acc, const Xyzz<P>& q) {
     if (xyzz_is_id(q)) return;
     if (xyzz_is_id(acc)) {
         acc = q;
         return;
     }
+    acc = xyzz_add_impl(acc, q);
+}
+template <class P>
+BZH_COLD Xyzz<P> xyzz_add_impl(Xyzz<P> acc, const Xyzz<P> q) {
     Fe<P> u1 = fe_mul(acc.x, q.zz);
     Fe<P> u2 = fe_mul(q.x, acc.zz);
     Fe<P> s1 = fe_mul(acc.y, q.zzz);
@@ -148,12 +162,8 @@ BZH_HD void xyzz_add(Xyzz<P>& acc, const Xyzz<P>& q) {
     Fe<P> pp_ = fe_sub(u2, u1);
     Fe<P> r = fe_sub(s2, s1);
     if (fe_is_zero(pp_)) {
-        if (fe_is_zero(r)) {
-            acc = xyzz_dbl(acc);
-        } else {
-            acc = xyzz_identity<P>();
-        }
-        return;
+        if (fe_is_zero(r)) return xyzz_dbl(acc);
+        return xyzz_identity<P>();
     }
     Fe<P> pp = fe_sqr(pp_);
     Fe<P> ppp = fe_mul(pp_, pp);
@@ -164,6 +174,7 @@ BZH_HD void xyzz_add(Xyzz<P>& acc, const Xyzz<P>& q) {
     acc.y = y3;
     acc.zz = fe_mul(fe_mul(acc.zz, q.zz), pp);
     acc.zzz = fe_mul(fe_mul(acc.zzz, q.zzz), ppp);
+    return acc;
 }
 
 // XYZZ -> Jacobian (X:Y:Z) with x = X/Z^2, y = Y/Z^3: Z = ZZZ/ZZ would need an
