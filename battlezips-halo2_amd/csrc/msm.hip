@@ -232,7 +232,20 @@ __global__ void __launch_bounds__(T) k_msm_accumulate(const uint32_t* __restrict
     for (int i = tid; i < M + 2; i += T) cnt[i] = 0;
     if (tid == 0) scratch[31] = 0;  // max bucket population
     __syncthreads();
-    for (int i = tid; i < len; i += T) {
+    // digits are read 8 at a time (one dwordx4 per lane) when the row is 16-byte aligned
+    const bool vec_ok = (reinterpret_cast<uintptr_t>(dg) & 15u) == 0;
+    const int nvec = vec_ok ? (len >> 3) : 0;
+    for (int v = tid; v < nvec; v += T) {
+        const uint4 d4 = reinterpret_cast<const uint4*>(dg)[v];
+        const uint32_t w4[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t m0 = w4[k] & 0x7fffu, m1 = (w4[k] >> 16) & 0x7fffu;
+            if (m0) atomicAdd(&cnt[m0], 1u);
+            if (m1) atomicAdd(&cnt[m1], 1u);
+        }
+    }
+    for (int i = nvec * 8 + tid; i < len; i += T) {
         uint32_t m = dg[i] & 0x7fffu;
         if (m) atomicAdd(&cnt[m], 1u);
     }
@@ -244,7 +257,19 @@ __global__ void __launch_bounds__(T) k_msm_accumulate(const uint32_t* __restrict
         if ((tid & 63) == 0) atomicMax(&scratch[31], mx);
     }
     block_exclusive_scan(cnt, M + 1, scratch);
-    for (int i = tid; i < len; i += T) {
+    for (int v = tid; v < nvec; v += T) {
+        const uint4 d4 = reinterpret_cast<const uint4*>(dg)[v];
+        const uint32_t w4[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t d = (w4[k >> 1] >> ((k & 1) * 16)) & 0xffffu, m = d & 0x7fffu;
+            if (m) {
+                uint32_t pos = atomicAdd(&cnt[m], 1u);
+                sorted[pos] = (uint16_t)((uint32_t)(v * 8 + k) | (d & 0x8000u));
+            }
+        }
+    }
+    for (int i = nvec * 8 + tid; i < len; i += T) {
         uint32_t d = dg[i], m = d & 0x7fffu;
         if (m) {
             uint32_t pos = atomicAdd(&cnt[m], 1u);
@@ -281,6 +306,17 @@ __global__ void __launch_bounds__(T) k_msm_accumulate(const uint32_t* __restrict
             if (cnt[mid] > start) hi = mid; else lo = mid + 1;
         }
         uint32_t m = lo, bbeg = cnt[m - 1], bend = cnt[m];
+        // software pipeline: the gather of item j+1 is in flight while item j is added
+        auto point_index = [&](uint32_t e) -> size_t {
+            size_t pidx = (size_t)(e & 0x7fffu);
+            if (remap) {
+                const size_t g = c0 + pidx, row = g / row_len;
+                pidx = row * row_stride + (g - row * row_len) - c0;
+            }
+            return pidx;
+        };
+        uint32_t e_next = sorted[start];
+        Affine<P> q_next = affine_load<P>(base0 + point_index(e_next) * 16);
         for (uint32_t j = start; j < end; j++) {
             if (j == bend) {  // bucket m ended inside this slice
                 if (bbeg < start) {  // head partial: parked in the stitch buffer, not in registers
@@ -294,13 +330,12 @@ __global__ void __launch_bounds__(T) k_msm_accumulate(const uint32_t* __restrict
                 bbeg = cnt[m - 1];
                 bend = cnt[m];
             }
-            const uint32_t e = sorted[j];
-            size_t pidx = (size_t)(e & 0x7fffu);
-            if (remap) {
-                const size_t g = c0 + pidx, row = g / row_len;
-                pidx = row * row_stride + (g - row * row_len) - c0;
+            const uint32_t e = e_next;
+            Affine<P> q = q_next;
+            if (j + 1 < end) {
+                e_next = sorted[j + 1];
+                q_next = affine_load<P>(base0 + point_index(e_next) * 16);
             }
-            Affine<P> q = affine_load<P>(base0 + pidx * 16);
             if (!aff_is_id(q)) {
                 if (e & 0x8000u) q.y = fe_neg(q.y);
                 xyzz_madd(acc, q);
@@ -416,6 +451,59 @@ __global__ void __launch_bounds__(256) k_msm_reduce(const uint4* __restrict__ bu
         xyzz_add(lo, hi);
         planes_put(winsums, (size_t)gridDim.x, segi, lo);
     }
+}
+
+// ---------------------------------------------------------------------------
+// k_msm_reduce_wave: the same sum, ONE wave per segment and no LDS: lane t owns L = M/64
+// buckets (2L additions), the suffix scan and the final sum run over cross-lane shuffles
+// (6 + 6 steps).  2L + 16 additions per wave instead of (2M/256 + 24) x 4 waves: 2.7x less issued
+// work at M = 1024, which is what counts once there are more segments than SIMDs.
+// ---------------------------------------------------------------------------
+template <class P>
+__device__ __forceinline__ Xyzz<P> xyzz_shfl_down(const Xyzz<P>& v, int d) {
+    Xyzz<P> o;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        o.x.l[k] = (uint32_t)__shfl_down((int)v.x.l[k], d, 64);
+        o.y.l[k] = (uint32_t)__shfl_down((int)v.y.l[k], d, 64);
+        o.zz.l[k] = (uint32_t)__shfl_down((int)v.zz.l[k], d, 64);
+        o.zzz.l[k] = (uint32_t)__shfl_down((int)v.zzz.l[k], d, 64);
+    }
+    return o;
+}
+
+template <class C>
+__global__ void __launch_bounds__(64) k_msm_reduce_wave(const uint4* __restrict__ buckets, int M, uint4* __restrict__ winsums) {
+    using P = typename C::Base;
+    const int lane = threadIdx.x;
+    const size_t segi = blockIdx.x;
+    const uint4* seg = buckets + segi * (size_t)M * 8;
+    const int L = M >> 6;  // host guarantees M >= 64, a power of two
+
+    Xyzz<P> S = xyzz_identity<P>(), W = xyzz_identity<P>();
+    for (int k = L; k >= 1; k--) {
+        Xyzz<P> bkt = planes_get<P>(seg, (size_t)M, (size_t)(lane * L + k - 1));
+        xyzz_add(S, bkt);
+        xyzz_add(W, S);
+    }
+    // inclusive suffix sums of S across lanes
+    Xyzz<P> suf = S;
+#pragma unroll 1
+    for (int d = 1; d < 64; d <<= 1) {
+        Xyzz<P> o = xyzz_shfl_down(suf, d);
+        if (lane + d < 64) xyzz_add(suf, o);
+    }
+    // V_t = W_t + L * Suf_t (t >= 1), then sum V over lanes
+    if (lane >= 1) {
+        for (int k = L; k > 1; k >>= 1) suf = xyzz_dbl(suf);
+        xyzz_add(W, suf);
+    }
+#pragma unroll 1
+    for (int d = 32; d >= 1; d >>= 1) {
+        Xyzz<P> o = xyzz_shfl_down(W, d);
+        if (lane < d) xyzz_add(W, o);
+    }
+    if (lane == 0) planes_put(winsums, (size_t)gridDim.x, segi, W);
 }
 
 // ---------------------------------------------------------------------------
@@ -602,8 +690,13 @@ static int msm_run_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_sca
         const size_t nseg = nb * segs_per_vec;
         {
             ScopedTimer t(ctx, BZH_T_MSM_REDUCE);
-            hipLaunchKernelGGL((k_msm_reduce<C>), dim3((unsigned)nseg), dim3(red_threads), red_lds, ctx->stream,
-                               (const uint4*)d_buckets, p.M, (uint4*)d_winsums);
+            if (p.M >= 64 && nseg >= 256) {
+                hipLaunchKernelGGL((k_msm_reduce_wave<C>), dim3((unsigned)nseg), dim3(64), 0, ctx->stream,
+                                   (const uint4*)d_buckets, p.M, (uint4*)d_winsums);
+            } else {
+                hipLaunchKernelGGL((k_msm_reduce<C>), dim3((unsigned)nseg), dim3(red_threads), red_lds, ctx->stream,
+                                   (const uint4*)d_buckets, p.M, (uint4*)d_winsums);
+            }
         }
         {
             ScopedTimer t(ctx, BZH_T_MSM_FINALIZE);

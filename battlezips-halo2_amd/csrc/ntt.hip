@@ -45,6 +45,12 @@ struct NttPassArgs {
     const uint32_t* pre_hi;
     const uint32_t* post_lo;  // last pass: output k *= post(k)    (n^-1 * shift^-k)
     const uint32_t* post_hi;
+    // Cheap scalings: halo2's extended coset uses shift = ZETA with ZETA^3 = 1, so shift^n takes only
+    // three values; a plain inverse needs the single constant n^-1.  cube[i] multiplies index = i mod 3.
+    int cube_pre;   // first pass: element n *= cube[n % 3] (cube[0] == 1 is skipped)
+    int cube_post;  // last pass:  output k *= cube[k % 3]
+    int tw_always;  // this pass's twiddle table carries a folded n^-1: apply it even when the exponent is 0
+    uint32_t cube[3][8];
 };
 
 template <class P>
@@ -65,6 +71,13 @@ __device__ __forceinline__ Fe<P> pow_table(const uint32_t* lo, const uint32_t* h
     Fe<P> a = fe_load<P>(lo + (e & (((size_t)1 << h) - 1)) * 8);
     Fe<P> b = fe_load<P>(hi + (e >> h) * 8);
     return fe_mul(a, b);
+}
+template <class P>
+__device__ __forceinline__ Fe<P> cube_const(const NttPassArgs& g, unsigned i) {
+    Fe<P> r;
+#pragma unroll
+    for (int k = 0; k < 8; k++) r.l[k] = i == 0 ? g.cube[0][k] : (i == 1 ? g.cube[1][k] : g.cube[2][k]);
+    return r;
 }
 __device__ __forceinline__ uint32_t bitrev(uint32_t x, int bits) { return bits ? (__brev(x) >> (32 - bits)) : 0u; }
 
@@ -88,6 +101,10 @@ __global__ void __launch_bounds__(kNttThreads) k_ntt_pass(NttPassArgs g) {
             const int col = it & (W - 1), row = it >> logW;
             Fe<P> v = fe_load<P>(base + ((size_t)row * B + col) * 8);
             if (g.pre_lo) v = fe_mul(v, pow_table<P>(g.pre_lo, g.pre_hi, g.h, (size_t)row * B + j0 + col));
+            if (g.cube_pre) {
+                const unsigned c3 = (unsigned)(((size_t)row * B + j0 + col) % 3);
+                if (c3) v = fe_mul(v, cube_const<P>(g, c3));
+            }
             tile_put(tile, (int)(bitrev((uint32_t)row, r) << logW) + col, v);
         }
     } else {
@@ -101,6 +118,7 @@ __global__ void __launch_bounds__(kNttThreads) k_ntt_pass(NttPassArgs g) {
             }
             Fe<P> v = fe_load<P>(vin + ((a << r) + rr) * 8);
             if (g.pre_lo) v = fe_mul(v, pow_table<P>(g.pre_lo, g.pre_hi, g.h, (size_t)rr));  // single-pass only
+            if (g.cube_pre && (rr % 3)) v = fe_mul(v, cube_const<P>(g, (unsigned)(rr % 3)));
             tile_put(tile, (int)(bitrev((uint32_t)rr, r) << logW) + i, v);
         }
     }
@@ -129,7 +147,7 @@ __global__ void __launch_bounds__(kNttThreads) k_ntt_pass(NttPassArgs g) {
             const int col = it & (W - 1), row = it >> logW;
             Fe<P> v = tile_get<P>(tile, it);
             const size_t e = ((size_t)row * (j0 + col)) << g.logA;
-            if (e) v = fe_mul(v, pow_table<P>(g.tw_lo, g.tw_hi, g.h, e));
+            if (e || g.tw_always) v = fe_mul(v, pow_table<P>(g.tw_lo, g.tw_hi, g.h, e));
             fe_store(base + ((size_t)row * B + col) * 8, v);
         }
     } else {
@@ -138,6 +156,7 @@ __global__ void __launch_bounds__(kNttThreads) k_ntt_pass(NttPassArgs g) {
             Fe<P> v = tile_get<P>(tile, it);
             const size_t k = ((size_t)kr << g.logA) + (tile_id << logW) + i;
             if (g.post_lo) v = fe_mul(v, pow_table<P>(g.post_lo, g.post_hi, g.h, k));
+            if (g.cube_post) v = fe_mul(v, cube_const<P>(g, (unsigned)(k % 3)));
             fe_store(vec + k * 8, v);
         }
     }
@@ -156,6 +175,9 @@ struct NttDomain {
     int h;
     uint32_t* d_tables = nullptr;  // one allocation
     size_t off_tw_lo, off_tw_hi, off_sc_lo, off_sc_hi;
+    size_t off_tw_hi_scaled;  // omega^(e << h) * n^-1 (inverse domains): pass 0 of a multi-pass plain inverse
+    int shift_is_cube;        // shift^3 == 1, shift != 1
+    uint32_t cube[3][8];      // forward: 1, s, s^2 ; inverse: n^-1, n^-1 s^-1, n^-1 s^-2 (s = 1 without a shift)
     size_t off_sub[12];  // sub-NTT twiddles for radix bits 1..11
 };
 
@@ -210,6 +232,7 @@ static int build_domain(bzh_ctx* ctx, NttDomain& d, const Fe<P>& omega_m, const 
     d.off_tw_hi = words; words += nhi * 8;
     d.off_sc_lo = words; words += nlo * 8;
     d.off_sc_hi = words; words += nhi * 8;
+    d.off_tw_hi_scaled = words; words += nhi * 8;
     for (int rb = 1; rb <= 11; rb++) {
         d.off_sub[rb] = words;
         if ((unsigned)rb <= k) words += ((size_t)1 << (rb - 1)) * 8;
@@ -228,6 +251,17 @@ static int build_domain(bzh_ctx* ctx, NttDomain& d, const Fe<P>& omega_m, const 
     }
     fill_pows<P>(host, d.off_sc_lo, sbase, fe_one<P>(), nlo);
     fill_pows<P>(host, d.off_sc_hi, pow2k(sbase, d.h), first_hi, nhi);
+    fill_pows<P>(host, d.off_tw_hi_scaled, pow2k(w, d.h), first_hi, nhi);
+    {
+        const Fe<P> s2 = fe_sqr(sbase), s3 = fe_mul(s2, sbase);
+        d.shift_is_cube = d.has_shift && fe_eq(s3, fe_one<P>()) && !fe_eq(sbase, fe_one<P>());
+        const Fe<P> c0 = first_hi, c1 = fe_mul(first_hi, sbase), c2 = fe_mul(first_hi, s2);
+        for (int q = 0; q < 8; q++) {
+            d.cube[0][q] = c0.l[q];
+            d.cube[1][q] = c1.l[q];
+            d.cube[2][q] = c2.l[q];
+        }
+    }
     for (int rb = 1; rb <= 11 && (unsigned)rb <= k; rb++) {
         Fe<P> wr = pow2k(w, (int)k - rb);  // omega_N^(N/R)
         fill_pows<P>(host, d.off_sub[rb], wr, fe_one<P>(), (size_t)1 << (rb - 1));
@@ -327,6 +361,26 @@ static int ntt_run_t(bzh_ctx* ctx, uint32_t* d_data, unsigned log_n, size_t batc
         a.pre_hi = dom->d_tables + dom->off_sc_hi;
         a.post_lo = (post && a.last) ? dom->d_tables + dom->off_sc_lo : nullptr;
         a.post_hi = dom->d_tables + dom->off_sc_hi;
+        a.cube_pre = a.cube_post = a.tw_always = 0;
+        memcpy(a.cube, dom->cube, sizeof(a.cube));
+        if (pre && dom->shift_is_cube) {  // coeff_to_extended: shift = ZETA
+            if (p == 0) a.cube_pre = 1;
+            a.pre_lo = nullptr;
+        }
+        if (post) {
+            if (coset_shift && dom->shift_is_cube) {  // extended_to_coeff: n^-1 * ZETA^-k
+                a.post_lo = nullptr;
+                a.cube_post = a.last ? 1 : 0;
+            } else if (!coset_shift) {  // plain ifft: the constant n^-1
+                a.post_lo = nullptr;
+                if (np == 1) {
+                    a.cube_post = 1;  // cube[0..2] all equal n^-1
+                } else if (p == 0) {
+                    a.tw_hi = dom->d_tables + dom->off_tw_hi_scaled;  // folded into the first inter-pass twiddle
+                    a.tw_always = 1;
+                }
+            }
+        }
         const size_t tiles = ((size_t)1 << log_n) >> (a.r + logW);
         {
             ScopedTimer t(ctx, BZH_T_NTT);

@@ -90,3 +90,31 @@ def test_ntt_2_22_roundtrip_and_spot_values(gpu_ctx, oracle_c):
     for i in (0, 5, 123457, n - 1):
         want = sum(v * pow(w, i * j, F.p) for j, v in zip(idx, vals)) % F.p
         assert C.limbs_to_int(out[i]) == want
+
+
+@pytest.mark.parametrize("k", [2, 3, 11, 14, 17])
+def test_coset_zeta_fast_path(gpu_ctx, oracle_c, k):
+    """halo2's extended coset generator is ZETA (a primitive cube root of unity): the library takes a
+    3-constant fast path for shift^3 == 1; results must equal the general-shift oracle."""
+    F = O.FP
+    zeta = pow(F.g, (F.p - 1) // 3, F.p)
+    assert pow(zeta, 3, F.p) == 1 and zeta != 1
+    rng = np.random.default_rng(300 + k)
+    a = rand_elems(rng, 1 << k)
+    w = F.omega(k)
+    fwd = gpu_ctx.ntt(0, a, omega=w, coset_shift=zeta)
+    assert (fwd == C.ntt(0, a, w, coset_shift=zeta, threads=8)).all()
+    inv = gpu_ctx.ntt(0, a, omega=w, inverse=True, coset_shift=zeta)
+    assert (inv == C.ntt(0, a, w, inverse=True, coset_shift=zeta, threads=8)).all()
+    assert (gpu_ctx.ntt(0, fwd, omega=w, inverse=True, coset_shift=zeta) == a).all()
+
+
+@pytest.mark.parametrize("k", [1, 11, 12, 19])
+def test_plain_inverse_all_pass_counts(gpu_ctx, oracle_c, k):
+    """n^-1 is a constant post-multiply for one pass and folded into the first inter-pass twiddle for
+    two (k=12) and three (k=19) passes."""
+    F = O.FQ
+    rng = np.random.default_rng(400 + k)
+    a = rand_elems(rng, 1 << k)
+    w = F.omega(k)
+    assert (gpu_ctx.ntt(1, a, omega=w, inverse=True) == C.ntt(1, a, w, inverse=True, threads=8)).all()
