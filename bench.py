@@ -256,6 +256,18 @@ def main():
             alg = wl.alg_bytes_msm_launch
             dom_name = "k_msm_accumulate"
         achieved = alg / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        # HBM-side traffic of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+        # WRITE_SIZE in separate runs of this same command; tools/pmc_traffic.py), if one exists for this workload
+        traffic, traffic_src = None, None
+        tj = os.path.join(ROOT, "profiles", "r01_e_%s_pmc_traffic.json" % args.workload)
+        if os.path.exists(tj) and args.workload != "ntt22":
+            try:
+                for e in json.load(open(tj))["kernels"]:
+                    if "k_msm_accumulate" in e["kernel"] and e["workgroup"] >= 512:
+                        traffic = e["read_bytes_raw"] + e["write_bytes"]
+                        traffic_src = os.path.relpath(tj, ROOT) + " (raw FETCH_SIZE: 64-B gathers, see its calibration note)"
+            except Exception:
+                traffic = None
         line = {
             "metric": ("%s proof MSM+NTT workloads per second" % args.workload) if is_proof else ("%s runs per second" % args.workload),
             "value": units / elapsed,
@@ -271,7 +283,7 @@ def main():
                             "algorithmic_GB_per_step": wl.alg_bytes_step / 1e9,
                             "whole_step_GBps": wl.alg_bytes_step * args.steps / elapsed / 1e9}, **wl.desc),
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg, "avg_launch_ms": dom_ms},
             "kernel_ms": {kname: v for kname, v in timings.items() if v["launches"]},
         }
