@@ -468,3 +468,32 @@ def _ctx_ipa_verify(self, bases: Bases, commitment, x3: int, v: int, proof: byte
 
 Context.ipa_open = _ctx_ipa_open
 Context.ipa_verify = _ctx_ipa_verify
+
+
+# ---- gate-expression evaluation (row a13) ------------------------------------------------------
+EXPORTS += ["bzh_expr_eval"]
+
+
+def _ctx_expr_eval(self, field: int, program, columns, form: int = FORM_CANONICAL) -> np.ndarray:
+    """Evaluate a compiled bzh2.expr.Program at every row; columns: list of (size, 4) uint64 arrays."""
+    from . import expr as _expr
+    L = load()
+    vp = ctypes.c_void_p
+    L.bzh_expr_eval.argtypes = [vp, ctypes.c_int, ctypes.POINTER(_expr.ExprOp), ctypes.c_size_t, ctypes.POINTER(vp), ctypes.c_size_t,
+                                vp, ctypes.c_size_t, ctypes.c_uint, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]
+    cols = [_as_elems(c) for c in columns]
+    size = cols[0].shape[0] if cols else 1
+    log_size = size.bit_length() - 1
+    assert all(c.shape[0] == size for c in cols) and (1 << log_size) == size
+    ptrs = (vp * max(len(cols), 1))(*[c.ctypes.data for c in cols])
+    consts = np.ascontiguousarray(np.stack([int_to_limbs(v) for v in program.consts]) if program.consts
+                                  else np.zeros((1, 4), dtype=np.uint64))
+    out = np.zeros((size, 4), dtype=np.uint64)
+    ops = program.as_array()
+    rc = L.bzh_expr_eval(self.handle, field, ops, len(program.ops), ptrs, len(cols), _vp(consts), len(program.consts), log_size,
+                         program.result_slot, form, MEM_HOST, _vp(out))
+    self._check(rc, "bzh_expr_eval")
+    return out
+
+
+Context.expr_eval = _ctx_expr_eval

@@ -473,6 +473,53 @@ int bzh_vec_mul(bzh_ctx* ctx, int field, uint64_t* a, const uint64_t* b, size_t 
     return s.out(a, da, count);
 }
 
+int bzh_expr_eval(bzh_ctx* ctx, int field, const bzh_expr_op* prog, size_t nops, const uint64_t* const* columns, size_t ncols,
+                  const uint64_t* consts, size_t nconsts, unsigned log_size, int result_slot, int form, int mem, uint64_t* out) {
+    BZH_POLY_PROLOGUE(!prog || !nops || (!columns && ncols) || (!consts && nconsts) || !out || log_size > 30 ||
+                      result_slot < 0 || result_slot >= BZH_EXPR_MAX_SLOTS);
+    const size_t size = (size_t)1 << log_size;
+    for (size_t i = 0; i < nops; i++) {  // validate the program: it indexes device memory
+        const bzh_expr_op& o = prog[i];
+        if (o.op > BZH_EXPR_COPY || o.dst >= BZH_EXPR_MAX_SLOTS) return BZH_E_ARG;
+        const int kinds[2] = {o.a_kind, (o.op == BZH_EXPR_NEG || o.op == BZH_EXPR_COPY) ? BZH_EXPR_SLOT : o.b_kind};
+        const int idxs[2] = {o.a_idx, (o.op == BZH_EXPR_NEG || o.op == BZH_EXPR_COPY) ? 0 : o.b_idx};
+        for (int q = 0; q < 2; q++) {
+            if (kinds[q] == BZH_EXPR_SLOT && (idxs[q] < 0 || idxs[q] >= BZH_EXPR_MAX_SLOTS)) return BZH_E_ARG;
+            if (kinds[q] == BZH_EXPR_COLUMN && (idxs[q] < 0 || (size_t)idxs[q] >= ncols)) return BZH_E_ARG;
+            if (kinds[q] == BZH_EXPR_CONST && (idxs[q] < 0 || (size_t)idxs[q] >= nconsts)) return BZH_E_ARG;
+            if (kinds[q] > BZH_EXPR_CONST || kinds[q] < 0) return BZH_E_ARG;
+        }
+    }
+    if (mem == BZH_MEM_DEVICE && form != BZH_FORM_MONTGOMERY) return BZH_E_ARG;
+    Stager s{ctx, field, form};
+    const size_t host_cols = mem == BZH_MEM_HOST ? ncols : 0;
+    if ((rc = s.begin((host_cols * size + nconsts + (mem == BZH_MEM_HOST ? size : 0)) * 32 + nops * sizeof(bzh_expr_op) +
+                      ncols * sizeof(void*) + 1024)))
+        return rc;
+    std::vector<const uint32_t*> ptrs(ncols);
+    for (size_t c = 0; c < ncols; c++) {
+        if (mem == BZH_MEM_HOST) {
+            uint32_t* d;
+            if ((rc = s.in(columns[c], size, &d))) return rc;
+            ptrs[c] = d;
+        } else {
+            ptrs[c] = (const uint32_t*)columns[c];
+        }
+    }
+    uint32_t* d_consts;
+    if ((rc = s.in(consts, nconsts, &d_consts))) return rc;
+    uint32_t* d_prog = s.carve(nops * sizeof(bzh_expr_op));
+    uint32_t* d_ptrs = s.carve(ncols * sizeof(void*) + 8);
+    BZH_HIP_TRY(ctx, hipMemcpyAsync(d_prog, prog, nops * sizeof(bzh_expr_op), hipMemcpyHostToDevice, ctx->stream));
+    if (ncols) BZH_HIP_TRY(ctx, hipMemcpyAsync(d_ptrs, ptrs.data(), ncols * sizeof(void*), hipMemcpyHostToDevice, ctx->stream));
+    uint32_t* d_out = mem == BZH_MEM_HOST ? s.carve(size * 32) : (uint32_t*)out;
+    rc = expr_eval(ctx, field, d_prog, (int)nops, (const uint32_t* const*)d_ptrs, d_consts, size, result_slot, d_out);
+    if (rc) return rc;
+    if (mem == BZH_MEM_HOST) return s.out(out, d_out, size);
+    BZH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // ptrs / prog staging is reused by the next call
+    return BZH_OK;
+}
+
 int bzh_ipa_open(bzh_ctx* ctx, const bzh_bases* bases, const uint64_t* poly, int form, int mem, const uint64_t* blind,
                  const uint64_t* x3, const uint8_t* rng, size_t rng_len, bzh_transcript* transcript, uint64_t* out_v) {
     if (!ctx || !bases || !poly || !blind || !x3 || !rng || !transcript || !out_v || !valid_form(form) || !valid_mem(mem))

@@ -111,6 +111,9 @@ int poly_inner_product(bzh_ctx* ctx, int field, const uint32_t* a, const uint32_
 int poly_fold(bzh_ctx* ctx, int field, const uint32_t* in, size_t half, size_t batch, const uint32_t* u, size_t u_stride,
               uint32_t* out);
 int poly_vec_mul(bzh_ctx* ctx, int field, uint32_t* a, const uint32_t* b, size_t count);
+// exprvm.hip
+int expr_eval(bzh_ctx* ctx, int field, const void* d_prog, int nops, const uint32_t* const* d_cols, const uint32_t* d_consts,
+              size_t size, int result_slot, uint32_t* d_out);
 // ipa.hip
 int ipa_open(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_poly, const uint64_t* blind, const uint64_t* x3,
              const uint8_t* rng_bytes, bzh_transcript* tr, uint64_t* out_v);

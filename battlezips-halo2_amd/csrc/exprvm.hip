@@ -1,0 +1,86 @@
+// Gate-expression evaluator over the extended coset.
+//
+// Device counterpart of halo2_proofs 0.2.0 `poly::Evaluator` as driven by
+// `vanishing::Argument::construct` in plonk::create_proof step 6 (UPSTREAM, un-vendored:
+// Cargo.lock:382-385; entered from benches/shot.rs:68, src/circuits/board.rs:913-920): every
+// custom gate, the permutation and the lookup identities are evaluated at each of the 2^(k+3)
+// points of the extended domain and folded with powers of y.  The gates are DATA here
+// (the 24 Shot / 57 Board gates, 19 of them from halo2_gadgets, live in crates this repository
+// cannot read): a straight-line program over
+//     COLUMN(c, rot)  value of column c at row (r + rot) mod size   (rot in extended-domain steps)
+//     CONST(i)        i-th constant (challenges, y, selectors folded by the host, ...)
+//     SLOT(s)         an earlier intermediate
+// with ops ADD / SUB / MUL / NEG / COPY, compiled on the host from halo2-style expression trees
+// (battlezips-halo2_amd/bzh2/expr.py).  One thread per row; intermediates live in a small private
+// slot file.  Modular-integer VALU work, no MFMA.
+#include "ctx.hpp"
+#include "field.cuh"
+
+namespace bzh {
+
+static constexpr int kExprSlots = 24;
+
+struct ExprOp {  // mirrors bzh_expr_op
+    uint8_t op, dst, a_kind, b_kind;
+    int32_t a_idx, b_idx, a_rot, b_rot;
+};
+
+template <class P>
+__device__ __forceinline__ Fe<P> expr_operand(int kind, int idx, int rot, const Fe<P>* slots, const uint32_t* const* cols,
+                                               const uint32_t* consts, size_t r, size_t mask) {
+    if (kind == BZH_EXPR_SLOT) return slots[idx];
+    if (kind == BZH_EXPR_CONST) return fe_load<P>(consts + (size_t)idx * 8);
+    const size_t row = (r + (size_t)(int64_t)rot) & mask;  // two's complement wrap, size is a power of two
+    return fe_load<P>(cols[idx] + row * 8);
+}
+
+template <class P>
+__global__ void __launch_bounds__(256) k_expr_eval(const ExprOp* __restrict__ prog, int nops, const uint32_t* const* __restrict__ cols,
+                                                     const uint32_t* __restrict__ consts, size_t size, int result_slot,
+                                                     uint32_t* __restrict__ out) {
+    const size_t r = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (r >= size) return;
+    const size_t mask = size - 1;
+    Fe<P> slots[kExprSlots];
+    for (int i = 0; i < nops; i++) {
+        const ExprOp op = prog[i];  // wave-uniform: scalar loads
+        const Fe<P> a = expr_operand<P>(op.a_kind, op.a_idx, op.a_rot, slots, cols, consts, r, mask);
+        Fe<P> v;
+        if (op.op == BZH_EXPR_NEG) {
+            v = fe_neg(a);
+        } else if (op.op == BZH_EXPR_COPY) {
+            v = a;
+        } else {
+            const Fe<P> b = expr_operand<P>(op.b_kind, op.b_idx, op.b_rot, slots, cols, consts, r, mask);
+            v = op.op == BZH_EXPR_ADD ? fe_add(a, b) : (op.op == BZH_EXPR_SUB ? fe_sub(a, b) : fe_mul(a, b));
+        }
+        slots[op.dst] = v;
+    }
+    fe_store(out + r * 8, slots[result_slot]);
+}
+
+template <class P>
+static int expr_eval_t(bzh_ctx* ctx, const ExprOp* d_prog, int nops, const uint32_t* const* d_cols, const uint32_t* d_consts,
+                       size_t size, int result_slot, uint32_t* d_out) {
+    ScopedTimer t(ctx, BZH_T_POLY);
+    hipLaunchKernelGGL((k_expr_eval<P>), dim3((unsigned)((size + 255) / 256)), dim3(256), 0, ctx->stream, d_prog, nops, d_cols,
+                       d_consts, size, result_slot, d_out);
+    BZH_HIP_TRY(ctx, hipGetLastError());
+    return BZH_OK;
+}
+
+int expr_eval(bzh_ctx* ctx, int field, const void* d_prog, int nops, const uint32_t* const* d_cols, const uint32_t* d_consts,
+              size_t size, int result_slot, uint32_t* d_out) {
+    const ExprOp* p = (const ExprOp*)d_prog;
+    switch (field) {
+        case BZH_FIELD_FP: return expr_eval_t<FpParams>(ctx, p, nops, d_cols, d_consts, size, result_slot, d_out);
+        case BZH_FIELD_FQ: return expr_eval_t<FqParams>(ctx, p, nops, d_cols, d_consts, size, result_slot, d_out);
+        case BZH_FIELD_BN254_FR: return expr_eval_t<BnFrParams>(ctx, p, nops, d_cols, d_consts, size, result_slot, d_out);
+        case BZH_FIELD_BN254_FQ: return expr_eval_t<BnFqParams>(ctx, p, nops, d_cols, d_consts, size, result_slot, d_out);
+    }
+    return BZH_E_ARG;
+}
+
+int expr_slots() { return kExprSlots; }
+
+}  // namespace bzh

@@ -177,6 +177,24 @@ int bzh_transcript_write_scalar(bzh_transcript* t, const uint64_t* s_canonical);
 int bzh_transcript_squeeze_challenge(bzh_transcript* t, uint64_t* out_canonical);
 int bzh_transcript_proof(const bzh_transcript* t, const uint8_t** data, size_t* len);
 
+/* ---- gate-expression evaluation over the extended coset (row a13: poly::Evaluator + vanishing::construct) --
+ * A straight-line program evaluated at every row r < 2^log_size:
+ *   operand kinds  BZH_EXPR_SLOT (idx = slot), BZH_EXPR_COLUMN (idx = column, rot = row offset, wraps mod size),
+ *                  BZH_EXPR_CONST (idx = constant);
+ *   ops            ADD, SUB, MUL (a, b);  NEG, COPY (a);  dst = slot < BZH_EXPR_MAX_SLOTS.
+ * out[r] = slot `result_slot` after the last op.  columns: host array of ncols pointers (each 2^log_size
+ * elements, `mem` says where they live); consts: nconsts elements (host).  A rotation by t rows of the
+ * 2^k-row circuit is rot = t * 2^(log_size - k) on the extended domain. */
+enum { BZH_EXPR_ADD = 0, BZH_EXPR_SUB = 1, BZH_EXPR_MUL = 2, BZH_EXPR_NEG = 3, BZH_EXPR_COPY = 4 };
+enum { BZH_EXPR_SLOT = 0, BZH_EXPR_COLUMN = 1, BZH_EXPR_CONST = 2 };
+enum { BZH_EXPR_MAX_SLOTS = 24 };
+typedef struct {
+    uint8_t op, dst, a_kind, b_kind;
+    int32_t a_idx, b_idx, a_rot, b_rot;
+} bzh_expr_op;
+int bzh_expr_eval(bzh_ctx* ctx, int field, const bzh_expr_op* prog, size_t nops, const uint64_t* const* columns, size_t ncols,
+                  const uint64_t* consts, size_t nconsts, unsigned log_size, int result_slot, int form, int mem, uint64_t* out);
+
 /* ---- inner-product-argument opening (halo2_proofs poly::commitment::{create_proof, verify_proof}) --
  * Step 9 of plonk::create_proof and the heart of verify_proof (benches/board.rs:80-86).
  * `bases` must hold n + 2 points: the n = 2^k SRS generators followed by U and W (Params.u, Params.w);
