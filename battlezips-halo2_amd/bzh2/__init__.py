@@ -497,3 +497,36 @@ def _ctx_expr_eval(self, field: int, program, columns, form: int = FORM_CANONICA
 
 
 Context.expr_eval = _ctx_expr_eval
+
+
+# ---- multiopen / lookup helpers ---------------------------------------------------------------------
+EXPORTS += ["bzh_kate_division", "bzh_permute_expression_pair"]
+
+
+def _ctx_kate_division(self, field: int, coeffs, x: int, form: int = FORM_CANONICAL) -> np.ndarray:
+    """arithmetic::kate_division: quotient of p(X) by (X - x) (n-1 coefficients)."""
+    c = _as_elems(coeffs)
+    n = c.shape[0]
+    out = np.zeros((max(n - 1, 0), 4), dtype=np.uint64)
+    L = load()
+    vp = ctypes.c_void_p
+    L.bzh_kate_division.argtypes = [vp, ctypes.c_int, vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int, ctypes.c_int, vp]
+    self._check(L.bzh_kate_division(self.handle, field, _vp(c), n, _u64(int_to_limbs(x)), form, MEM_HOST, _vp(out)), "bzh_kate_division")
+    return out
+
+
+Context.kate_division = _ctx_kate_division
+
+
+def permute_expression_pair(field: int, input_vals, table_vals, usable_rows: int, form: int = FORM_CANONICAL):
+    """lookup::prover::permute_expression_pair over the first usable_rows rows -> (permuted_input, permuted_table)."""
+    a, t = _as_elems(input_vals), _as_elems(table_vals)
+    oa = np.zeros((usable_rows, 4), dtype=np.uint64)
+    ot = np.zeros((usable_rows, 4), dtype=np.uint64)
+    L = load()
+    vp = ctypes.c_void_p
+    L.bzh_permute_expression_pair.argtypes = [ctypes.c_int, vp, vp, ctypes.c_size_t, ctypes.c_int, vp, vp]
+    rc = L.bzh_permute_expression_pair(field, _vp(a), _vp(t), usable_rows, form, _vp(oa), _vp(ot))
+    if rc != OK:
+        raise BzhError(rc, "bzh_permute_expression_pair")
+    return oa, ot

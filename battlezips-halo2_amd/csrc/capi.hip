@@ -1,6 +1,7 @@
 // C ABI entry points (include/bzh2.h): context, base tables, host<->device
 // staging around the MSM / NTT drivers, and the host-side helpers.
 #include <cstring>
+#include <algorithm>
 #include <new>
 #include <vector>
 
@@ -135,6 +136,54 @@ static void omega_host(unsigned S, uint32_t gen, unsigned log_n, int form, uint6
     Fe<P> root = fe_pow(g, sh);
     for (unsigned i = log_n; i < S; i++) root = fe_sqr(root);
     store_host<P>(out, root, form);
+}
+
+template <class PP>
+static int permute_pair_host(const uint64_t* input, const uint64_t* table, size_t usable, int form, uint64_t* out_input,
+                             uint64_t* out_table) {
+    // canonical values as sortable keys (pasta_curves orders field elements by canonical value)
+    struct Key {
+        uint64_t l[4];
+        bool operator<(const Key& o) const {
+            for (int i = 3; i >= 0; i--)
+                if (l[i] != o.l[i]) return l[i] < o.l[i];
+            return false;
+        }
+        bool operator==(const Key& o) const { return !memcmp(l, o.l, 32); }
+    };
+    std::vector<Key> a(usable), t(usable);
+    for (size_t i = 0; i < usable; i++) {
+        store_host<PP>(a[i].l, load_host<PP>(input + 4 * i, form), BZH_FORM_CANONICAL);
+        store_host<PP>(t[i].l, load_host<PP>(table + 4 * i, form), BZH_FORM_CANONICAL);
+    }
+    std::sort(a.begin(), a.end());
+    std::sort(t.begin(), t.end());
+    // leftover multiset = table minus one copy of every distinct input value
+    std::vector<Key> s(usable);
+    std::vector<size_t> repeated;
+    std::vector<char> used(usable, 0);
+    size_t tp = 0;
+    for (size_t i = 0; i < usable; i++) {
+        if (i == 0 || !(a[i] == a[i - 1])) {
+            while (tp < usable && t[tp] < a[i]) tp++;
+            if (tp >= usable || !(t[tp] == a[i])) return BZH_E_RANGE;  // input value not in the table
+            used[tp++] = 1;
+            s[i] = a[i];
+        } else {
+            repeated.push_back(i);
+        }
+    }
+    for (size_t j = 0; j < usable; j++) {  // ascending leftovers go to the repeated rows from the last one backwards
+        if (used[j]) continue;
+        if (repeated.empty()) return BZH_E_RANGE;
+        s[repeated.back()] = t[j];
+        repeated.pop_back();
+    }
+    for (size_t i = 0; i < usable; i++) {
+        store_host<PP>(out_input + 4 * i, load_host<PP>(a[i].l, BZH_FORM_CANONICAL), form);
+        store_host<PP>(out_table + 4 * i, load_host<PP>(s[i].l, BZH_FORM_CANONICAL), form);
+    }
+    return BZH_OK;
 }
 
 }  // namespace
@@ -471,6 +520,63 @@ int bzh_vec_mul(bzh_ctx* ctx, int field, uint64_t* a, const uint64_t* b, size_t 
     if ((rc = s.in(b, count, &db))) return rc;
     if ((rc = poly_vec_mul(ctx, field, da, db, count))) return rc;
     return s.out(a, da, count);
+}
+
+int bzh_kate_division(bzh_ctx* ctx, int field, const uint64_t* coeffs, size_t n, const uint64_t* x, int form, int mem,
+                      uint64_t* out) {
+    BZH_POLY_PROLOGUE(!coeffs || !x || !out || n < 1);
+    if (n == 1) return BZH_OK;
+    if (mem == BZH_MEM_DEVICE && form != BZH_FORM_MONTGOMERY) return BZH_E_ARG;
+    // x^-1 on the host (one inversion), both uploaded in Montgomery form
+    uint64_t xs[8];
+    int x_is_zero = 0;
+    {
+        uint64_t xin[4];
+        memcpy(xin, x, 32);
+        auto go = [&](auto tag) {
+            using PP = decltype(tag);
+            Fe<PP> xm = load_host<PP>(xin, form);
+            x_is_zero = fe_is_zero(xm);
+            store_host<PP>(xs, xm, BZH_FORM_MONTGOMERY);
+            store_host<PP>(xs + 4, fe_inv(xm), BZH_FORM_MONTGOMERY);
+        };
+        switch (field) {
+            case BZH_FIELD_FP: go(FpParams{}); break;
+            case BZH_FIELD_FQ: go(FqParams{}); break;
+            case BZH_FIELD_BN254_FR: go(BnFrParams{}); break;
+            default: go(BnFqParams{}); break;
+        }
+    }
+    Stager s{ctx, field, BZH_FORM_MONTGOMERY};
+    if ((rc = s.begin((2 * n + 4) * 32 + 512))) return rc;
+    uint32_t* d_x;
+    if ((rc = s.in(xs, 2, &d_x))) return rc;
+    uint32_t* d_c;
+    uint32_t* d_q;
+    if (mem == BZH_MEM_HOST) {
+        Stager sc{ctx, field, form};
+        sc.cur = s.cur;
+        if ((rc = sc.in(coeffs, n, &d_c))) return rc;
+        d_q = sc.carve((n - 1) * 32);
+        rc = poly_kate_division(ctx, field, d_c, n, d_x, d_x + 8, x_is_zero, d_q);
+        if (rc) return rc;
+        return sc.out(out, d_q, n - 1);
+    }
+    rc = poly_kate_division(ctx, field, (const uint32_t*)coeffs, n, d_x, d_x + 8, x_is_zero, (uint32_t*)out);
+    if (rc) return rc;
+    BZH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // d_x staging is reused by the next call
+    return BZH_OK;
+}
+
+int bzh_permute_expression_pair(int field, const uint64_t* input, const uint64_t* table, size_t usable_rows, int form,
+                                uint64_t* out_input, uint64_t* out_table) {
+    if (!valid_field(field) || !valid_form(form) || ((!input || !table || !out_input || !out_table) && usable_rows)) return BZH_E_ARG;
+    switch (field) {
+        case BZH_FIELD_FP: return permute_pair_host<FpParams>(input, table, usable_rows, form, out_input, out_table);
+        case BZH_FIELD_FQ: return permute_pair_host<FqParams>(input, table, usable_rows, form, out_input, out_table);
+        case BZH_FIELD_BN254_FR: return permute_pair_host<BnFrParams>(input, table, usable_rows, form, out_input, out_table);
+        default: return permute_pair_host<BnFqParams>(input, table, usable_rows, form, out_input, out_table);
+    }
 }
 
 int bzh_expr_eval(bzh_ctx* ctx, int field, const bzh_expr_op* prog, size_t nops, const uint64_t* const* columns, size_t ncols,

@@ -111,6 +111,8 @@ int poly_inner_product(bzh_ctx* ctx, int field, const uint32_t* a, const uint32_
 int poly_fold(bzh_ctx* ctx, int field, const uint32_t* in, size_t half, size_t batch, const uint32_t* u, size_t u_stride,
               uint32_t* out);
 int poly_vec_mul(bzh_ctx* ctx, int field, uint32_t* a, const uint32_t* b, size_t count);
+int poly_kate_division(bzh_ctx* ctx, int field, const uint32_t* d_c, size_t n, const uint32_t* d_x, const uint32_t* d_xinv,
+                       int x_is_zero, uint32_t* d_q);
 // exprvm.hip
 int expr_eval(bzh_ctx* ctx, int field, const void* d_prog, int nops, const uint32_t* const* d_cols, const uint32_t* d_consts,
               size_t size, int result_slot, uint32_t* d_out);

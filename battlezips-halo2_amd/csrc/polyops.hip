@@ -55,6 +55,17 @@ __global__ void __launch_bounds__(kVecThreads) k_batch_invert(uint32_t* __restri
 static constexpr int kScanTile = 2048;  // 256 threads x 8 consecutive elements
 
 template <class P>
+struct MulOp {
+    static __device__ __forceinline__ Fe<P> id() { return fe_one<P>(); }
+    static __device__ __forceinline__ Fe<P> op(const Fe<P>& a, const Fe<P>& b) { return fe_mul(a, b); }
+};
+template <class P>
+struct AddOp {
+    static __device__ __forceinline__ Fe<P> id() { return fe_zero<P>(); }
+    static __device__ __forceinline__ Fe<P> op(const Fe<P>& a, const Fe<P>& b) { return fe_add(a, b); }
+};
+
+template <class P, class Op>
 __global__ void __launch_bounds__(256) k_scan_tiles(uint32_t* __restrict__ data, size_t n, size_t tiles_per_vec,
                                                       uint32_t* __restrict__ totals) {
     __shared__ __align__(16) uint4 sh[2][2 * 256];
@@ -64,15 +75,15 @@ __global__ void __launch_bounds__(256) k_scan_tiles(uint32_t* __restrict__ data,
     const size_t lim = min((size_t)kScanTile, n - tile * kScanTile);
     // thread-local products over 8 consecutive elements
     Fe<P> loc[8];
-    Fe<P> run = fe_one<P>();
+    Fe<P> run = Op::id();
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         size_t i = (size_t)tid * 8 + k;
-        loc[k] = i < lim ? fe_load<P>(base + i * 8) : fe_one<P>();
+        loc[k] = i < lim ? fe_load<P>(base + i * 8) : Op::id();
     }
     Fe<P> tot = loc[0];
 #pragma unroll
-    for (int k = 1; k < 8; k++) tot = fe_mul(tot, loc[k]);
+    for (int k = 1; k < 8; k++) tot = Op::op(tot, loc[k]);
     // inclusive Hillis-Steele scan of the 256 thread totals in LDS (planes layout)
     int cur = 0;
     Fe<P> incl = tot;
@@ -85,7 +96,7 @@ __global__ void __launch_bounds__(256) k_scan_tiles(uint32_t* __restrict__ data,
             Fe<P> o;
             o.l[0] = a.x; o.l[1] = a.y; o.l[2] = a.z; o.l[3] = a.w;
             o.l[4] = b.x; o.l[5] = b.y; o.l[6] = b.z; o.l[7] = b.w;
-            incl = fe_mul(incl, o);
+            incl = Op::op(incl, o);
         }
         cur ^= 1;
     }
@@ -102,25 +113,25 @@ __global__ void __launch_bounds__(256) k_scan_tiles(uint32_t* __restrict__ data,
     for (int k = 0; k < 8; k++) {
         size_t i = (size_t)tid * 8 + k;
         if (i < lim) fe_store(base + i * 8, run);
-        run = fe_mul(run, loc[k]);
+        run = Op::op(run, loc[k]);
     }
     if (tid == 255) fe_store(totals + (vec * tiles_per_vec + tile) * 8, incl);
 }
 
-template <class P>
+template <class P, class Op>
 __global__ void __launch_bounds__(64) k_scan_totals(uint32_t* __restrict__ totals, size_t tiles_per_vec, size_t batch) {
     const size_t vec = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (vec >= batch) return;
-    Fe<P> run = fe_one<P>();
+    Fe<P> run = Op::id();
     uint32_t* t = totals + vec * tiles_per_vec * 8;
     for (size_t k = 0; k < tiles_per_vec; k++) {
         Fe<P> v = fe_load<P>(t + k * 8);
         fe_store(t + k * 8, run);
-        run = fe_mul(run, v);
+        run = Op::op(run, v);
     }
 }
 
-template <class P>
+template <class P, class Op>
 __global__ void __launch_bounds__(256) k_scan_apply(uint32_t* __restrict__ data, size_t n, size_t tiles_per_vec,
                                                       const uint32_t* __restrict__ totals) {
     const size_t vec = blockIdx.y, tile = blockIdx.x;
@@ -128,7 +139,7 @@ __global__ void __launch_bounds__(256) k_scan_apply(uint32_t* __restrict__ data,
     const Fe<P> off = fe_load<P>(totals + (vec * tiles_per_vec + tile) * 8);
     uint32_t* base = data + (vec * n + tile * kScanTile) * 8;
     const size_t lim = min((size_t)kScanTile, n - tile * kScanTile);
-    for (size_t i = threadIdx.x; i < lim; i += 256) fe_store(base + i * 8, fe_mul(fe_load<P>(base + i * 8), off));
+    for (size_t i = threadIdx.x; i < lim; i += 256) fe_store(base + i * 8, Op::op(fe_load<P>(base + i * 8), off));
 }
 
 // ---------------------------------------------------------------------------
@@ -245,22 +256,22 @@ static int batch_invert_t(bzh_ctx* ctx, uint32_t* d, size_t count) {
     return BZH_OK;
 }
 
-template <class P>
-static int prefix_product_t(bzh_ctx* ctx, uint32_t* d, size_t n, size_t batch) {
+template <class P, class Op>
+static int prefix_scan_t(bzh_ctx* ctx, uint32_t* d, size_t n, size_t batch) {
     if (!n || !batch) return BZH_OK;
     const size_t tiles = (n + kScanTile - 1) / kScanTile;
     void* tot = nullptr;
-    int rc = ws_ensure(ctx, 0, tiles * batch * 32, &tot);
+    int rc = ws_ensure(ctx, 2, tiles * batch * 32, &tot);
     if (rc) return rc;
     ScopedTimer t(ctx, BZH_T_POLY);
     for (size_t b0 = 0; b0 < batch; b0 += 65535) {
         const size_t nb = batch - b0 < 65535 ? batch - b0 : 65535;
         uint32_t* dd = d + b0 * n * 8;
         uint32_t* tt = (uint32_t*)tot + b0 * tiles * 8;
-        hipLaunchKernelGGL((k_scan_tiles<P>), dim3((unsigned)tiles, (unsigned)nb), dim3(256), 0, ctx->stream, dd, n, tiles, tt);
+        hipLaunchKernelGGL((k_scan_tiles<P, Op>), dim3((unsigned)tiles, (unsigned)nb), dim3(256), 0, ctx->stream, dd, n, tiles, tt);
         if (tiles > 1) {
-            hipLaunchKernelGGL((k_scan_totals<P>), dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, ctx->stream, tt, tiles, nb);
-            hipLaunchKernelGGL((k_scan_apply<P>), dim3((unsigned)tiles, (unsigned)nb), dim3(256), 0, ctx->stream, dd, n, tiles, tt);
+            hipLaunchKernelGGL((k_scan_totals<P, Op>), dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, ctx->stream, tt, tiles, nb);
+            hipLaunchKernelGGL((k_scan_apply<P, Op>), dim3((unsigned)tiles, (unsigned)nb), dim3(256), 0, ctx->stream, dd, n, tiles, tt);
         }
     }
     BZH_HIP_TRY(ctx, hipGetLastError());
@@ -292,13 +303,80 @@ int poly_batch_invert(bzh_ctx* ctx, int field, uint32_t* d, size_t count) {
 #undef CALL
 }
 int poly_prefix_product(bzh_ctx* ctx, int field, uint32_t* d, size_t n, size_t batch) {
-#define CALL(PP) prefix_product_t<PP>(ctx, d, n, batch)
+#define CALL(PP) prefix_scan_t<PP, MulOp<PP>>(ctx, d, n, batch)
     BZH_FIELD_SWITCH(field, CALL)
 #undef CALL
 }
 int poly_eval(bzh_ctx* ctx, int field, const uint32_t* coeffs, size_t n, size_t batch, const uint32_t* xs, size_t x_stride,
               uint32_t* out) {
 #define CALL(PP) eval_poly_t<PP>(ctx, coeffs, n, batch, xs, x_stride, out)
+    BZH_FIELD_SWITCH(field, CALL)
+#undef CALL
+}
+
+// ---------------------------------------------------------------------------
+// kate_division: quotient of p(X) by (X - x).  With d_t = c_(n-1-t) the quotient obeys the Horner
+// recurrence r_k = x r_(k-1) + d_k, i.e. r_k = x^k * sum_(t<=k) d_t x^-t: one element-wise pass,
+// one additive scan, one element-wise pass (q_(n-2-k) = r_k, the remainder r_(n-1) = p(x) is dropped).
+// ---------------------------------------------------------------------------
+template <class P>
+__device__ __forceinline__ Fe<P> fe_pow_u64(Fe<P> base, size_t e) {
+    Fe<P> acc = fe_one<P>();
+    for (; e; e >>= 1) {
+        if (e & 1) acc = fe_mul(acc, base);
+        base = fe_sqr(base);
+    }
+    return acc;
+}
+template <class P>
+__global__ void __launch_bounds__(kVecThreads) k_kate_pre(const uint32_t* __restrict__ c, size_t n, const uint32_t* __restrict__ xinv,
+                                                            uint32_t* __restrict__ a) {
+    const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    fe_store(a + t * 8, fe_mul(fe_load<P>(c + (n - 1 - t) * 8), fe_pow_u64(fe_load<P>(xinv), t)));
+}
+template <class P>
+__global__ void __launch_bounds__(kVecThreads) k_kate_post(const uint32_t* __restrict__ excl, const uint32_t* __restrict__ a, size_t n,
+                                                             const uint32_t* __restrict__ x, uint32_t* __restrict__ q) {
+    const size_t k = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (k + 1 >= n) return;  // k <= n-2
+    const Fe<P> incl = fe_add(fe_load<P>(excl + k * 8), fe_load<P>(a + k * 8));
+    fe_store(q + (n - 2 - k) * 8, fe_mul(incl, fe_pow_u64(fe_load<P>(x), k)));
+}
+// x == 0: q_(i-1) = c_i
+template <class P>
+__global__ void __launch_bounds__(kVecThreads) k_shift_down(const uint32_t* __restrict__ c, size_t n, uint32_t* __restrict__ q) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i + 1 >= n) return;
+    fe_store(q + i * 8, fe_load<P>(c + (i + 1) * 8));
+}
+
+template <class P>
+static int kate_t(bzh_ctx* ctx, const uint32_t* d_c, size_t n, const uint32_t* d_x, const uint32_t* d_xinv, int x_is_zero,
+                  uint32_t* d_q) {
+    if (n < 2) return BZH_OK;
+    const dim3 grid((unsigned)((n + kVecThreads - 1) / kVecThreads)), block(kVecThreads);
+    if (x_is_zero) {
+        hipLaunchKernelGGL((k_shift_down<P>), grid, block, 0, ctx->stream, d_c, n, d_q);
+        BZH_HIP_TRY(ctx, hipGetLastError());
+        return BZH_OK;
+    }
+    void* w = nullptr;
+    int rc = ws_ensure(ctx, 1, 2 * n * 32, &w);
+    if (rc) return rc;
+    uint32_t* a = (uint32_t*)w;
+    uint32_t* sc = a + n * 8;
+    hipLaunchKernelGGL((k_kate_pre<P>), grid, block, 0, ctx->stream, d_c, n, d_xinv, a);
+    BZH_HIP_TRY(ctx, hipMemcpyAsync(sc, a, n * 32, hipMemcpyDeviceToDevice, ctx->stream));
+    rc = prefix_scan_t<P, AddOp<P>>(ctx, sc, n, 1);
+    if (rc) return rc;
+    hipLaunchKernelGGL((k_kate_post<P>), grid, block, 0, ctx->stream, sc, a, n, d_x, d_q);
+    BZH_HIP_TRY(ctx, hipGetLastError());
+    return BZH_OK;
+}
+int poly_kate_division(bzh_ctx* ctx, int field, const uint32_t* d_c, size_t n, const uint32_t* d_x, const uint32_t* d_xinv,
+                       int x_is_zero, uint32_t* d_q) {
+#define CALL(PP) kate_t<PP>(ctx, d_c, n, d_x, d_xinv, x_is_zero, d_q)
     BZH_FIELD_SWITCH(field, CALL)
 #undef CALL
 }

@@ -159,6 +159,16 @@ int bzh_inner_product(bzh_ctx* ctx, int field, const uint64_t* a, const uint64_t
 int bzh_fold(bzh_ctx* ctx, int field, const uint64_t* in, size_t half, size_t batch, const uint64_t* u, size_t nu, int form,
              int mem, uint64_t* out);
 int bzh_vec_mul(bzh_ctx* ctx, int field, uint64_t* a, const uint64_t* b, size_t count, int form, int mem);
+/* arithmetic::kate_division (multiopen): out (n-1 coefficients) = quotient of the n-coefficient p(X) by (X - x);
+ * the remainder p(x) is dropped.  x: 4 limbs in `form` (host). */
+int bzh_kate_division(bzh_ctx* ctx, int field, const uint64_t* coeffs, size_t n, const uint64_t* x, int form, int mem,
+                      uint64_t* out);
+/* lookup::prover::permute_expression_pair (host: one sort per lookup argument): over the first usable_rows rows,
+ * out_input = the input column sorted by canonical value; out_table holds the input value wherever a new run of
+ * equal inputs starts and the table's unused values elsewhere (ascending, filled from the last repeated row
+ * backwards, as upstream).  BZH_E_RANGE if an input value is missing from the table. */
+int bzh_permute_expression_pair(int field, const uint64_t* input, const uint64_t* table, size_t usable_rows, int form,
+                                uint64_t* out_input, uint64_t* out_table);
 
 /* ---- Fiat-Shamir transcript (host; halo2_proofs transcript::{Blake2bWrite, Challenge255}) --
  * What every create_proof caller builds first (benches/shot.rs:66-67, src/circuits/board.rs:911-912:

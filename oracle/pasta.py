@@ -650,3 +650,34 @@ def ipa_verify(curve: "Curve", g, w, u, commitment, x3: int, v: int, proof: byte
         b0 = b0 * (1 + uj * pow(x3, 1 << (k - 1 - j), p)) % p
     rhs = curve.add(curve.mul(c, g0), curve.add(curve.mul(c * b0 % p * z % p, u), curve.mul(f, w)))
     return acc == rhs
+
+
+def permute_expression_pair(input_vals, table_vals, usable_rows: int, field: FieldSpec):
+    """lookup::prover::permute_expression_pair (halo2_proofs 0.2.0, UPSTREAM/unvendored), on the first
+    `usable_rows` rows (blinding rows are appended by the caller):
+      A' = input sorted ascending (by canonical value);
+      S'[i] = A'[i] wherever A'[i] starts a new run (i == 0 or A'[i] != A'[i-1]); the table values not
+      consumed that way are taken in ascending order (BTreeMap iteration) and written to the repeated rows
+      from the LAST repeated row backwards (`repeated_input_rows.pop()`).
+    Raises if some input value is missing from the table (Error::ConstraintSystemFailure upstream)."""
+    a = sorted(input_vals[:usable_rows])
+    leftover = {}
+    for t in table_vals[:usable_rows]:
+        leftover[t] = leftover.get(t, 0) + 1
+    s = [None] * usable_rows
+    repeated = []
+    for i, v in enumerate(a):
+        if i == 0 or v != a[i - 1]:
+            if leftover.get(v, 0) == 0:
+                raise ValueError("lookup input not in table")
+            s[i] = v
+            leftover[v] -= 1
+        else:
+            repeated.append(i)
+    rest = []
+    for t in sorted(leftover):
+        rest += [t] * leftover[t]
+    assert len(rest) == len(repeated)
+    for t in rest:
+        s[repeated.pop()] = t
+    return a, s

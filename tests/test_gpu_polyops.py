@@ -100,3 +100,13 @@ def test_montgomery_form_roundtrip(gpu_ctx):
     vm = C.ints_to_array([x * F.R % F.p for x in v])
     got = C.array_to_ints(gpu_ctx.batch_invert(0, vm, form=bzh2.FORM_MONTGOMERY))
     assert got == [F.inv(x) * F.R % F.p for x in v]
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 257, 2048, 5000, 16384])
+def test_kate_division(gpu_ctx, n):
+    F = O.FP
+    rng = random.Random(500 + n)
+    c = rand_ints(rng, n, F.p)
+    for x in (rng.randrange(F.p), 0, 1):
+        got = C.array_to_ints(gpu_ctx.kate_division(0, C.ints_to_array(c), x))
+        assert got == O.kate_division(c, x, F), (n, x)
