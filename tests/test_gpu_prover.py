@@ -1,0 +1,62 @@
+"""Row a1: the GPU create_proof driver (bzh2/prover.py) against the big-int oracle prover
+(oracle/halo2_oracle.py): SAME proof bytes under a shared RNG byte stream, and the oracle verifier
+accepts them (and rejects a wrong instance).  Call sites of the reference: create_proof
+benches/shot.rs:68, src/circuits/board.rs:913-920; verify_proof benches/board.rs:80-86."""
+import random
+
+import pytest
+
+import halo2_oracle as H
+import pasta as O
+import sample_circuit as S
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("k,with_lookup,degree", [(4, False, None), (5, True, None), (5, True, 6), (6, True, 9)])
+def test_create_proof_bytes_match_oracle(gpu_ctx, oracle_c, k, with_lookup, degree):
+    import bzh2
+    from bzh2 import prover as P
+    cv, F = O.VESTA, O.FP
+    cs, fixed, copies, adv, inst = S.build(k=k, seed=10 + k, with_lookup=with_lookup, degree=degree)
+    rng = random.Random(1000 + k)
+    g = [cv.random_point(rng) for _ in range(cs.n)]
+    w, u = cv.random_point(rng), cv.random_point(rng)
+    ndraws = 4000 + 3 * cs.n
+    rbytes = bytes(rng.getrandbits(8) for _ in range(64 * ndraws))
+    rs = [O.from_u512(rbytes[64 * i:64 * (i + 1)], F) for i in range(ndraws)]
+    # oracle
+    keys = H.Keys(cs, H.Domain(cs, F), cv, g, w, u, fixed, copies)
+    want = H.create_proof(keys, adv, inst, rs, O.Blake2bTranscript(F))
+    assert H.verify_proof(keys, inst, want, O.Blake2bTranscript(F))
+    # GPU driver
+    circ = P.Circuit(cs.k, cs.num_advice, cs.num_fixed, cs.num_instance, cs.gates, cs.perm_columns, cs.lookups, fixed, copies,
+                     degree=degree)
+    assert (circ.degree, circ.blinding_factors, circ.extended_k) == (cs.degree, cs.blinding_factors, cs.extended_k)
+    pk = P.ProvingKey(gpu_ctx, circ, bzh2.CURVE_VESTA, g, w, u)
+    t = bzh2.Transcript(bzh2.FIELD_FP)
+    got = P.create_proof(pk, adv, inst, rbytes, t)
+    assert got == want
+    assert not H.verify_proof(keys, [[inst[0][0] + 1]], got, O.Blake2bTranscript(F))
+
+
+def test_unsatisfied_witness_yields_a_rejected_proof(gpu_ctx, oracle_c):
+    """create_proof does not check satisfiability (neither does upstream: benches/shot.rs proves an
+    unsatisfiable witness); the proof it emits for a broken witness must not verify."""
+    import bzh2
+    from bzh2 import prover as P
+    cv, F = O.VESTA, O.FP
+    cs, fixed, copies, adv, inst = S.build(k=5, seed=3, with_lookup=False)
+    adv[2][0] = (adv[2][0] + 1) % F.p                   # break the running-sum gate
+    rng = random.Random(5)
+    g = [cv.random_point(rng) for _ in range(cs.n)]
+    w, u = cv.random_point(rng), cv.random_point(rng)
+    circ = P.Circuit(cs.k, cs.num_advice, cs.num_fixed, cs.num_instance, cs.gates, cs.perm_columns, cs.lookups, fixed, copies)
+    pk = P.ProvingKey(gpu_ctx, circ, bzh2.CURVE_VESTA, g, w, u)
+    rbytes = bytes(rng.getrandbits(8) for _ in range(64 * 3000))
+    try:
+        proof = P.create_proof(pk, adv, inst, rbytes, bzh2.Transcript(bzh2.FIELD_FP))
+    except ValueError:
+        return                                           # surplus quotient coefficients exposed it already
+    keys = H.Keys(cs, H.Domain(cs, F), cv, g, w, u, fixed, copies)
+    assert not H.verify_proof(keys, inst, proof, O.Blake2bTranscript(F))
