@@ -413,6 +413,19 @@ int bzh_ntt(bzh_ctx* ctx, int field, uint64_t* data, unsigned log_n, size_t batc
     int rc = BZH_OK;                                                                            \
     (void)rc
 
+int bzh_field_convert(bzh_ctx* ctx, int field, uint64_t* data, size_t count, int to_montgomery, int mem) {
+    const int form = BZH_FORM_MONTGOMERY;
+    BZH_POLY_PROLOGUE(!data && count);
+    if (!count) return BZH_OK;
+    if (mem == BZH_MEM_DEVICE) return field_convert(ctx, field, (uint32_t*)data, count, to_montgomery ? 1 : 0);
+    Stager s{ctx, field, BZH_FORM_MONTGOMERY};
+    uint32_t* d;
+    if ((rc = s.begin(count * 32))) return rc;
+    if ((rc = s.in(data, count, &d))) return rc;
+    if ((rc = field_convert(ctx, field, d, count, to_montgomery ? 1 : 0))) return rc;
+    return s.out(data, d, count);
+}
+
 int bzh_batch_invert(bzh_ctx* ctx, int field, uint64_t* data, size_t count, int form, int mem) {
     BZH_POLY_PROLOGUE(!data && count);
     if (!count) return BZH_OK;

@@ -150,6 +150,8 @@ int bzh_ntt(bzh_ctx* ctx, int field, uint64_t* data, unsigned log_n, size_t batc
  * bzh_fold             IPA round fold: out[b][i] = in[b][i] + u_b * in[b][half + i], i < half; nu = 1 or batch
  * bzh_vec_mul          a[i] <- a[i] * b[i]
  */
+/* canonical <-> Montgomery (x * 2^256 mod p) in place; device-resident pipelines keep Montgomery form throughout */
+int bzh_field_convert(bzh_ctx* ctx, int field, uint64_t* data, size_t count, int to_montgomery, int mem);
 int bzh_batch_invert(bzh_ctx* ctx, int field, uint64_t* data, size_t count, int form, int mem);
 int bzh_prefix_product(bzh_ctx* ctx, int field, uint64_t* data, size_t n, size_t batch, int form, int mem);
 int bzh_eval_polynomial(bzh_ctx* ctx, int field, const uint64_t* coeffs, size_t n, size_t batch, const uint64_t* xs, size_t nx,

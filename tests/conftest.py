@@ -25,6 +25,14 @@ def oracle_c():
 def gpu_ctx():
     """One bzh2 context on cuda:0 for the whole GPU session; fails loudly if the
     HIP library is missing or no device is visible (no CPU fallback exists)."""
+    # torch bundles its own HIP runtime: it must initialise before libbzh2.so's (the system one) does,
+    # otherwise torch later reports "No HIP GPUs are available" in the same process
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.zeros(1, device="cuda")
+    except ImportError:
+        pass
     import bzh2
     bzh2.load()
     if bzh2.device_count() < 1:

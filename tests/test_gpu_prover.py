@@ -60,3 +60,37 @@ def test_unsatisfied_witness_yields_a_rejected_proof(gpu_ctx, oracle_c):
         return                                           # surplus quotient coefficients exposed it already
     keys = H.Keys(cs, H.Domain(cs, F), cv, g, w, u, fixed, copies)
     assert not H.verify_proof(keys, inst, proof, O.Blake2bTranscript(F))
+
+
+@pytest.fixture(scope="module")
+def stream_ctx(gpu_ctx):
+    """A bzh2 context on torch's current stream (device-resident pipeline: torch owns the allocations)."""
+    import torch
+    import bzh2
+    ctx = bzh2.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    yield ctx
+    torch.cuda.synchronize()
+    ctx.close()
+
+
+@pytest.mark.parametrize("k,with_lookup,degree", [(4, False, None), (5, True, None), (6, True, 9)])
+def test_device_resident_prover_bytes_match_oracle(stream_ctx, oracle_c, k, with_lookup, degree):
+    import torch
+    import bzh2
+    from bzh2 import prover as P, prover_dev as D
+    cv, F = O.VESTA, O.FP
+    cs, fixed, copies, adv, inst = S.build(k=k, seed=20 + k, with_lookup=with_lookup, degree=degree)
+    rng = random.Random(2000 + k)
+    g = [cv.random_point(rng) for _ in range(cs.n)]
+    w, u = cv.random_point(rng), cv.random_point(rng)
+    ndraws = 4000 + 3 * cs.n
+    rbytes = bytes(rng.getrandbits(8) for _ in range(64 * ndraws))
+    rs = [O.from_u512(rbytes[64 * i:64 * (i + 1)], F) for i in range(ndraws)]
+    keys = H.Keys(cs, H.Domain(cs, F), cv, g, w, u, fixed, copies)
+    want = H.create_proof(keys, adv, inst, rs, O.Blake2bTranscript(F))
+    circ = P.Circuit(cs.k, cs.num_advice, cs.num_fixed, cs.num_instance, cs.gates, cs.perm_columns, cs.lookups, fixed, copies,
+                     degree=degree)
+    pk = D.DeviceProvingKey(stream_ctx, circ, bzh2.CURVE_VESTA, g, w, u, torch.device("cuda", 0))
+    got = D.create_proof(pk, adv, inst, rbytes, bzh2.Transcript(bzh2.FIELD_FP))
+    assert got == want
+    assert H.verify_proof(keys, inst, got, O.Blake2bTranscript(F))
