@@ -283,7 +283,7 @@ def _bind_poly(L):
     L.bzh_vec_mul.argtypes = [vp, ctypes.c_int, vp, vp, ctypes.c_size_t, ctypes.c_int, ctypes.c_int]
 
 
-EXPORTS += ["bzh_field_convert", "bzh_batch_invert", "bzh_prefix_product", "bzh_eval_polynomial", "bzh_inner_product", "bzh_fold", "bzh_vec_mul"]
+EXPORTS += ["bzh_field_convert", "bzh_random_field", "bzh_batch_invert", "bzh_prefix_product", "bzh_eval_polynomial", "bzh_inner_product", "bzh_fold", "bzh_vec_mul"]
 TIMER_NAMES[5] = "poly"
 
 

@@ -52,6 +52,14 @@ class DeviceOps:
         b = t.contiguous().cpu().numpy().tobytes()
         return [int.from_bytes(b[i:i + 32], "little") * self.Rinv % self.p for i in range(0, len(b), 32)]
 
+    def random_field(self, raw: bytes, count: int) -> torch.Tensor:
+        """`count` Field::random draws (64 RNG bytes each) reduced on the device -> Montgomery tensor (count, 4)."""
+        out = self.zeros(count)
+        self.L.bzh_random_field.argtypes = [_VP, ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, _VP]
+        self._chk(self.L.bzh_random_field(self.ctx.handle, self.field, raw, count, FORM_MONTGOMERY, MEM_DEVICE, _VP(out.data_ptr())),
+                  "bzh_random_field")
+        return out
+
     def zeros(self, *shape) -> torch.Tensor:
         return torch.zeros((*shape, 4), dtype=torch.int64, device=self.dev)
 

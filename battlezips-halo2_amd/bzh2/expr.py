@@ -95,19 +95,27 @@ class Program:
         return arr
 
 
-def _depth(e: Expr) -> int:
-    """Sethi-Ullman number: slots needed to evaluate e when leaves are free operands."""
+def _depth(e: Expr, memo: dict) -> int:
+    """Sethi-Ullman number: slots needed to evaluate e when leaves are free operands (memoised by node identity:
+    the quotient's Horner chain is hundreds of nodes deep)."""
+    k = id(e)
+    if k in memo:
+        return memo[k]
     if isinstance(e, (Constant, Query)):
-        return 0
-    if isinstance(e, (Negated, Scaled)):
-        return max(1, _depth(e.a))
-    da, db = _depth(e.a), _depth(e.b)
-    return max(da, db) if da != db else da + 1
+        d = 0
+    elif isinstance(e, (Negated, Scaled)):
+        d = max(1, _depth(e.a, memo))
+    else:
+        da, db = _depth(e.a, memo), _depth(e.b, memo)
+        d = max(da, db) if da != db else da + 1
+    memo[k] = d
+    return d
 
 
 def compile_expression(e: Expr, modulus: int) -> Program:
     prog = Program()
     free = list(range(MAX_SLOTS - 1, -1, -1))
+    memo: dict = {}
 
     def alloc():
         if not free:
@@ -140,15 +148,13 @@ def compile_expression(e: Expr, modulus: int) -> Program:
             prog.ops.append((MUL, d, a, (CONST, prog.const(x.k % modulus), 0)))
             return d
         # evaluate the deeper child first so the shallower one never needs more slots than are left
-        first_b = _depth(x.b) > _depth(x.a)
+        first_b = _depth(x.b, memo) > _depth(x.a, memo)
         if first_b:
             b, rb = operand(x.b)
             a, ra = operand(x.a)
         else:
             a, ra = operand(x.a)
             b, rb = operand(x.b)
-        if isinstance(x, Sum) and isinstance(x.b, Negated) and False:
-            pass
         d = ra if ra is not None else (rb if rb is not None else alloc())
         prog.ops.append((ADD if isinstance(x, Sum) else MUL, d, a, b))
         for r in (ra, rb):

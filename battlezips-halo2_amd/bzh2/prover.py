@@ -260,6 +260,12 @@ class _Rng:
         self.o += 64
         return v
 
+    def take(self, count: int) -> bytes:
+        """raw bytes of the next `count` draws (reduced on the device by bzh_random_field)"""
+        b = self.data[self.o:self.o + 64 * count]
+        self.o += 64 * count
+        return b
+
     def rest(self) -> bytes:
         return self.data[self.o:]
 

@@ -129,17 +129,27 @@ def create_proof(pk: DeviceProvingKey, advice, instance, rng_bytes: bytes, trans
     T = transcript
     up = ops.upload
     T.common_scalar(pk.vk_repr)
-    inst = [up(list(col) + [0] * (n - len(col))) for col in instance]
+    inst = []
+    for col in instance:                                # instance columns hold a handful of public inputs
+        t_ = ops.zeros(n)
+        if len(col):
+            t_[:len(col)] = up(col)
+        inst.append(t_)
     inst_polys = pk.to_coeff(inst)
     for pt in pk.commit(inst_polys, [1] * len(inst_polys)):
         T.common_point(pt)
     inst_cosets = pk.to_extended(inst_polys)
-    adv_i = [list(col) + [0] * (n - len(col)) for col in advice]
-    for col in adv_i:
-        for r in range(usable, n):
-            col[r] = rng.scalar()
-    adv_blinds = [rng.scalar() for _ in adv_i]
-    adv = [up(col) for col in adv_i]
+    # advice columns: int lists, or tensors already resident in HBM (Montgomery form, n rows); the
+    # blinding rows are drawn column by column, then one blind per column (upstream's draw order)
+    adv = []
+    for col in advice:
+        if isinstance(col, torch.Tensor):
+            a = col.clone()
+        else:
+            a = up(list(col) + [0] * (n - len(col)))
+        a[usable:] = up([rng.scalar() for _ in range(usable, n)])
+        adv.append(a)
+    adv_blinds = [rng.scalar() for _ in adv]
     adv_polys = pk.to_coeff(adv)
     for pt in pk.commit(adv_polys, adv_blinds):
         T.write_point(cv, pt)
@@ -221,7 +231,7 @@ def create_proof(pk: DeviceProvingKey, advice, instance, rng_bytes: bytes, trans
         d['z_poly'] = pk.to_coeff([z])[0]
         T.write_point(cv, pk.commit([d['z_poly']], [d['z_blind']])[0])
         d['a_coset'], d['s_coset'], d['z_coset'] = pk.to_extended([d['a_poly'], d['s_poly'], d['z_poly']])
-    random_poly = up([rng.scalar() for _ in range(n)])
+    random_poly = ops.random_field(rng.take(n), n)      # n Field::random draws, reduced on the device
     random_blind = rng.scalar()
     T.write_point(cv, pk.commit([random_poly], [random_blind])[0])
     y = T.squeeze_challenge()

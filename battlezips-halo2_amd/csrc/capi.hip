@@ -426,6 +426,24 @@ int bzh_field_convert(bzh_ctx* ctx, int field, uint64_t* data, size_t count, int
     return s.out(data, d, count);
 }
 
+int bzh_random_field(bzh_ctx* ctx, int field, const uint8_t* rng_bytes, size_t count, int form, int mem, uint64_t* out) {
+    BZH_POLY_PROLOGUE((!rng_bytes || !out) && count);
+    if (!count) return BZH_OK;
+    Stager s{ctx, field, BZH_FORM_MONTGOMERY};
+    if ((rc = s.begin(count * 64 + (mem == BZH_MEM_HOST ? count * 32 : 0) + 256))) return rc;
+    uint32_t* d_raw = s.carve(count * 64);
+    BZH_HIP_TRY(ctx, hipMemcpyAsync(d_raw, rng_bytes, count * 64, hipMemcpyHostToDevice, ctx->stream));
+    uint32_t* d_out = mem == BZH_MEM_HOST ? s.carve(count * 32) : (uint32_t*)out;
+    if ((rc = random_field(ctx, field, d_raw, count, d_out))) return rc;
+    if (form == BZH_FORM_CANONICAL && (rc = field_convert(ctx, field, d_out, count, 0))) return rc;
+    if (mem == BZH_MEM_HOST) {
+        Stager so{ctx, field, BZH_FORM_MONTGOMERY};  // already in the requested form: plain copy out
+        return so.out(out, d_out, count);
+    }
+    BZH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // the raw-byte staging is reused by the next call
+    return BZH_OK;
+}
+
 int bzh_batch_invert(bzh_ctx* ctx, int field, uint64_t* data, size_t count, int form, int mem) {
     BZH_POLY_PROLOGUE(!data && count);
     if (!count) return BZH_OK;

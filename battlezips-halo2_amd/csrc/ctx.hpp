@@ -117,6 +117,7 @@ int poly_kate_division(bzh_ctx* ctx, int field, const uint32_t* d_c, size_t n, c
 int expr_eval(bzh_ctx* ctx, int field, const void* d_prog, int nops, const uint32_t* const* d_cols, const uint32_t* d_consts,
               size_t size, int result_slot, uint32_t* d_out);
 // ipa.hip
+int random_field(bzh_ctx* ctx, int field, const uint32_t* d_raw, size_t count, uint32_t* d_out);
 int ipa_open(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_poly, const uint64_t* blind, const uint64_t* x3,
              const uint8_t* rng_bytes, bzh_transcript* tr, uint64_t* out_v);
 int ipa_verify(bzh_ctx* ctx, const bzh_bases* bases, const uint64_t* commitment_xy, const uint64_t* x3, const uint64_t* v,

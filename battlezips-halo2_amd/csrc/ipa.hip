@@ -523,6 +523,20 @@ static int ipa_verify_t(bzh_ctx* ctx, const bzh_bases* bases, const uint64_t* co
     return memcmp(lhs, rhs, 64) == 0 ? BZH_OK : BZH_E_VERIFY;
 }
 
+int random_field(bzh_ctx* ctx, int field, const uint32_t* d_raw, size_t count, uint32_t* d_out) {
+    if (!count) return BZH_OK;
+    const dim3 grid((unsigned)((count + 255) / 256)), block(256);
+    switch (field) {
+        case BZH_FIELD_FP: hipLaunchKernelGGL((k_reduce_wide<FpParams>), grid, block, 0, ctx->stream, d_raw, count, d_out); break;
+        case BZH_FIELD_FQ: hipLaunchKernelGGL((k_reduce_wide<FqParams>), grid, block, 0, ctx->stream, d_raw, count, d_out); break;
+        case BZH_FIELD_BN254_FR: hipLaunchKernelGGL((k_reduce_wide<BnFrParams>), grid, block, 0, ctx->stream, d_raw, count, d_out); break;
+        case BZH_FIELD_BN254_FQ: hipLaunchKernelGGL((k_reduce_wide<BnFqParams>), grid, block, 0, ctx->stream, d_raw, count, d_out); break;
+        default: return BZH_E_ARG;
+    }
+    BZH_HIP_TRY(ctx, hipGetLastError());
+    return BZH_OK;
+}
+
 int ipa_open(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_poly, const uint64_t* blind, const uint64_t* x3,
              const uint8_t* rng_bytes, bzh_transcript* tr, uint64_t* out_v) {
     switch (bases->curve) {

@@ -443,14 +443,13 @@ __global__ void __launch_bounds__(256) k_msm_reduce(const uint4* __restrict__ bu
         cur = nxt;
         nxt = tmp;
     }
-    if (tid == 0) suf = xyzz_identity<P>();  // only t >= 1 contribute t * S_t
-    Xyzz<P> hi = block_tree_sum(suf, bufA, T);
-    Xyzz<P> lo = block_tree_sum(W, bufA, T);
-    if (tid == 0) {
-        for (int k = L; k > 1; k >>= 1) hi = xyzz_dbl(hi);
-        xyzz_add(lo, hi);
-        planes_put(winsums, (size_t)gridDim.x, segi, lo);
+    // V_t = W_t + L * Suf_t for t >= 1 (log2 L doublings per thread), then ONE tree sum
+    if (tid >= 1) {
+        for (int k = L; k > 1; k >>= 1) suf = xyzz_dbl(suf);
+        xyzz_add(W, suf);
     }
+    Xyzz<P> lo = block_tree_sum(W, bufA, T);
+    if (tid == 0) planes_put(winsums, (size_t)gridDim.x, segi, lo);
 }
 
 // ---------------------------------------------------------------------------

@@ -45,9 +45,12 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="board_k14",
-                    choices=["board_k14", "board_k12", "shot_k11", "board_k17", "shot_k11_batch", "msm24", "msm20", "ntt22"])
+                    choices=["board_k14", "board_k12", "shot_k11", "board_k17", "shot_k11_batch", "msm24", "msm20", "ntt22",
+                             "proof_k11", "proof_k12", "proof_k14", "proof_k8"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-precompute", action="store_true", help="plain bases: no fixed-base window table for the SRS")
+    ap.add_argument("--concurrency", type=int, default=1,
+                    help="proof_k* workloads: independent proofs in flight per GPU (host threads, one ctx + stream each)")
     return ap.parse_args()
 
 
@@ -82,7 +85,7 @@ def make_bases(ctx, curve, n, seed):
 class Workload:
     """Device-resident inputs + the list of library calls that make one step."""
 
-    def __init__(self, name, ctx, device, seed, precompute=True):
+    def __init__(self, name, ctx, device, seed, precompute=True, concurrency=1):
         self.name, self.ctx = name, ctx
         gen = torch.Generator(device=device)
         gen.manual_seed(seed)
@@ -123,6 +126,72 @@ class Workload:
             self.desc = {"k": k, "proofs_per_step": proofs, "msm": "%dx2^%d vesta" % (28 * proofs, k),
                          "ntt": "%dx iNTT 2^%d + %dx coset NTT 2^%d + %dx coset iNTT 2^%d (Fp)" % (17 * proofs, k, 18 * proofs, k + 3, proofs, k + 3)}
             self.result = self.msm_out
+        elif name.startswith("proof_k"):
+            # a COMPLETE proof per step: bzh2/prover_dev.create_proof on a circuit with the shape of the reference's
+            # Shot / Board circuits (bzh2/synth.py); witness columns are resident in HBM before the timed region
+            from bzh2 import prover_dev as D, synth
+            k = int(name[len("proof_k"):])
+            n = 1 << k
+            self.k = k
+            circ, adv, inst = synth.battlezips_shaped(k, seed)
+            pts = make_bases(ctx, self.curve, n + 2, seed + 1)
+            as_pt = lambda a: (bzh2.limbs_to_int(a[:4]), bzh2.limbs_to_int(a[4:]))
+            g = [as_pt(a) for a in pts]
+            self.pk = D.DeviceProvingKey(ctx, circ, self.curve, g[:n], g[n + 1], g[n], device)
+            self.adv_dev = [self.pk.ops.upload(col) for col in adv]
+            self.inst = inst
+            self.circ = circ
+            ndraws = 3 * n + 2048
+            self.rng_pool = [np.random.default_rng(seed + 100 + i).bytes(64 * ndraws) for i in range(4)]
+            self.step_no = 0
+            self.last_proof = b""
+
+            # `concurrency` independent proofs per step, one host thread each with its own ctx + HIP stream;
+            # the proving key (SRS window table, fixed / permutation polynomials) is shared read-only
+            import copy
+            import threading
+            self.units_per_step = concurrency
+            self.workers = []
+            for wi in range(concurrency):
+                if wi == 0:
+                    self.workers.append((None, self.pk))
+                    continue
+                st = torch.cuda.Stream(device=device)
+                wctx = bzh2.Context(device.index or 0, stream=st.cuda_stream)
+                wpk = copy.copy(self.pk)
+                wpk.ctx = wctx
+                wpk.ops = type(self.pk.ops)(wctx, self.pk.field, self.pk.curve, self.pk.p, device)
+                self.workers.append((st, wpk))
+
+            def prove_one(wi, rb):
+                st, wpk = self.workers[wi]
+                if st is None:
+                    self.last_proof = D.create_proof(wpk, self.adv_dev, self.inst, rb, bzh2.Transcript(bzh2.FIELD_FP))
+                else:
+                    with torch.cuda.stream(st):
+                        D.create_proof(wpk, self.adv_dev, self.inst, rb, bzh2.Transcript(bzh2.FIELD_FP))
+                    st.synchronize()
+
+            def prove():
+                rbs = [self.rng_pool[(self.step_no + wi) % len(self.rng_pool)] for wi in range(concurrency)]
+                self.step_no += 1
+                if concurrency == 1:
+                    prove_one(0, rbs[0])
+                    return
+                ths = [threading.Thread(target=prove_one, args=(wi, rbs[wi])) for wi in range(1, concurrency)]
+                for t in ths:
+                    t.start()
+                prove_one(0, rbs[0])
+                for t in ths:
+                    t.join()
+            self.calls = [("create_proof", prove)]
+            self.alg_bytes_msm_launch = 0
+            nm = 11 + 2 + 2 + 1 + 1 + 8 + 1
+            self.alg_bytes_step = nm * n * 32 + n * 64 + 64 * (17 * n + 19 * (n << 3))
+            self.desc = {"k": k, "circuit": "synthetic, BattleZips-shaped: 11 advice / 8 fixed / 1 instance, 24 gates, degree 9, "
+                                            "13 permutation columns, one 10-bit lookup (bzh2/synth.py)",
+                         "proof_bytes": None}
+            self.result = torch.zeros((1, 12), dtype=torch.int64, device=device)
         elif name in ("msm24", "msm20"):
             k = 24 if name == "msm24" else 20
             n = 1 << k
@@ -215,7 +284,7 @@ def main():
 
     stream = torch.cuda.current_stream(device)
     ctx = bzh2.Context(local_rank, stream=stream.cuda_stream)
-    wl = Workload(args.workload, ctx, device, seed=1234 + rank, precompute=not args.no_precompute)
+    wl = Workload(args.workload, ctx, device, seed=1234 + rank, precompute=not args.no_precompute, concurrency=args.concurrency)
 
     def barrier():
         torch.cuda.synchronize(device)
@@ -245,6 +314,7 @@ def main():
     if rank == 0:
         units = wl.units_per_step * args.steps * world
         is_proof = args.workload.startswith(("board", "shot"))
+        is_full = args.workload.startswith("proof_k")
         acc = timings["msm_accumulate"]
         nt = timings["ntt"]
         if args.workload == "ntt22":
@@ -269,9 +339,11 @@ def main():
             except Exception:
                 traffic = None
         line = {
-            "metric": ("%s proof MSM+NTT workloads per second" % args.workload) if is_proof else ("%s runs per second" % args.workload),
+            "metric": ("%s proof MSM+NTT workloads per second" % args.workload) if is_proof else
+                      (("complete proofs per second, BattleZips-shaped circuit, k=%d, IPA/Pasta" % wl.k) if is_full
+                       else ("%s runs per second" % args.workload)),
             "value": units / elapsed,
-            "unit": "proof-workloads/s" if is_proof else "runs/s",
+            "unit": "proof-workloads/s" if is_proof else ("proofs/s" if is_full else "runs/s"),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -287,6 +359,11 @@ def main():
                          "algorithmic_bytes_per_launch": alg, "avg_launch_ms": dom_ms},
             "kernel_ms": {kname: v for kname, v in timings.items() if v["launches"]},
         }
+        if is_full:
+            line["config"]["stages"] = ("complete create_proof: commitments, lookup, permutation, vanishing, quotient, evaluations, "
+                                        "multiopen, IPA, transcript; witness synthesis excluded (columns resident in HBM)")
+            line["config"]["proof_bytes"] = len(wl.last_proof)
+            line["config"]["proofs_in_flight_per_gpu"] = args.concurrency
         if world == 1 and is_proof and not args.no_cpu_baseline and args.workload != "shot_k11_batch":
             line["cpu_baseline"] = cpu_baseline(args.workload, wl.k)
         print(json.dumps(line))

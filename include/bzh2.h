@@ -152,6 +152,10 @@ int bzh_ntt(bzh_ctx* ctx, int field, uint64_t* data, unsigned log_n, size_t batc
  */
 /* canonical <-> Montgomery (x * 2^256 mod p) in place; device-resident pipelines keep Montgomery form throughout */
 int bzh_field_convert(bzh_ctx* ctx, int field, uint64_t* data, size_t count, int to_montgomery, int mem);
+/* ff::Field::random for `count` draws from a caller-supplied RNG byte stream (host pointer, 64 bytes per draw, the
+ * 8 x next_u64 of pasta_curves): out[i] = bytes[64i .. 64i+64) as a 512-bit little-endian integer mod p.
+ * The prover's random polynomials (vanishing argument, IPA s(X)) are n draws each; `mem` applies to out. */
+int bzh_random_field(bzh_ctx* ctx, int field, const uint8_t* rng_bytes, size_t count, int form, int mem, uint64_t* out);
 int bzh_batch_invert(bzh_ctx* ctx, int field, uint64_t* data, size_t count, int form, int mem);
 int bzh_prefix_product(bzh_ctx* ctx, int field, uint64_t* data, size_t n, size_t batch, int form, int mem);
 int bzh_eval_polynomial(bzh_ctx* ctx, int field, const uint64_t* coeffs, size_t n, size_t batch, const uint64_t* xs, size_t nx,

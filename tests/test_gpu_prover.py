@@ -94,3 +94,27 @@ def test_device_resident_prover_bytes_match_oracle(stream_ctx, oracle_c, k, with
     got = D.create_proof(pk, adv, inst, rbytes, bzh2.Transcript(bzh2.FIELD_FP))
     assert got == want
     assert H.verify_proof(keys, inst, got, O.Blake2bTranscript(F))
+
+
+def test_battlezips_shaped_circuit_proof_matches_oracle(stream_ctx, oracle_c):
+    """The benchmark circuit (bzh2/synth.py: 11 advice / 8 fixed / 13 permutation columns / degree 9 / one lookup /
+    24 gates) at k = 7: device-resident proof == oracle proof, and the oracle verifier accepts it."""
+    import torch
+    import bzh2
+    from bzh2 import prover_dev as D, synth
+    cv, F = O.VESTA, O.FP
+    circ, adv, inst = synth.battlezips_shaped(7, seed=5)
+    cs = H.ConstraintSystem(circ.k, 11, 8, 1, circ.gates, circ.perm_columns, circ.lookups, degree=9)
+    rng = random.Random(77)
+    g = [cv.random_point(rng) for _ in range(cs.n)]
+    w, u = cv.random_point(rng), cv.random_point(rng)
+    ndraws = 6000
+    rbytes = bytes(rng.getrandbits(8) for _ in range(64 * ndraws))
+    rs = [O.from_u512(rbytes[64 * i:64 * (i + 1)], F) for i in range(ndraws)]
+    keys = H.Keys(cs, H.Domain(cs, F), cv, g, w, u, circ.fixed, circ.copies)
+    want = H.create_proof(keys, adv, inst, rs, O.Blake2bTranscript(F))
+    assert H.verify_proof(keys, inst, want, O.Blake2bTranscript(F))
+    pk = D.DeviceProvingKey(stream_ctx, circ, bzh2.CURVE_VESTA, g, w, u, torch.device("cuda", 0))
+    adv_dev = [pk.ops.upload(col) for col in adv]          # witness resident in HBM, as in bench.py
+    got = D.create_proof(pk, adv_dev, inst, rbytes, bzh2.Transcript(bzh2.FIELD_FP))
+    assert got == want
