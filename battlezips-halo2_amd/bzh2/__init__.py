@@ -39,7 +39,7 @@ CURVE_SCALAR_FIELD = {CURVE_VESTA: FIELD_FP, CURVE_PALLAS: FIELD_FQ, CURVE_BN254
 # every symbol include/bzh2.h declares
 EXPORTS = [
     "bzh_version", "bzh_strerror", "bzh_device_count", "bzh_ctx_create", "bzh_ctx_create_on_stream",
-    "bzh_ctx_destroy", "bzh_ctx_sync", "bzh_last_error", "bzh_ctx_profile", "bzh_ctx_timings",
+    "bzh_ctx_destroy", "bzh_ctx_sync", "bzh_last_error", "bzh_ctx_profile", "bzh_ctx_timings", "bzh_ctx_work",
     "bzh_bases_upload", "bzh_bases_precompute", "bzh_bases_free", "bzh_bases_len", "bzh_msm", "bzh_ntt",
     "bzh_jacobian_to_affine", "bzh_affine_compress", "bzh_field_omega",
 ]
@@ -179,7 +179,10 @@ class Context:
         ms = (ctypes.c_double * T_COUNT)()
         n = (ctypes.c_uint64 * T_COUNT)()
         self._check(load().bzh_ctx_timings(self.handle, ms, n), "bzh_ctx_timings")
-        return {TIMER_NAMES[i]: {"ms": ms[i], "launches": int(n[i])} for i in TIMER_NAMES}
+        wb = (ctypes.c_double * T_COUNT)()
+        load().bzh_ctx_work.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]
+        self._check(load().bzh_ctx_work(self.handle, wb), "bzh_ctx_work")
+        return {TIMER_NAMES[i]: {"ms": ms[i], "launches": int(n[i]), "algorithmic_bytes": wb[i]} for i in TIMER_NAMES}
 
     # ---- bases ----
     def upload_bases(self, curve: int, xy, n: int | None = None, form: int = FORM_CANONICAL, device_ptr: bool = False) -> Bases:

@@ -53,7 +53,7 @@ def _horner(terms, ch):
 
 
 class DeviceProvingKey:
-    def __init__(self, ctx, circuit: Circuit, curve: int, g, w, u, device: torch.device, vk_repr=0x1234):
+    def __init__(self, ctx, circuit: Circuit, curve: int, g, w, u, device: torch.device, vk_repr=0x1234, window_bits: int = 8):
         self.ctx, self.c, self.curve = ctx, circuit, curve
         self.field = CURVE_SCALAR_FIELD[curve]
         self.p = p = MODULI[self.field]
@@ -68,7 +68,10 @@ class DeviceProvingKey:
         self.delta = pow(MULT_GEN, 1 << TWO_ADICITY, p)
         self.vk_repr = vk_repr % p
         tbl = np.stack([np.concatenate([int_to_limbs(pt[0]), int_to_limbs(pt[1])]) for pt in list(g) + [u, w]])
-        self.bases = ctx.upload_bases(curve, tbl).precompute()
+        # 8-bit windows: a single proof issues its ~25 MSMs one at a time (transcript dependencies), so each one is
+        # latency-bound by the bucket reduction, which scales with the bucket count (k=11: 22.4 -> 18.0 ms per proof
+        # against the throughput-optimal 10/11-bit table)
+        self.bases = ctx.upload_bases(curve, tbl).precompute(window_bits)
         up = ops.upload
         self.fixed = [up(list(col) + [0] * (n - len(col))) for col in c.fixed]
         self.fixed_polys = self.to_coeff(self.fixed)

@@ -293,8 +293,16 @@ int bzh_ctx_profile(bzh_ctx* ctx, int enable) {
     for (int i = 0; i < BZH_T_COUNT; i++) {
         ctx->acc_ms[i] = 0;
         ctx->acc_n[i] = 0;
+        ctx->alg_bytes[i] = 0;
     }
     ctx->profiling = enable != 0;
+    return BZH_OK;
+}
+
+int bzh_ctx_work(bzh_ctx* ctx, double* algorithmic_bytes) {
+    if (!ctx || !algorithmic_bytes) return BZH_E_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    for (int i = 0; i < BZH_T_COUNT; i++) algorithmic_bytes[i] = ctx->alg_bytes[i];
     return BZH_OK;
 }
 

@@ -36,6 +36,7 @@ struct bzh_ctx {
     std::vector<hipEvent_t> event_pool;
     double acc_ms[BZH_T_COUNT] = {0};
     uint64_t acc_n[BZH_T_COUNT] = {0};
+    double alg_bytes[BZH_T_COUNT] = {0};  // algorithmic bytes of the launches timed while profiling
     int num_cu = 256;
 };
 

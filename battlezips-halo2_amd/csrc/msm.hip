@@ -676,6 +676,7 @@ static int msm_run_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_sca
         }
         {
             ScopedTimer t(ctx, BZH_T_MSM_ACCUMULATE);
+            if (ctx->profiling) ctx->alg_bytes[BZH_T_MSM_ACCUMULATE] += (double)nb * (double)n * 32.0 + (double)n * 64.0;
             const dim3 grid((unsigned)p.nchunks, (unsigned)acc_nwin, (unsigned)nb);
 #define BZH_LAUNCH_ACC(TT)                                                                                              \
     hipLaunchKernelGGL((k_msm_accumulate<C, TT>), grid, dim3(TT), acc_lds, ctx->stream, bases->d_xy,                      \

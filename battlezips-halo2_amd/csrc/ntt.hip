@@ -384,6 +384,7 @@ static int ntt_run_t(bzh_ctx* ctx, uint32_t* d_data, unsigned log_n, size_t batc
         const size_t tiles = ((size_t)1 << log_n) >> (a.r + logW);
         {
             ScopedTimer t(ctx, BZH_T_NTT);
+            if (ctx->profiling && p == 0) ctx->alg_bytes[BZH_T_NTT] += 64.0 * (double)batch * (double)((size_t)1 << log_n);
             for (size_t b0 = 0; b0 < batch; b0 += 65535) {
                 size_t nb = batch - b0 < 65535 ? batch - b0 : 65535;
                 NttPassArgs aa = a;

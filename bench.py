@@ -1,26 +1,26 @@
 #!/usr/bin/env python3
-"""bench.py -- the create_proof commit/evaluate hot path on MI355X through libbzh2.so.
+"""bench.py -- halo2 create_proof on MI355X through libbzh2.so.
 
-One "step" = the MSM + NTT schedule of ONE BoardCircuit proof at k=14 over
-IPA/Pasta (Vesta commitments, Fp polynomials), SURVEY.md section 3.1:
-    28 MSMs of n = 2^14 against one SRS table (one batched bzh_msm call)
-    17 iNTT(n)            lagrange_to_coeff of every committed column
-    18 coset NTT(8n)      coeff_to_extended
-     1 extended iNTT(8n)  extended_to_coeff of h(X)
-Inputs are synthetic (seeded random field elements in pasta_curves' Montgomery
-form; bases are random multiples of the Vesta generator produced by the HIP MSM
-itself) and are resident in HBM before the timed region starts.
+Default workload `proof_k14` (BASELINE.json configs[1]: single BoardCircuit-sized proof, k=14, IPA/Pasta):
+one "step" = ONE COMPLETE create_proof (bzh2/prover_dev.py) of a circuit with the reference's Board/Shot
+shape (bzh2/synth.py: 11 advice / 8 fixed / 1 instance columns, 24 gates, degree 9, 13 permutation columns,
+one 10-bit lookup): column commitments, lookup permute + grand product, permutation grand products, vanishing
+argument (quotient over the 8n coset), evaluations, multiopen and the IPA opening, transcript included.
+Witness columns are synthetic and resident in HBM before the timed region starts; the proof bytes come back
+to the host inside it.  `--concurrency C` keeps C independent proofs in flight per GPU (host threads, one
+ctx + HIP stream each; proofs are independent, no data is shared but the read-only proving key).
 
-What is NOT yet in the step (and so not in the number): witness synthesis, the
-quotient evaluation, permutation/lookup grand products, multiopen/IPA folding
-and the transcript -- i.e. this is the proof's MSM+NTT workload, not a complete
-proof; `config.stages` says so in the JSON line.
+`board_k14` / `board_k12` / `shot_k11` / `board_k17` / `shot_k11_batch` time only the MSM + NTT schedule of
+such a proof (28 MSMs of n, 17 iNTT(n), 18 coset NTT(8n), 1 extended iNTT(8n));
+`msm24` / `msm20` / `ntt22` are the config-5 microbenches.
 
-Other workloads (config 5 microbenches): --workload msm24 | ntt22 | shot_k11_batch.
+roofline: the dominant kernel is k_msm_accumulate; `achieved` = the library's own count of algorithmic bytes
+(32 B per scalar + 64 B per base point per launch, bzh_ctx_work) / its HIP-event time on the launch stream
+(bzh_ctx_timings), both taken live over the timed region.
 
-Multi-GPU: one process per GPU (torchrun); proofs are independent, so every rank
-runs the same per-GPU workload (weak scaling) and the only collective is one
-RCCL all_gather of the ranks' commitment outputs at the end of the timed region.
+Multi-GPU: one process per GPU (torchrun); proofs are independent, so every rank runs the same per-GPU
+workload (weak scaling) and the only collective is one RCCL all_gather of the ranks' outputs at the end of
+the timed region.
 """
 import argparse
 import json
@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="board_k14",
+    ap.add_argument("--workload", default="proof_k14",
                     choices=["board_k14", "board_k12", "shot_k11", "board_k17", "shot_k11_batch", "msm24", "msm20", "ntt22",
                              "proof_k11", "proof_k12", "proof_k14", "proof_k8"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -186,8 +186,7 @@ class Workload:
                     t.join()
             self.calls = [("create_proof", prove)]
             self.alg_bytes_msm_launch = 0
-            nm = 11 + 2 + 2 + 1 + 1 + 8 + 1
-            self.alg_bytes_step = nm * n * 32 + n * 64 + 64 * (17 * n + 19 * (n << 3))
+            self.alg_bytes_step = 0  # filled from the library's own counters (bzh_ctx_work) after the timed region
             self.desc = {"k": k, "circuit": "synthetic, BattleZips-shaped: 11 advice / 8 fixed / 1 instance, 24 gates, degree 9, "
                                             "13 permutation columns, one 10-bit lookup (bzh2/synth.py)",
                          "proof_bytes": None}
@@ -295,7 +294,9 @@ def main():
     for _ in range(args.warmup):
         wl.step()
     barrier()
-    ctx.profile(True)
+    all_ctx = [ctx] + [w[1].ctx for w in getattr(wl, "workers", []) if w[0] is not None]
+    for c in all_ctx:
+        c.profile(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         wl.step()
@@ -305,7 +306,12 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     timings = ctx.timings()
-    ctx.profile(False)
+    for c in all_ctx[1:]:  # proofs in flight on their own ctx + stream: sum their kernel classes into the report
+        for kname, v in c.timings().items():
+            for f in v:
+                timings[kname][f] += v[f]
+    for c in all_ctx:
+        c.profile(False)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -321,6 +327,13 @@ def main():
             dom_ms = nt["ms"] / max(nt["launches"], 1) * (nt["launches"] / max(args.steps, 1))  # all passes of one NTT
             alg = wl.alg_bytes_step
             dom_name = "k_ntt_pass (all passes of one 2^22 NTT)"
+        elif is_full:
+            # MSM launches of a proof differ in size (28 column commits batched by phase, then the halving IPA
+            # rounds): average the bytes the library counted per launch (bzh_ctx_work) over the same launches
+            dom_ms = acc["ms"] / max(acc["launches"], 1)
+            alg = acc["algorithmic_bytes"] / max(acc["launches"], 1)
+            dom_name = "k_msm_accumulate (mean over the %d launches of one proof)" % (acc["launches"] // max(units, 1))
+            wl.alg_bytes_step = (acc["algorithmic_bytes"] + nt["algorithmic_bytes"]) / max(args.steps, 1)
         else:
             dom_ms = acc["ms"] / max(acc["launches"], 1)
             alg = wl.alg_bytes_msm_launch
@@ -364,8 +377,12 @@ def main():
                                         "multiopen, IPA, transcript; witness synthesis excluded (columns resident in HBM)")
             line["config"]["proof_bytes"] = len(wl.last_proof)
             line["config"]["proofs_in_flight_per_gpu"] = args.concurrency
-        if world == 1 and is_proof and not args.no_cpu_baseline and args.workload != "shot_k11_batch":
+        if world == 1 and (is_proof or is_full) and not args.no_cpu_baseline and args.workload != "shot_k11_batch":
             line["cpu_baseline"] = cpu_baseline(args.workload, wl.k)
+            if is_full:
+                line["cpu_baseline"]["unit"] = "proofs/s (upper bound)"
+                line["cpu_baseline"]["sample"] += ("; only the proof's MSM+NTT schedule is timed on the CPU, so a CPU prover's "
+                                                   "complete-proof rate is below this figure")
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()

@@ -100,6 +100,9 @@ const char* bzh_last_error(const bzh_ctx* ctx);
  * since enabling.  ms / launches must each hold BZH_T_COUNT entries. */
 int bzh_ctx_profile(bzh_ctx* ctx, int enable);
 int bzh_ctx_timings(bzh_ctx* ctx, double* ms, uint64_t* launches);
+/* Algorithmic bytes (MSM 32*B*N + 64*N per launch, NTT 64*N per transform) of the launches timed since
+ * profiling was enabled, per kernel class (BZH_T_COUNT entries); divides by bzh_ctx_timings' ms for GB/s. */
+int bzh_ctx_work(bzh_ctx* ctx, double* algorithmic_bytes);
 
 /* ---- commitment bases (Params.g / Params.g_lagrange of halo2's IPA params) -
  * Replaces the `bases: &[C]` argument of best_multiexp for tables that live
