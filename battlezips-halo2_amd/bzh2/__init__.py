@@ -433,7 +433,7 @@ class Transcript:
 
 
 # ---- IPA opening --------------------------------------------------------------------------------
-EXPORTS += ["bzh_ipa_open", "bzh_ipa_verify"]
+EXPORTS += ["bzh_ipa_open", "bzh_ipa_open_batch", "bzh_ipa_verify"]
 E_VERIFY = -6
 
 
@@ -469,7 +469,29 @@ def _ctx_ipa_verify(self, bases: Bases, commitment, x3: int, v: int, proof: byte
     return True
 
 
+def _ctx_ipa_open_batch(self, bases: Bases, polys, blinds, x3s, rng_list, transcripts, form: int = FORM_CANONICAL):
+    """`len(transcripts)` openings in lockstep (bzh_ipa_open_batch); polys: (batch, n, 4) uint64; returns the v's."""
+    L = load()
+    vp = ctypes.c_void_p
+    u64p = ctypes.POINTER(ctypes.c_uint64)
+    L.bzh_ipa_open_batch.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_size_t, u64p, u64p, ctypes.c_char_p,
+                                     ctypes.c_size_t, ctypes.POINTER(vp), u64p]
+    B = len(transcripts)
+    p = np.ascontiguousarray(np.asarray(polys, dtype=np.uint64).reshape(B, -1, 4))
+    stride = len(rng_list[0])
+    assert all(len(r) == stride for r in rng_list)
+    bl = np.ascontiguousarray(np.stack([int_to_limbs(v) for v in blinds]))
+    xs = np.ascontiguousarray(np.stack([int_to_limbs(v) for v in x3s]))
+    out = np.zeros((B, 4), dtype=np.uint64)
+    trs = (vp * B)(*[t.h for t in transcripts])
+    rc = L.bzh_ipa_open_batch(self.handle, bases.handle, _vp(p), form, MEM_HOST, B, _u64(bl), _u64(xs), b"".join(rng_list), stride,
+                              trs, _u64(out))
+    self._check(rc, "bzh_ipa_open_batch")
+    return [limbs_to_int(o) for o in out]
+
+
 Context.ipa_open = _ctx_ipa_open
+Context.ipa_open_batch = _ctx_ipa_open_batch
 Context.ipa_verify = _ctx_ipa_verify
 
 

@@ -249,7 +249,7 @@ int bzh_ctx_destroy(bzh_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     ntt_cache_drop(ctx);
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < bzh_ctx::kWsSlots; i++)
         if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
     for (auto& s : ctx->spans) {
         (void)hipEventDestroy(s.a);
@@ -665,33 +665,37 @@ int bzh_expr_eval(bzh_ctx* ctx, int field, const bzh_expr_op* prog, size_t nops,
     return BZH_OK;
 }
 
-int bzh_ipa_open(bzh_ctx* ctx, const bzh_bases* bases, const uint64_t* poly, int form, int mem, const uint64_t* blind,
-                 const uint64_t* x3, const uint8_t* rng, size_t rng_len, bzh_transcript* transcript, uint64_t* out_v) {
-    if (!ctx || !bases || !poly || !blind || !x3 || !rng || !transcript || !out_v || !valid_form(form) || !valid_mem(mem))
+int bzh_ipa_open_batch(bzh_ctx* ctx, const bzh_bases* bases, const uint64_t* polys, int form, int mem, size_t batch,
+                       const uint64_t* blinds, const uint64_t* x3s, const uint8_t* rng, size_t rng_stride,
+                       bzh_transcript* const* transcripts, uint64_t* out_v) {
+    if (!ctx || !bases || !polys || !blinds || !x3s || !rng || !transcripts || !out_v || !valid_form(form) || !valid_mem(mem))
         return BZH_E_ARG;
-    if (bases->n < 3 || bases->device != ctx->device) return BZH_E_ARG;
+    if (bases->n < 3 || bases->device != ctx->device || !batch || batch > 32767) return BZH_E_ARG;
     const size_t n = bases->n - 2;
     if (n & (n - 1)) return BZH_E_ARG;
     unsigned k = 0;
     while (((size_t)1 << k) < n) k++;
-    if (rng_len < 64 * (n + 1 + 2 * (size_t)k)) return BZH_E_ARG;
+    if (rng_stride < 64 * (n + 1 + 2 * (size_t)k)) return BZH_E_ARG;
+    for (size_t b = 0; b < batch; b++)
+        if (!transcripts[b]) return BZH_E_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     BZH_HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int field = bases->curve == BZH_CURVE_VESTA ? BZH_FIELD_FP : (bases->curve == BZH_CURVE_PALLAS ? BZH_FIELD_FQ : BZH_FIELD_BN254_FR);
     if (mem == BZH_MEM_DEVICE) {
         if (form != BZH_FORM_MONTGOMERY) return BZH_E_ARG;
-        return ipa_open(ctx, bases, (const uint32_t*)poly, blind, x3, rng, transcript, out_v);
+        return ipa_open(ctx, bases, (const uint32_t*)polys, batch, blinds, x3s, rng, rng_stride, transcripts, out_v);
     }
-    // stage the polynomial in its own allocation (ipa_open uses workspace slot 3 itself)
-    uint32_t* d_poly = nullptr;
-    BZH_HIP_TRY(ctx, hipMalloc((void**)&d_poly, n * 32));
-    int rc = BZH_OK;
-    if (hipMemcpyAsync(d_poly, poly, n * 32, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = BZH_E_HIP;
-    if (!rc && form == BZH_FORM_CANONICAL) rc = field_convert(ctx, field, d_poly, n, 1);
-    if (!rc) rc = ipa_open(ctx, bases, d_poly, blind, x3, rng, transcript, out_v);
-    (void)hipStreamSynchronize(ctx->stream);
-    (void)hipFree(d_poly);
-    return rc;
+    int rc;
+    Stager s{ctx, field, form};  // workspace slot 3; the opening itself works in slots 0-2, 4 and 5
+    if ((rc = s.begin(batch * n * 32))) return rc;
+    uint32_t* d_polys;
+    if ((rc = s.in(polys, batch * n, &d_polys))) return rc;
+    return ipa_open(ctx, bases, d_polys, batch, blinds, x3s, rng, rng_stride, transcripts, out_v);
+}
+
+int bzh_ipa_open(bzh_ctx* ctx, const bzh_bases* bases, const uint64_t* poly, int form, int mem, const uint64_t* blind,
+                 const uint64_t* x3, const uint8_t* rng, size_t rng_len, bzh_transcript* transcript, uint64_t* out_v) {
+    return bzh_ipa_open_batch(ctx, bases, poly, form, mem, 1, blind, x3, rng, rng_len, &transcript, out_v);
 }
 
 int bzh_ipa_verify(bzh_ctx* ctx, const bzh_bases* bases, const uint64_t* commitment_xy, const uint64_t* x3, const uint64_t* v,

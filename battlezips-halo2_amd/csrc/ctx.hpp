@@ -24,8 +24,9 @@ struct bzh_ctx {
     std::mutex mu;
     std::string last_error;
     // grow-only device workspaces (calls on a ctx are serialised and stream-ordered)
-    void* ws[4] = {nullptr, nullptr, nullptr, nullptr};
-    size_t ws_bytes[4] = {0, 0, 0, 0};
+    static constexpr int kWsSlots = 6;  // 0-2 msm / scans, 3 host staging, 4-5 ipa
+    void* ws[kWsSlots] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t ws_bytes[kWsSlots] = {0, 0, 0, 0, 0, 0};
     // profiling
     bool profiling = false;
     struct Span {
@@ -119,8 +120,8 @@ int expr_eval(bzh_ctx* ctx, int field, const void* d_prog, int nops, const uint3
               size_t size, int result_slot, uint32_t* d_out);
 // ipa.hip
 int random_field(bzh_ctx* ctx, int field, const uint32_t* d_raw, size_t count, uint32_t* d_out);
-int ipa_open(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_poly, const uint64_t* blind, const uint64_t* x3,
-             const uint8_t* rng_bytes, bzh_transcript* tr, uint64_t* out_v);
+int ipa_open(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_polys, size_t batch, const uint64_t* blinds,
+             const uint64_t* x3s, const uint8_t* rng_bytes, size_t rng_stride, bzh_transcript* const* trs, uint64_t* out_v);
 int ipa_verify(bzh_ctx* ctx, const bzh_bases* bases, const uint64_t* commitment_xy, const uint64_t* x3, const uint64_t* v,
                const uint8_t* proof, size_t proof_len, bzh_transcript* tr, const uint64_t* g0_u_w_xy);
 

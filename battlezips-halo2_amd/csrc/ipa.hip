@@ -19,6 +19,7 @@
 #include <cstring>
 #include <vector>
 
+#include "block.cuh"
 #include "ctx.hpp"
 #include "curve.cuh"
 
@@ -36,56 +37,6 @@ __global__ void __launch_bounds__(256) k_reduce_wide(const uint32_t* __restrict_
     // value = lo + hi * 2^256; Montgomery image = lo*R + hi*R*R = mul(lo, R2) + mul(mul(hi, R2), R2)
     Fe<P> r2 = fe_r2<P>();
     fe_store(out + g * 8, fe_add(fe_mul(lo, r2), fe_mul(fe_mul(hi, r2), r2)));
-}
-
-// out[i] = x^i (binary method per thread)
-template <class P>
-__global__ void __launch_bounds__(256) k_powers(const uint32_t* __restrict__ x, size_t n, uint32_t* __restrict__ out) {
-    const size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (g >= n) return;
-    Fe<P> acc = fe_one<P>(), pw = fe_load<P>(x);
-    for (size_t e = g; e; e >>= 1) {
-        if (e & 1) acc = fe_mul(acc, pw);
-        pw = fe_sqr(pw);
-    }
-    fe_store(out + g * 8, acc);
-}
-
-// v[0] -= *s
-template <class P>
-__global__ void k_sub_at0(uint32_t* __restrict__ v, const uint32_t* __restrict__ s) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) fe_store(v, fe_sub(fe_load<P>(v), fe_load<P>(s)));
-}
-
-// Round scalars: for idx < n with r = idx mod m, t = idx div m:
-//   L[idx] = r <  m/2 ? p[r + m/2] * s[t] : 0        R[idx] = r >= m/2 ? p[r - m/2] * s[t] : 0
-//   L[n] = vl * z, L[n+1] = l_rand                   R[n] = vr * z, R[n+1] = r_rand
-template <class P>
-__global__ void __launch_bounds__(256) k_ipa_round_vectors(const uint32_t* __restrict__ p, const uint32_t* __restrict__ s, size_t n,
-                                                             unsigned log_m, const uint32_t* __restrict__ vlr,
-                                                             const uint32_t* __restrict__ z, const uint32_t* __restrict__ rands,
-                                                             uint32_t* __restrict__ lr) {
-    const size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    uint32_t* L = lr;
-    uint32_t* R = lr + (n + 2) * 8;
-    if (g < n) {
-        const size_t m = (size_t)1 << log_m, half = m >> 1, r = g & (m - 1), t = g >> log_m;
-        const Fe<P> st = fe_load<P>(s + t * 8);
-        const Fe<P> zero = fe_zero<P>();
-        if (r < half) {
-            fe_store(L + g * 8, fe_mul(fe_load<P>(p + (r + half) * 8), st));
-            fe_store(R + g * 8, zero);
-        } else {
-            fe_store(L + g * 8, zero);
-            fe_store(R + g * 8, fe_mul(fe_load<P>(p + (r - half) * 8), st));
-        }
-    } else if (g == n) {
-        const Fe<P> zz = fe_load<P>(z);
-        fe_store(L + n * 8, fe_mul(fe_load<P>(vlr), zz));
-        fe_store(R + n * 8, fe_mul(fe_load<P>(vlr + 8), zz));
-        fe_store(L + (n + 1) * 8, fe_load<P>(rands));
-        fe_store(R + (n + 1) * 8, fe_load<P>(rands + 8));
-    }
 }
 
 // s_new[2t + beta] = s[t] * u^beta
@@ -252,147 +203,297 @@ struct DevBuf {
     } while (0)
 
 // ---------------------------------------------------------------------------
-// prover
+// prover, batched: `batch` independent openings advance in lockstep so that every round is ONE
+// MSM launch of 2*batch vectors, one device->host copy and one host<-device challenge upload.
+// Per-proof vectors are compact: p, b are (batch, m) and s is (batch, n/m) in round j (m = n >> j).
 // ---------------------------------------------------------------------------
+// host-written constants per proof (d_hc): [0] x3, [1] xi, [2] z, [3] u, [4] u_inv   (stride kHc)
+static constexpr size_t kHc = 8;
+
+template <class P>
+__global__ void k_sub_at0_batch(uint32_t* __restrict__ v, size_t stride, const uint32_t* __restrict__ s, size_t batch) {
+    const size_t b = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    uint32_t* e = v + b * stride * 8;
+    fe_store(e, fe_sub(fe_load<P>(e), fe_load<P>(s + b * 8)));
+}
+
+// commit scalars of S: out[b] = [s_poly_b (n) | 0 | s_blind_b]
+template <class P>
+__global__ void __launch_bounds__(256) k_ipa_commit_scalars(const uint32_t* __restrict__ spoly, const uint32_t* __restrict__ rands,
+                                                              size_t n, size_t nrand, uint32_t* __restrict__ out) {
+    const size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (g >= n + 2) return;
+    Fe<P> v = fe_zero<P>();
+    if (g < n) v = fe_load<P>(spoly + (b * n + g) * 8);
+    else if (g == n + 1) v = fe_load<P>(rands + (b * nrand + n) * 8);
+    fe_store(out + (b * (n + 2) + g) * 8, v);
+}
+
+// p'[b][i] = poly[b][i] + xi_b * s[b][i]
+template <class P>
+__global__ void __launch_bounds__(256) k_ipa_axpy(const uint32_t* __restrict__ poly, const uint32_t* __restrict__ spoly,
+                                                    const uint32_t* __restrict__ hc, size_t n, uint32_t* __restrict__ out) {
+    const size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (g >= n) return;
+    const Fe<P> xi = fe_load<P>(hc + (b * kHc + 1) * 8);
+    const size_t o = (b * n + g) * 8;
+    fe_store(out + o, fe_add(fe_load<P>(poly + o), fe_mul(xi, fe_load<P>(spoly + o))));
+}
+
+// bvec[b][i] = x3_b^i, s[b][0] = 1
+template <class P>
+__global__ void __launch_bounds__(256) k_ipa_init_b_s(const uint32_t* __restrict__ hc, size_t n, uint32_t* __restrict__ bvec,
+                                                        uint32_t* __restrict__ s) {
+    const size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (g >= n) return;
+    Fe<P> acc = fe_one<P>(), pw = fe_load<P>(hc + b * kHc * 8);
+    if (g == 0) fe_store(s + b * 8, acc);
+    for (size_t e = g; e; e >>= 1) {
+        if (e & 1) acc = fe_mul(acc, pw);
+        pw = fe_sqr(pw);
+    }
+    fe_store(bvec + (b * n + g) * 8, acc);
+}
+
+// out[b][0] = <p_hi, b_lo>, out[b][1] = <p_lo, b_hi>; grid (batch, 2)
+template <class P>
+__global__ void __launch_bounds__(256) k_ipa_inner2(const uint32_t* __restrict__ p, const uint32_t* __restrict__ bv, size_t half,
+                                                      uint32_t* __restrict__ out) {
+    __shared__ __align__(16) uint4 sh[2 * 256];
+    const size_t b = blockIdx.x, side = blockIdx.y, m = 2 * half;
+    const uint32_t* pa = p + (b * m + (side ? 0 : half)) * 8;
+    const uint32_t* ba = bv + (b * m + (side ? half : 0)) * 8;
+    Fe<P> acc = fe_zero<P>();
+    for (size_t i = threadIdx.x; i < half; i += 256) acc = fe_add(acc, fe_mul(fe_load<P>(pa + i * 8), fe_load<P>(ba + i * 8)));
+    acc = block_sum(acc, sh, 256);
+    if (threadIdx.x == 0) fe_store(out + (b * 2 + side) * 8, acc);
+}
+
+// Round scalars of proof b: for idx < n with r = idx mod m, t = idx div m:
+//   L[idx] = r <  m/2 ? p[r + m/2] * s[t] : 0        R[idx] = r >= m/2 ? p[r - m/2] * s[t] : 0
+//   L[n] = vl * z, L[n+1] = l_rand                   R[n] = vr * z, R[n+1] = r_rand
+template <class P>
+__global__ void __launch_bounds__(256) k_ipa_round_vectors(const uint32_t* __restrict__ p, const uint32_t* __restrict__ s, size_t n,
+                                                             unsigned log_m, const uint32_t* __restrict__ vlr,
+                                                             const uint32_t* __restrict__ hc, const uint32_t* __restrict__ rands,
+                                                             size_t nrand, unsigned round, uint32_t* __restrict__ lr) {
+    const size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x, b = blockIdx.y;
+    const size_t m = (size_t)1 << log_m, half = m >> 1;
+    const uint32_t* pb = p + b * m * 8;
+    const uint32_t* sb = s + b * (n >> log_m) * 8;
+    uint32_t* L = lr + b * 2 * (n + 2) * 8;
+    uint32_t* R = L + (n + 2) * 8;
+    if (g < n) {
+        const size_t r = g & (m - 1), t = g >> log_m;
+        const Fe<P> st = fe_load<P>(sb + t * 8);
+        const Fe<P> zero = fe_zero<P>();
+        if (r < half) {
+            fe_store(L + g * 8, fe_mul(fe_load<P>(pb + (r + half) * 8), st));
+            fe_store(R + g * 8, zero);
+        } else {
+            fe_store(L + g * 8, zero);
+            fe_store(R + g * 8, fe_mul(fe_load<P>(pb + (r - half) * 8), st));
+        }
+    } else if (g == n) {
+        const Fe<P> zz = fe_load<P>(hc + (b * kHc + 2) * 8);
+        const uint32_t* rd = rands + (b * nrand + n + 1 + 2 * (size_t)round) * 8;
+        fe_store(L + n * 8, fe_mul(fe_load<P>(vlr + b * 16), zz));
+        fe_store(R + n * 8, fe_mul(fe_load<P>(vlr + b * 16 + 8), zz));
+        fe_store(L + (n + 1) * 8, fe_load<P>(rd));
+        fe_store(R + (n + 1) * 8, fe_load<P>(rd + 8));
+    }
+}
+
+// one launch per round: p' = p_lo + u^-1 p_hi, b' = b_lo + u b_hi (i < half), s'[2t + beta] = s[t] u^beta (t < cnt)
+template <class P>
+__global__ void __launch_bounds__(256) k_ipa_round_fold(const uint32_t* __restrict__ p, const uint32_t* __restrict__ bv,
+                                                          const uint32_t* __restrict__ s, size_t half, size_t cnt,
+                                                          const uint32_t* __restrict__ hc, uint32_t* __restrict__ p_out,
+                                                          uint32_t* __restrict__ b_out, uint32_t* __restrict__ s_out) {
+    const size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x, b = blockIdx.y;
+    const Fe<P> u = fe_load<P>(hc + (b * kHc + 3) * 8);
+    if (g < half) {
+        const Fe<P> ui = fe_load<P>(hc + (b * kHc + 4) * 8);
+        const uint32_t* pb = p + b * 2 * half * 8;
+        const uint32_t* bb = bv + b * 2 * half * 8;
+        fe_store(p_out + (b * half + g) * 8, fe_add(fe_load<P>(pb + g * 8), fe_mul(ui, fe_load<P>(pb + (half + g) * 8))));
+        fe_store(b_out + (b * half + g) * 8, fe_add(fe_load<P>(bb + g * 8), fe_mul(u, fe_load<P>(bb + (half + g) * 8))));
+    }
+    if (g < cnt) {
+        const Fe<P> v = fe_load<P>(s + (b * cnt + g) * 8);
+        fe_store(s_out + (b * 2 * cnt + 2 * g) * 8, v);
+        fe_store(s_out + (b * 2 * cnt + 2 * g + 1) * 8, fe_mul(v, u));
+    }
+}
+
+// Jacobian (Montgomery limbs as produced by msm_run) -> affine canonical x||y for `cnt` points with ONE inversion
+template <class PB>
+static void h_jac_batch_to_affine_canonical(const uint64_t* xyz, size_t cnt, uint64_t* xy) {
+    std::vector<Fe<PB>> pre(cnt + 1);
+    pre[0] = fe_one<PB>();
+    for (size_t i = 0; i < cnt; i++) {
+        const Fe<PB> Z = h_load<PB>(xyz + i * 12 + 8);
+        pre[i + 1] = fe_is_zero(Z) ? pre[i] : fe_mul(pre[i], Z);
+    }
+    Fe<PB> inv = fe_inv(pre[cnt]);
+    for (size_t i = cnt; i-- > 0;) {
+        const Fe<PB> Z = h_load<PB>(xyz + i * 12 + 8);
+        if (fe_is_zero(Z)) {
+            memset(xy + i * 8, 0, 64);
+            continue;
+        }
+        const Fe<PB> zi = fe_mul(inv, pre[i]);
+        inv = fe_mul(inv, Z);
+        const Fe<PB> zi2 = fe_sqr(zi), zi3 = fe_mul(zi2, zi);
+        h_store<PB>(xy + i * 8, fe_from_mont(fe_mul(h_load<PB>(xyz + i * 12), zi2)));
+        h_store<PB>(xy + i * 8 + 4, fe_from_mont(fe_mul(h_load<PB>(xyz + i * 12 + 4), zi3)));
+    }
+}
+
 template <class C>
-static int ipa_open_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_poly_in, int poly_on_device, const uint64_t* blind,
-                      const uint64_t* x3, const uint8_t* rng_bytes, bzh_transcript* tr, uint64_t* out_v) {
+static int ipa_open_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_polys, size_t batch, const uint64_t* blinds,
+                      const uint64_t* x3s, const uint8_t* rng_bytes, size_t rng_stride, bzh_transcript* const* trs,
+                      uint64_t* out_v) {
     using SF = typename CurveMeta<C>::SF;
     using PB = typename C::Base;
     const int field = CurveMeta<C>::scalar_field;
-    const size_t n = bases->n - 2;
+    const size_t n = bases->n - 2, B = batch;
     unsigned k = 0;
     while (((size_t)1 << k) < n) k++;
-    if (((size_t)1 << k) != n) return BZH_E_ARG;
-    const size_t nrand = n + 1 + 2 * (size_t)k;
+    if (((size_t)1 << k) != n || !B) return BZH_E_ARG;
+    const size_t nrand = n + 1 + 2 * (size_t)k, ntail = 1 + 2 * (size_t)k;
     hipStream_t st = ctx->stream;
 
-    // device arena: raw rng | rand scalars | s_poly | pp(2n: [poly | s_poly] then folded) | b | svec x2 | LR(2(n+2)) | small
-    const size_t words = nrand * 16 + nrand * 8 + 2 * n * 8 + n * 8 + 2 * n * 8 + n * 8 + 2 * (n + 2) * 8 + 64 * 8 + (n + 2) * 8;
-    DevBuf arena;
-    BZH_HIP_TRY(ctx, hipMalloc(&arena.p, words * 4));
-    uint32_t* cur = (uint32_t*)arena.p;
+    // device arena (workspace slot 4), per proof: raw rng | rand scalars | s_poly | p x2 | b x2 | s x2 | LR | S scalars | small
+    const size_t per = nrand * 16 + nrand * 8 + n * 8 + 2 * n * 8 + 2 * n * 8 + 2 * n * 8 + 2 * (n + 2) * 8 + (n + 2) * 8 +
+                       (kHc + 4) * 8;
+    void* arena = nullptr;
+    IPA_TRY(ws_ensure(ctx, 4, B * per * 4 + 256, &arena));
+    uint32_t* cur = (uint32_t*)arena;
     auto take = [&](size_t w) {
         uint32_t* r = cur;
         cur += w;
         return r;
     };
-    uint32_t* d_raw = take(nrand * 16);
-    uint32_t* d_rand = take(nrand * 8);
-    uint32_t* d_pp = take(2 * n * 8);   // [poly | s_poly] -> p' (first n)
-    uint32_t* d_ppb = take(n * 8);      // fold ping-pong
-    uint32_t* d_b = take(n * 8);
-    uint32_t* d_bb = take(n * 8);
-    uint32_t* d_s0 = take(n * 8);
-    uint32_t* d_lr = take(2 * (n + 2) * 8);
-    uint32_t* d_small = take(64 * 8);   // [0] x3, [1] s(x3)/v, [2] xi, [3] z, [4..5] vl vr, [6] u, [7] u_inv
-    uint32_t* d_commit = take((n + 2) * 8);
+    uint32_t* d_raw = take(B * nrand * 16);
+    uint32_t* d_rand = take(B * nrand * 8);
+    uint32_t* d_spoly = take(B * n * 8);
+    uint32_t* p_cur = take(B * n * 8);
+    uint32_t* p_nxt = take(B * n * 8);
+    uint32_t* b_cur = take(B * n * 8);
+    uint32_t* b_nxt = take(B * n * 8);
+    uint32_t* s_cur = take(B * n * 8);
+    uint32_t* s_nxt = take(B * n * 8);
+    uint32_t* d_lr = take(B * 2 * (n + 2) * 8);
+    uint32_t* d_commit = take(B * (n + 2) * 8);
+    uint32_t* d_hc = take(B * kHc * 8);
+    uint32_t* d_dv = take(B * 8);       // s(x3) / v per proof
+    uint32_t* d_vlr = take(B * 2 * 8);  // value_l, value_r per proof
     void* d_out = nullptr;
-    IPA_TRY(ws_ensure(ctx, 3, 4 * 96, &d_out));
+    IPA_TRY(ws_ensure(ctx, 5, 2 * B * 96, &d_out));
 
-    auto up = [&](uint32_t* dst, const Fe<SF>& v) -> int {  // Montgomery element to device
-        BZH_HIP_TRY(ctx, hipMemcpyAsync(dst, v.l, 32, hipMemcpyHostToDevice, st));
-        BZH_HIP_TRY(ctx, hipStreamSynchronize(st));  // v is a stack temporary
-        return BZH_OK;
-    };
-    auto down = [&](const uint32_t* src, Fe<SF>& v) -> int {
-        BZH_HIP_TRY(ctx, hipMemcpyAsync(v.l, src, 32, hipMemcpyDeviceToHost, st));
-        BZH_HIP_TRY(ctx, hipStreamSynchronize(st));
-        return BZH_OK;
-    };
     const unsigned g256 = 256;
-    auto blocks = [&](size_t c) { return dim3((unsigned)((c + g256 - 1) / g256)); };
+    auto grid2 = [&](size_t c) { return dim3((unsigned)((c + g256 - 1) / g256), (unsigned)B); };
+    if (B > 65535) return BZH_E_ARG;
 
     // randomness: upstream draw order = n coefficients of s(X), s_blind, then (l_j, r_j) per round
-    BZH_HIP_TRY(ctx, hipMemcpyAsync(d_raw, rng_bytes, nrand * 64, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL((k_reduce_wide<SF>), blocks(nrand), dim3(g256), 0, st, d_raw, nrand, d_rand);
-    uint32_t* d_spoly = d_pp + n * 8;
-    BZH_HIP_TRY(ctx, hipMemcpyAsync(d_spoly, d_rand, n * 32, hipMemcpyDeviceToDevice, st));
-    if (poly_on_device) {
-        BZH_HIP_TRY(ctx, hipMemcpyAsync(d_pp, d_poly_in, n * 32, hipMemcpyDeviceToDevice, st));
-    }  // else the caller staged it into d_poly_in == nullptr path below
-    const Fe<SF> x3m = fe_to_mont(h_load<SF>(x3));
-    IPA_TRY(up(d_small, x3m));
+    for (size_t b = 0; b < B; b++)
+        BZH_HIP_TRY(ctx, hipMemcpyAsync(d_raw + b * nrand * 16, rng_bytes + b * rng_stride, nrand * 64, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL((k_reduce_wide<SF>), dim3((unsigned)((B * nrand + g256 - 1) / g256)), dim3(g256), 0, st, d_raw, B * nrand,
+                       d_rand);
+    BZH_HIP_TRY(ctx, hipMemcpy2DAsync(d_spoly, n * 32, d_rand, nrand * 32, n * 32, B, hipMemcpyDeviceToDevice, st));
+    // the scalars the host needs (s_blind and the round blinds) come back in one strided copy
+    std::vector<Fe<SF>> tail(B * ntail);
+    BZH_HIP_TRY(ctx, hipMemcpy2DAsync(tail.data(), ntail * 32, d_rand + n * 8, nrand * 32, ntail * 32, B, hipMemcpyDeviceToHost, st));
+
+    std::vector<Fe<SF>> hc(B * kHc, fe_zero<SF>());
+    for (size_t b = 0; b < B; b++) hc[b * kHc] = fe_to_mont(h_load<SF>(x3s + 4 * b));
+    auto push_hc = [&]() -> int {
+        BZH_HIP_TRY(ctx, hipMemcpyAsync(d_hc, hc.data(), B * kHc * 32, hipMemcpyHostToDevice, st));
+        return BZH_OK;
+    };
+    IPA_TRY(push_hc());
     // s(X) -= s(x3)
-    IPA_TRY(poly_eval(ctx, field, d_spoly, n, 1, d_small, 0, d_small + 8));
-    hipLaunchKernelGGL((k_sub_at0<SF>), dim3(1), dim3(64), 0, st, d_spoly, d_small + 8);
+    IPA_TRY(poly_eval(ctx, field, d_spoly, n, B, d_hc, kHc, d_dv));
+    hipLaunchKernelGGL((k_sub_at0_batch<SF>), dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st, d_spoly, n, d_dv, B);
     // S = commit(s, s_blind): scalars [s..., 0, s_blind]
-    BZH_HIP_TRY(ctx, hipMemcpyAsync(d_commit, d_spoly, n * 32, hipMemcpyDeviceToDevice, st));
-    BZH_HIP_TRY(ctx, hipMemsetAsync(d_commit + n * 8, 0, 32, st));
-    BZH_HIP_TRY(ctx, hipMemcpyAsync(d_commit + (n + 1) * 8, d_rand + n * 8, 32, hipMemcpyDeviceToDevice, st));
-    IPA_TRY(msm_run(ctx, bases, d_commit, n + 2, 1, BZH_FORM_MONTGOMERY, (uint32_t*)d_out));
-    uint64_t jac[24], xy[8];
-    BZH_HIP_TRY(ctx, hipMemcpyAsync(jac, d_out, 96, hipMemcpyDeviceToHost, st));
-    Fe<SF> s_blind;
-    IPA_TRY(down(d_rand + n * 8, s_blind));
-    h_jac_to_affine_canonical<PB>(jac, xy);
-    IPA_TRY(bzh_transcript_write_point(tr, C::id, xy));
+    hipLaunchKernelGGL((k_ipa_commit_scalars<SF>), grid2(n + 2), dim3(g256), 0, st, d_spoly, d_rand, n, nrand, d_commit);
+    BZH_HIP_TRY(ctx, hipGetLastError());
+    IPA_TRY(msm_run(ctx, bases, d_commit, n + 2, B, BZH_FORM_MONTGOMERY, (uint32_t*)d_out));
+    std::vector<uint64_t> jac(2 * B * 12), xy(2 * B * 8);
+    BZH_HIP_TRY(ctx, hipMemcpyAsync(jac.data(), d_out, B * 96, hipMemcpyDeviceToHost, st));
+    BZH_HIP_TRY(ctx, hipStreamSynchronize(st));
+    h_jac_batch_to_affine_canonical<PB>(jac.data(), B, xy.data());
     uint64_t ch[4];
-    IPA_TRY(bzh_transcript_squeeze_challenge(tr, ch));
-    const Fe<SF> xi = fe_to_mont(h_load<SF>(ch));
-    IPA_TRY(bzh_transcript_squeeze_challenge(tr, ch));
-    const Fe<SF> z = fe_to_mont(h_load<SF>(ch));
-    IPA_TRY(up(d_small + 16, xi));
-    IPA_TRY(up(d_small + 24, z));
-    // p' = poly + xi * s_poly   ([poly | s_poly] folded with xi), then p'[0] -= v, v = p'(x3)
-    IPA_TRY(poly_fold(ctx, field, d_pp, n, 1, d_small + 16, 0, d_ppb));
-    uint32_t* p_cur = d_ppb;
-    uint32_t* p_nxt = d_pp;
-    IPA_TRY(poly_eval(ctx, field, p_cur, n, 1, d_small, 0, d_small + 8));
-    hipLaunchKernelGGL((k_sub_at0<SF>), dim3(1), dim3(64), 0, st, p_cur, d_small + 8);
-    Fe<SF> vm;
-    IPA_TRY(down(d_small + 8, vm));
-    h_store<SF>(out_v, fe_from_mont(vm));
-    Fe<SF> f = fe_add(fe_mul(s_blind, xi), fe_to_mont(h_load<SF>(blind)));
-    // b = powers of x3 ; s = [1]
-    hipLaunchKernelGGL((k_powers<SF>), blocks(n), dim3(g256), 0, st, d_small, n, d_b);
-    uint32_t* b_cur = d_b;
-    uint32_t* b_nxt = d_bb;
-    uint32_t* s_cur = d_s0;
-    uint32_t* s_nxt = d_commit;  // n elements are enough (d_commit is free after S)
-    IPA_TRY(up(s_cur, fe_one<SF>()));
+    std::vector<Fe<SF>> f(B);
+    for (size_t b = 0; b < B; b++) {
+        IPA_TRY(bzh_transcript_write_point(trs[b], C::id, xy.data() + b * 8));
+        IPA_TRY(bzh_transcript_squeeze_challenge(trs[b], ch));
+        const Fe<SF> xi = fe_to_mont(h_load<SF>(ch));
+        IPA_TRY(bzh_transcript_squeeze_challenge(trs[b], ch));
+        hc[b * kHc + 1] = xi;
+        hc[b * kHc + 2] = fe_to_mont(h_load<SF>(ch));
+        f[b] = fe_add(fe_mul(tail[b * ntail], xi), fe_to_mont(h_load<SF>(blinds + 4 * b)));
+    }
+    IPA_TRY(push_hc());
+    // p' = poly + xi * s_poly, then p'[0] -= v with v = p'(x3)
+    hipLaunchKernelGGL((k_ipa_axpy<SF>), grid2(n), dim3(g256), 0, st, d_polys, d_spoly, d_hc, n, p_cur);
+    IPA_TRY(poly_eval(ctx, field, p_cur, n, B, d_hc, kHc, d_dv));
+    hipLaunchKernelGGL((k_sub_at0_batch<SF>), dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st, p_cur, n, d_dv, B);
+    std::vector<Fe<SF>> vm(B);
+    BZH_HIP_TRY(ctx, hipMemcpyAsync(vm.data(), d_dv, B * 32, hipMemcpyDeviceToHost, st));  // read after the next sync
+    hipLaunchKernelGGL((k_ipa_init_b_s<SF>), grid2(n), dim3(g256), 0, st, d_hc, n, b_cur, s_cur);
     BZH_HIP_TRY(ctx, hipGetLastError());
 
+    std::vector<Fe<SF>> us(B), pre(B + 1);
     for (unsigned j = 0; j < k; j++) {
-        const size_t m = n >> j, half = m >> 1;
-        // value_l = <p_hi, b_lo>, value_r = <p_lo, b_hi>
-        IPA_TRY(poly_inner_product(ctx, field, p_cur + half * 8, b_cur, half, 1, d_small + 32));
-        IPA_TRY(poly_inner_product(ctx, field, p_cur, b_cur + half * 8, half, 1, d_small + 40));
-        hipLaunchKernelGGL((k_ipa_round_vectors<SF>), blocks(n + 1), dim3(g256), 0, st, p_cur, s_cur, n, k - j, d_small + 32,
-                           d_small + 24, d_rand + (n + 1 + 2 * (size_t)j) * 8, d_lr);
+        const size_t m = n >> j, half = m >> 1, cnt = (size_t)1 << j;
+        hipLaunchKernelGGL((k_ipa_inner2<SF>), dim3((unsigned)B, 2), dim3(256), 0, st, p_cur, b_cur, half, d_vlr);
+        hipLaunchKernelGGL((k_ipa_round_vectors<SF>), grid2(n + 1), dim3(g256), 0, st, p_cur, s_cur, n, k - j, d_vlr, d_hc, d_rand,
+                           nrand, j, d_lr);
         BZH_HIP_TRY(ctx, hipGetLastError());
-        IPA_TRY(msm_run(ctx, bases, d_lr, n + 2, 2, BZH_FORM_MONTGOMERY, (uint32_t*)d_out));
-        BZH_HIP_TRY(ctx, hipMemcpyAsync(jac, d_out, 192, hipMemcpyDeviceToHost, st));
-        Fe<SF> lr[2];
-        BZH_HIP_TRY(ctx, hipMemcpyAsync(lr, d_rand + (n + 1 + 2 * (size_t)j) * 8, 64, hipMemcpyDeviceToHost, st));
+        IPA_TRY(msm_run(ctx, bases, d_lr, n + 2, 2 * B, BZH_FORM_MONTGOMERY, (uint32_t*)d_out));
+        BZH_HIP_TRY(ctx, hipMemcpyAsync(jac.data(), d_out, 2 * B * 96, hipMemcpyDeviceToHost, st));
         BZH_HIP_TRY(ctx, hipStreamSynchronize(st));
-        h_jac_to_affine_canonical<PB>(jac, xy);
-        IPA_TRY(bzh_transcript_write_point(tr, C::id, xy));
-        h_jac_to_affine_canonical<PB>(jac + 12, xy);
-        IPA_TRY(bzh_transcript_write_point(tr, C::id, xy));
-        IPA_TRY(bzh_transcript_squeeze_challenge(tr, ch));
-        const Fe<SF> u = fe_to_mont(h_load<SF>(ch));
-        const Fe<SF> u_inv = fe_inv(u);
-        Fe<SF> uu[2] = {u, u_inv};
-        BZH_HIP_TRY(ctx, hipMemcpyAsync(d_small + 48, uu, 64, hipMemcpyHostToDevice, st));
-        BZH_HIP_TRY(ctx, hipStreamSynchronize(st));
+        h_jac_batch_to_affine_canonical<PB>(jac.data(), 2 * B, xy.data());
+        pre[0] = fe_one<SF>();
+        for (size_t b = 0; b < B; b++) {
+            IPA_TRY(bzh_transcript_write_point(trs[b], C::id, xy.data() + (2 * b) * 8));
+            IPA_TRY(bzh_transcript_write_point(trs[b], C::id, xy.data() + (2 * b + 1) * 8));
+            IPA_TRY(bzh_transcript_squeeze_challenge(trs[b], ch));
+            us[b] = fe_to_mont(h_load<SF>(ch));
+            if (fe_is_zero(us[b])) return BZH_E_ARG;  // a zero challenge has no inverse (probability 2^-255)
+            pre[b + 1] = fe_mul(pre[b], us[b]);
+        }
+        Fe<SF> inv = fe_inv(pre[B]);
+        for (size_t b = B; b-- > 0;) {
+            const Fe<SF> u_inv = fe_mul(inv, pre[b]);
+            inv = fe_mul(inv, us[b]);
+            hc[b * kHc + 3] = us[b];
+            hc[b * kHc + 4] = u_inv;
+            f[b] = fe_add(f[b], fe_add(fe_mul(tail[b * ntail + 1 + 2 * j], u_inv), fe_mul(tail[b * ntail + 2 + 2 * j], us[b])));
+        }
+        IPA_TRY(push_hc());
         // p' <- p_lo + u^-1 p_hi ; b <- b_lo + u b_hi ; s <- s (x) (1, u)
-        IPA_TRY(poly_fold(ctx, field, p_cur, half, 1, d_small + 56, 0, p_nxt));
-        IPA_TRY(poly_fold(ctx, field, b_cur, half, 1, d_small + 48, 0, b_nxt));
-        hipLaunchKernelGGL((k_ipa_s_update<SF>), blocks((size_t)1 << j), dim3(g256), 0, st, s_cur, (size_t)1 << j, d_small + 48, s_nxt);
+        hipLaunchKernelGGL((k_ipa_round_fold<SF>), grid2(half > cnt ? half : cnt), dim3(g256), 0, st, p_cur, b_cur, s_cur, half, cnt,
+                           d_hc, p_nxt, b_nxt, s_nxt);
         BZH_HIP_TRY(ctx, hipGetLastError());
         std::swap(p_cur, p_nxt);
         std::swap(b_cur, b_nxt);
         std::swap(s_cur, s_nxt);
-        f = fe_add(f, fe_add(fe_mul(lr[0], u_inv), fe_mul(lr[1], u)));
     }
-    Fe<SF> c;
-    IPA_TRY(down(p_cur, c));
-    uint64_t sc[4];
-    h_store<SF>(sc, fe_from_mont(c));
-    IPA_TRY(bzh_transcript_write_scalar(tr, sc));
-    h_store<SF>(sc, fe_from_mont(f));
-    IPA_TRY(bzh_transcript_write_scalar(tr, sc));
+    std::vector<Fe<SF>> c(B);
+    BZH_HIP_TRY(ctx, hipMemcpyAsync(c.data(), p_cur, B * 32, hipMemcpyDeviceToHost, st));
+    BZH_HIP_TRY(ctx, hipStreamSynchronize(st));
+    for (size_t b = 0; b < B; b++) {
+        h_store<SF>(out_v + 4 * b, fe_from_mont(vm[b]));
+        uint64_t sc[4];
+        h_store<SF>(sc, fe_from_mont(c[b]));
+        IPA_TRY(bzh_transcript_write_scalar(trs[b], sc));
+        h_store<SF>(sc, fe_from_mont(f[b]));
+        IPA_TRY(bzh_transcript_write_scalar(trs[b], sc));
+    }
     return BZH_OK;
 }
 
@@ -537,12 +638,12 @@ int random_field(bzh_ctx* ctx, int field, const uint32_t* d_raw, size_t count, u
     return BZH_OK;
 }
 
-int ipa_open(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_poly, const uint64_t* blind, const uint64_t* x3,
-             const uint8_t* rng_bytes, bzh_transcript* tr, uint64_t* out_v) {
+int ipa_open(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_polys, size_t batch, const uint64_t* blinds,
+             const uint64_t* x3s, const uint8_t* rng_bytes, size_t rng_stride, bzh_transcript* const* trs, uint64_t* out_v) {
     switch (bases->curve) {
-        case BZH_CURVE_VESTA: return ipa_open_t<VestaCurve>(ctx, bases, d_poly, 1, blind, x3, rng_bytes, tr, out_v);
-        case BZH_CURVE_PALLAS: return ipa_open_t<PallasCurve>(ctx, bases, d_poly, 1, blind, x3, rng_bytes, tr, out_v);
-        case BZH_CURVE_BN254: return ipa_open_t<Bn254Curve>(ctx, bases, d_poly, 1, blind, x3, rng_bytes, tr, out_v);
+        case BZH_CURVE_VESTA: return ipa_open_t<VestaCurve>(ctx, bases, d_polys, batch, blinds, x3s, rng_bytes, rng_stride, trs, out_v);
+        case BZH_CURVE_PALLAS: return ipa_open_t<PallasCurve>(ctx, bases, d_polys, batch, blinds, x3s, rng_bytes, rng_stride, trs, out_v);
+        case BZH_CURVE_BN254: return ipa_open_t<Bn254Curve>(ctx, bases, d_polys, batch, blinds, x3s, rng_bytes, rng_stride, trs, out_v);
     }
     return BZH_E_ARG;
 }

@@ -10,6 +10,7 @@
 //   lo + u * hi                              IPA round folding of p' and b
 // All kernels work on Montgomery-form elements (8 x u32), strided so that a wave touches
 // 64 consecutive 32-byte elements; modular-integer VALU work, no MFMA.
+#include "block.cuh"
 #include "ctx.hpp"
 #include "field.cuh"
 
@@ -140,30 +141,6 @@ __global__ void __launch_bounds__(256) k_scan_apply(uint32_t* __restrict__ data,
     uint32_t* base = data + (vec * n + tile * kScanTile) * 8;
     const size_t lim = min((size_t)kScanTile, n - tile * kScanTile);
     for (size_t i = threadIdx.x; i < lim; i += 256) fe_store(base + i * 8, Op::op(fe_load<P>(base + i * 8), off));
-}
-
-// ---------------------------------------------------------------------------
-// block-wide sum of one field element per thread (LDS tree), result in thread 0
-// ---------------------------------------------------------------------------
-template <class P>
-__device__ __forceinline__ Fe<P> block_sum(Fe<P> v, uint4* sh /* 2*T */, int T) {
-    const int tid = threadIdx.x;
-    for (int s = T >> 1; s >= 1; s >>= 1) {
-        __syncthreads();
-        if (tid >= s && tid < 2 * s) {
-            sh[tid] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
-            sh[T + tid] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
-        }
-        __syncthreads();
-        if (tid < s) {
-            uint4 a = sh[tid + s], b = sh[T + tid + s];
-            Fe<P> o;
-            o.l[0] = a.x; o.l[1] = a.y; o.l[2] = a.z; o.l[3] = a.w;
-            o.l[4] = b.x; o.l[5] = b.y; o.l[6] = b.z; o.l[7] = b.w;
-            v = fe_add(v, o);
-        }
-    }
-    return v;
 }
 
 // ---------------------------------------------------------------------------

@@ -227,6 +227,12 @@ int bzh_expr_eval(bzh_ctx* ctx, int field, const bzh_expr_op* prog, size_t nops,
  *                g0_u_w: G_0, U, W as 3 canonical affine points.  Returns BZH_OK or BZH_E_VERIFY. */
 int bzh_ipa_open(bzh_ctx* ctx, const bzh_bases* bases, const uint64_t* poly, int form, int mem, const uint64_t* blind,
                  const uint64_t* x3, const uint8_t* rng, size_t rng_len, bzh_transcript* transcript, uint64_t* out_v);
+/* `batch` independent openings against the same bases, advanced in lockstep (every round is one MSM launch of
+ * 2*batch vectors and one host round trip): polys = batch x n coefficients, blinds / x3s / out_v = batch x 4 limbs,
+ * proof b draws from rng + b*rng_stride and writes to transcripts[b].  bzh_ipa_open is the batch = 1 case. */
+int bzh_ipa_open_batch(bzh_ctx* ctx, const bzh_bases* bases, const uint64_t* polys, int form, int mem, size_t batch,
+                       const uint64_t* blinds, const uint64_t* x3s, const uint8_t* rng, size_t rng_stride,
+                       bzh_transcript* const* transcripts, uint64_t* out_v);
 int bzh_ipa_verify(bzh_ctx* ctx, const bzh_bases* bases, const uint64_t* commitment_xy, const uint64_t* x3, const uint64_t* v,
                    const uint8_t* proof, size_t proof_len, bzh_transcript* transcript, const uint64_t* g0_u_w);
 

@@ -71,6 +71,45 @@ def test_ipa_open_bytes_match_oracle_and_verify(gpu_ctx, cid, k, precompute):
         hb.free()
 
 
+@pytest.mark.parametrize("k,batch", [(3, 4), (6, 3)])
+def test_ipa_open_batch_matches_per_proof_oracle(gpu_ctx, k, batch):
+    """bzh_ipa_open_batch: independent openings in lockstep, each with its own polynomial, blind, point, randomness
+    and transcript state, must emit exactly the bytes the oracle emits for that opening alone."""
+    import bzh2
+    cid = 0
+    cases = [setup_case(cid, k, 900 + k) for _ in range(1)]
+    cv, F, g, w, u = cases[0][:5]
+    rng = random.Random(77 + k)
+    n = 1 << k
+    hb = gpu_ctx.upload_bases(cid, C.points_to_array(g + [u, w])).precompute()
+    try:
+        polys, blinds, x3s, rbs, want_v, want_proof, trs = [], [], [], [], [], [], []
+        for b in range(batch):
+            poly = [rng.randrange(F.p) for _ in range(n)]
+            if b == 1:
+                poly = [0] * n                      # an all-zero polynomial: every L/R scalar vector is sparse
+            blind, x3 = rng.randrange(F.p), rng.randrange(F.p)
+            rbytes = bytes(rng.getrandbits(8) for _ in range(64 * (n + 1 + 2 * k)))
+            rs = [O.from_u512(rbytes[64 * i:64 * (i + 1)], F) for i in range(n + 1 + 2 * k)]
+            ot = O.Blake2bTranscript(F)
+            ot.common_scalar(1000 + b)
+            want_v.append(O.ipa_open(cv, g, w, u, poly, blind, x3, rs, ot))
+            want_proof.append(bytes(ot.proof))
+            t = bzh2.Transcript(bzh2.CURVE_SCALAR_FIELD[cid])
+            t.common_scalar(1000 + b)
+            trs.append(t)
+            polys.append(C.ints_to_array(poly))
+            blinds.append(blind)
+            x3s.append(x3)
+            rbs.append(rbytes)
+        got_v = gpu_ctx.ipa_open_batch(hb, np.stack(polys), blinds, x3s, rbs, trs)
+        assert got_v == want_v
+        for t, wp in zip(trs, want_proof):
+            assert t.proof() == wp
+    finally:
+        hb.free()
+
+
 def test_ipa_k11_roundtrip_shot_size(gpu_ctx, oracle_c):
     """Shot-circuit size (k = 11, benches/shot.rs:22): prove on the GPU, verify on the GPU; the commitment
     is checked against the C oracle's MSM."""
