@@ -496,7 +496,7 @@ Context.ipa_verify = _ctx_ipa_verify
 
 
 # ---- gate-expression evaluation (row a13) ------------------------------------------------------
-EXPORTS += ["bzh_expr_eval"]
+EXPORTS += ["bzh_expr_eval", "bzh_expr_eval_batch"]
 
 
 def _ctx_expr_eval(self, field: int, program, columns, form: int = FORM_CANONICAL) -> np.ndarray:
@@ -525,7 +525,7 @@ Context.expr_eval = _ctx_expr_eval
 
 
 # ---- multiopen / lookup helpers ---------------------------------------------------------------------
-EXPORTS += ["bzh_kate_division", "bzh_permute_expression_pair"]
+EXPORTS += ["bzh_kate_division", "bzh_kate_division_batch", "bzh_permute_expression_pair"]
 
 
 def _ctx_kate_division(self, field: int, coeffs, x: int, form: int = FORM_CANONICAL) -> np.ndarray:

@@ -131,6 +131,60 @@ class DeviceOps:
         self._chk(rc, "bzh_expr_eval")
         return out
 
+    # ---- batched (lockstep proofs) ---------------------------------------------------------------
+    def expr_batch(self, prog, ops_arr, cols, const_rows, size: int, batch: int) -> torch.Tensor:
+        """One launch of a compiled program over `batch` vectors.  cols: list of (data_ptr, stride_elems) with stride 0 for
+        columns shared by all vectors; const_rows: (batch, nconsts, 4) uint64 Montgomery limbs (or (1, nconsts, 4) shared)."""
+        L = self.L
+        if not hasattr(L, "_bzh_expr_batch_bound"):
+            L.bzh_expr_eval_batch.argtypes = [_VP, ctypes.c_int, ctypes.POINTER(X.ExprOp), ctypes.c_size_t, ctypes.POINTER(_VP),
+                                              ctypes.POINTER(ctypes.c_size_t), ctypes.c_size_t, _VP, ctypes.c_size_t, ctypes.c_size_t,
+                                              ctypes.c_uint, ctypes.c_int, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, _VP]
+            L._bzh_expr_batch_bound = True
+        nc = max(len(cols), 1)
+        ptrs = (_VP * nc)(*[c[0] for c in cols])
+        strides = (ctypes.c_size_t * nc)(*[c[1] for c in cols])
+        nconst = const_rows.shape[1]
+        cstride = nconst if const_rows.shape[0] > 1 else 0
+        consts = np.ascontiguousarray(const_rows if nconst else np.zeros((1, 1, 4), dtype=np.uint64))
+        out = torch.empty((batch, size, 4), dtype=torch.int64, device=self.dev)
+        rc = L.bzh_expr_eval_batch(self.ctx.handle, self.field, ops_arr, len(prog.ops), ptrs, strides, len(cols), _VP(consts.ctypes.data),
+                                   nconst, cstride, size.bit_length() - 1, prog.result_slot, batch, FORM_MONTGOMERY, MEM_DEVICE,
+                                   _VP(out.data_ptr()))
+        self._chk(rc, "bzh_expr_eval_batch")
+        return out
+
+    def kate_batch(self, coeffs: torch.Tensor, xs) -> torch.Tensor:
+        """coeffs (B, m, 4) contiguous, xs: B canonical ints -> (B, m-1, 4): vector b divided by (X - xs[b])"""
+        L = self.L
+        B, m = coeffs.shape[0], coeffs.shape[1]
+        L.bzh_kate_division_batch.argtypes = [_VP, ctypes.c_int, _VP, ctypes.c_size_t, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint64),
+                                              ctypes.c_int, ctypes.c_int, _VP]
+        out = torch.empty((B, m - 1, 4), dtype=torch.int64, device=self.dev)
+        xl = np.ascontiguousarray(np.stack([self.limbs_mont(x) for x in xs]))
+        self._chk(L.bzh_kate_division_batch(self.ctx.handle, self.field, _VP(coeffs.data_ptr()), m, B,
+                                            xl.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), FORM_MONTGOMERY, MEM_DEVICE,
+                                            _VP(out.data_ptr())), "bzh_kate_division_batch")
+        return out
+
+    def ipa_open_batch(self, bases: Bases, polys: torch.Tensor, blinds, x3s, rng_list, transcripts):
+        """polys (B, n, 4) Montgomery on the device; per-proof blinds / points / rng bytes / transcripts"""
+        L = self.L
+        u64p = ctypes.POINTER(ctypes.c_uint64)
+        L.bzh_ipa_open_batch.argtypes = [_VP, _VP, _VP, ctypes.c_int, ctypes.c_int, ctypes.c_size_t, u64p, u64p, ctypes.c_char_p,
+                                         ctypes.c_size_t, ctypes.POINTER(_VP), u64p]
+        B = len(transcripts)
+        stride = len(rng_list[0])
+        bl = np.ascontiguousarray(np.stack([int_to_limbs(v) for v in blinds]))
+        xs = np.ascontiguousarray(np.stack([int_to_limbs(v) for v in x3s]))
+        out = np.zeros((B, 4), dtype=np.uint64)
+        trs = (_VP * B)(*[t.h for t in transcripts])
+        rc = L.bzh_ipa_open_batch(self.ctx.handle, bases.handle, _VP(polys.data_ptr()), FORM_MONTGOMERY, MEM_DEVICE, B,
+                                  bl.ctypes.data_as(u64p), xs.ctypes.data_as(u64p), b"".join(rng_list), stride, trs,
+                                  out.ctypes.data_as(u64p))
+        self._chk(rc, "bzh_ipa_open_batch")
+        return [limbs_to_int(o) for o in out]
+
     def ipa_open(self, bases: Bases, poly: torch.Tensor, blind: int, x3: int, rng_bytes: bytes, transcript) -> int:
         out = np.zeros(4, dtype=np.uint64)
         u64p = ctypes.POINTER(ctypes.c_uint64)

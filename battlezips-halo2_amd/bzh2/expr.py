@@ -40,6 +40,13 @@ class Constant(Expr):
 
 
 @dataclass(frozen=True)
+class Symbol(Expr):
+    """A constant bound at evaluation time (a challenge): the program is compiled once per proving key and every
+    proof supplies its own value through Program.bind."""
+    name: object
+
+
+@dataclass(frozen=True)
 class Query(Expr):
     """Fixed / Advice / Instance query: column index into the caller's column list, rotation in rows
     of the evaluation domain (already multiplied by the extension factor)."""
@@ -78,7 +85,7 @@ class ExprOp(ctypes.Structure):
 class Program:
     def __init__(self):
         self.ops = []          # (op, dst, (kind, idx, rot), (kind, idx, rot))
-        self.consts = []       # ints
+        self.consts = []       # ints, or Symbol leaves to be bound per evaluation
         self._const_ix = {}
         self.result_slot = 0
 
@@ -87,6 +94,10 @@ class Program:
             self._const_ix[v] = len(self.consts)
             self.consts.append(v)
         return self._const_ix[v]
+
+    def bind(self, env: dict) -> list:
+        """constant values for one evaluation: Symbols looked up in `env`"""
+        return [env[c.name] if isinstance(c, Symbol) else c for c in self.consts]
 
     def as_array(self):
         arr = (ExprOp * len(self.ops))()
@@ -101,7 +112,7 @@ def _depth(e: Expr, memo: dict) -> int:
     k = id(e)
     if k in memo:
         return memo[k]
-    if isinstance(e, (Constant, Query)):
+    if isinstance(e, (Constant, Query, Symbol)):
         d = 0
     elif isinstance(e, (Negated, Scaled)):
         d = max(1, _depth(e.a, memo))
@@ -126,13 +137,15 @@ def compile_expression(e: Expr, modulus: int) -> Program:
         """-> (kind, idx, rot), slot_to_release_or_None"""
         if isinstance(x, Constant):
             return (CONST, prog.const(x.value % modulus), 0), None
+        if isinstance(x, Symbol):
+            return (CONST, prog.const(x), 0), None
         if isinstance(x, Query):
             return (COLUMN, x.column, x.rotation), None
         s = emit(x)
         return (SLOT, s, 0), s
 
     def emit(x) -> int:
-        if isinstance(x, (Constant, Query)):
+        if isinstance(x, (Constant, Query, Symbol)):
             a, _ = operand(x)
             d = alloc()
             prog.ops.append((COPY, d, a, (SLOT, 0, 0)))
@@ -166,15 +179,17 @@ def compile_expression(e: Expr, modulus: int) -> Program:
     return prog
 
 
-def evaluate_tree(e: Expr, columns, row: int, size: int, p: int) -> int:
+def evaluate_tree(e: Expr, columns, row: int, size: int, p: int, env: dict | None = None) -> int:
     """Direct (recursive) evaluation of the tree at one row -- the definition."""
     if isinstance(e, Constant):
         return e.value % p
+    if isinstance(e, Symbol):
+        return env[e.name] % p
     if isinstance(e, Query):
         return columns[e.column][(row + e.rotation) % size]
     if isinstance(e, Negated):
-        return (-evaluate_tree(e.a, columns, row, size, p)) % p
+        return (-evaluate_tree(e.a, columns, row, size, p, env)) % p
     if isinstance(e, Scaled):
-        return evaluate_tree(e.a, columns, row, size, p) * e.k % p
-    a, b = evaluate_tree(e.a, columns, row, size, p), evaluate_tree(e.b, columns, row, size, p)
+        return evaluate_tree(e.a, columns, row, size, p, env) * e.k % p
+    a, b = evaluate_tree(e.a, columns, row, size, p, env), evaluate_tree(e.b, columns, row, size, p, env)
     return (a + b) % p if isinstance(e, Sum) else a * b % p

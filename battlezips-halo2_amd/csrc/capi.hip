@@ -42,7 +42,8 @@ struct Stager {
     int in(const void* host, size_t elems, uint32_t** dev) {
         *dev = carve(elems * 32);
         if (!elems) return BZH_OK;
-        BZH_HIP_TRY(ctx, hipMemcpyAsync(*dev, host, elems * 32, hipMemcpyHostToDevice, ctx->stream));
+        int rc = h2d_small(ctx, *dev, host, elems * 32);
+        if (rc) return rc;
         if (form == BZH_FORM_CANONICAL) return field_convert(ctx, field, *dev, elems, 1);
         return BZH_OK;
     }
@@ -251,6 +252,7 @@ int bzh_ctx_destroy(bzh_ctx* ctx) {
     ntt_cache_drop(ctx);
     for (int i = 0; i < bzh_ctx::kWsSlots; i++)
         if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
+    if (ctx->pin) (void)hipHostFree(ctx->pin);
     for (auto& s : ctx->spans) {
         (void)hipEventDestroy(s.a);
         (void)hipEventDestroy(s.b);
@@ -448,8 +450,7 @@ int bzh_random_field(bzh_ctx* ctx, int field, const uint8_t* rng_bytes, size_t c
         Stager so{ctx, field, BZH_FORM_MONTGOMERY};  // already in the requested form: plain copy out
         return so.out(out, d_out, count);
     }
-    BZH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // the raw-byte staging is reused by the next call
-    return BZH_OK;
+    return BZH_OK;  // staging reuse by the next call is stream-ordered
 }
 
 int bzh_batch_invert(bzh_ctx* ctx, int field, uint64_t* data, size_t count, int form, int mem) {
@@ -561,50 +562,58 @@ int bzh_vec_mul(bzh_ctx* ctx, int field, uint64_t* a, const uint64_t* b, size_t 
     return s.out(a, da, count);
 }
 
-int bzh_kate_division(bzh_ctx* ctx, int field, const uint64_t* coeffs, size_t n, const uint64_t* x, int form, int mem,
-                      uint64_t* out) {
-    BZH_POLY_PROLOGUE(!coeffs || !x || !out || n < 1);
+int bzh_kate_division_batch(bzh_ctx* ctx, int field, const uint64_t* coeffs, size_t n, size_t batch, const uint64_t* xs, int form,
+                            int mem, uint64_t* out) {
+    BZH_POLY_PROLOGUE(!coeffs || !xs || !out || n < 1 || !batch || batch > 65535);
     if (n == 1) return BZH_OK;
     if (mem == BZH_MEM_DEVICE && form != BZH_FORM_MONTGOMERY) return BZH_E_ARG;
-    // x^-1 on the host (one inversion), both uploaded in Montgomery form
-    uint64_t xs[8];
-    int x_is_zero = 0;
-    {
-        uint64_t xin[4];
-        memcpy(xin, x, 32);
-        auto go = [&](auto tag) {
-            using PP = decltype(tag);
-            Fe<PP> xm = load_host<PP>(xin, form);
-            x_is_zero = fe_is_zero(xm);
-            store_host<PP>(xs, xm, BZH_FORM_MONTGOMERY);
-            store_host<PP>(xs + 4, fe_inv(xm), BZH_FORM_MONTGOMERY);
-        };
-        switch (field) {
-            case BZH_FIELD_FP: go(FpParams{}); break;
-            case BZH_FIELD_FQ: go(FqParams{}); break;
-            case BZH_FIELD_BN254_FR: go(BnFrParams{}); break;
-            default: go(BnFqParams{}); break;
+    // [x_v, x_v^-1] per vector, inverted on the host with one inversion for the whole batch; uploaded in Montgomery form
+    std::vector<uint64_t> xh(batch * 8);
+    auto go = [&](auto tag) {
+        using PP = decltype(tag);
+        std::vector<Fe<PP>> xm(batch), pre(batch + 1);
+        pre[0] = fe_one<PP>();
+        for (size_t v = 0; v < batch; v++) {
+            xm[v] = load_host<PP>(xs + 4 * v, form);
+            pre[v + 1] = fe_is_zero(xm[v]) ? pre[v] : fe_mul(pre[v], xm[v]);
         }
+        Fe<PP> inv = fe_inv(pre[batch]);
+        for (size_t v = batch; v-- > 0;) {
+            Fe<PP> xi = fe_zero<PP>();
+            if (!fe_is_zero(xm[v])) {
+                xi = fe_mul(inv, pre[v]);
+                inv = fe_mul(inv, xm[v]);
+            }
+            store_host<PP>(xh.data() + v * 8, xm[v], BZH_FORM_MONTGOMERY);
+            store_host<PP>(xh.data() + v * 8 + 4, xi, BZH_FORM_MONTGOMERY);
+        }
+    };
+    switch (field) {
+        case BZH_FIELD_FP: go(FpParams{}); break;
+        case BZH_FIELD_FQ: go(FqParams{}); break;
+        case BZH_FIELD_BN254_FR: go(BnFrParams{}); break;
+        default: go(BnFqParams{}); break;
     }
     Stager s{ctx, field, BZH_FORM_MONTGOMERY};
-    if ((rc = s.begin((2 * n + 4) * 32 + 512))) return rc;
+    if ((rc = s.begin(((mem == BZH_MEM_HOST ? 2 * n : 0) + 2) * batch * 32 + 512))) return rc;
     uint32_t* d_x;
-    if ((rc = s.in(xs, 2, &d_x))) return rc;
-    uint32_t* d_c;
-    uint32_t* d_q;
+    if ((rc = s.in(xh.data(), 2 * batch, &d_x))) return rc;
     if (mem == BZH_MEM_HOST) {
         Stager sc{ctx, field, form};
         sc.cur = s.cur;
-        if ((rc = sc.in(coeffs, n, &d_c))) return rc;
-        d_q = sc.carve((n - 1) * 32);
-        rc = poly_kate_division(ctx, field, d_c, n, d_x, d_x + 8, x_is_zero, d_q);
-        if (rc) return rc;
-        return sc.out(out, d_q, n - 1);
+        uint32_t* d_c;
+        if ((rc = sc.in(coeffs, n * batch, &d_c))) return rc;
+        uint32_t* d_q = sc.carve((n - 1) * batch * 32);
+        if ((rc = poly_kate_division(ctx, field, d_c, n, batch, d_x, d_q))) return rc;
+        return sc.out(out, d_q, (n - 1) * batch);
     }
-    rc = poly_kate_division(ctx, field, (const uint32_t*)coeffs, n, d_x, d_x + 8, x_is_zero, (uint32_t*)out);
-    if (rc) return rc;
-    BZH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // d_x staging is reused by the next call
-    return BZH_OK;
+    rc = poly_kate_division(ctx, field, (const uint32_t*)coeffs, n, batch, d_x, (uint32_t*)out);
+    return rc;  // staging reuse by the next call is stream-ordered
+}
+
+int bzh_kate_division(bzh_ctx* ctx, int field, const uint64_t* coeffs, size_t n, const uint64_t* x, int form, int mem,
+                      uint64_t* out) {
+    return bzh_kate_division_batch(ctx, field, coeffs, n, 1, x, form, mem, out);
 }
 
 int bzh_permute_expression_pair(int field, const uint64_t* input, const uint64_t* table, size_t usable_rows, int form,
@@ -618,10 +627,12 @@ int bzh_permute_expression_pair(int field, const uint64_t* input, const uint64_t
     }
 }
 
-int bzh_expr_eval(bzh_ctx* ctx, int field, const bzh_expr_op* prog, size_t nops, const uint64_t* const* columns, size_t ncols,
-                  const uint64_t* consts, size_t nconsts, unsigned log_size, int result_slot, int form, int mem, uint64_t* out) {
+int bzh_expr_eval_batch(bzh_ctx* ctx, int field, const bzh_expr_op* prog, size_t nops, const uint64_t* const* columns,
+                        const size_t* column_strides, size_t ncols, const uint64_t* consts, size_t nconsts, size_t const_stride,
+                        unsigned log_size, int result_slot, size_t batch, int form, int mem, uint64_t* out) {
     BZH_POLY_PROLOGUE(!prog || !nops || (!columns && ncols) || (!consts && nconsts) || !out || log_size > 30 ||
-                      result_slot < 0 || result_slot >= BZH_EXPR_MAX_SLOTS);
+                      result_slot < 0 || result_slot >= BZH_EXPR_MAX_SLOTS || !batch || batch > 65535 ||
+                      (const_stride && const_stride < nconsts));
     const size_t size = (size_t)1 << log_size;
     for (size_t i = 0; i < nops; i++) {  // validate the program: it indexes device memory
         const bzh_expr_op& o = prog[i];
@@ -636,33 +647,54 @@ int bzh_expr_eval(bzh_ctx* ctx, int field, const bzh_expr_op* prog, size_t nops,
         }
     }
     if (mem == BZH_MEM_DEVICE && form != BZH_FORM_MONTGOMERY) return BZH_E_ARG;
+    // host columns: vector v of column c is columns[c] + v * stride * 4 limbs; they are staged as `reps` consecutive copies
+    std::vector<size_t> strides(ncols, 0), reps(ncols, 1);
+    size_t host_elems = 0;
+    for (size_t c = 0; c < ncols; c++) {
+        strides[c] = (column_strides && batch > 1) ? column_strides[c] : 0;
+        if (strides[c] && strides[c] < size) return BZH_E_ARG;
+        reps[c] = strides[c] ? batch : 1;
+        host_elems += reps[c] * size;
+    }
+    const size_t nconst_total = const_stride ? const_stride * (batch - 1) + nconsts : nconsts;
     Stager s{ctx, field, form};
-    const size_t host_cols = mem == BZH_MEM_HOST ? ncols : 0;
-    if ((rc = s.begin((host_cols * size + nconsts + (mem == BZH_MEM_HOST ? size : 0)) * 32 + nops * sizeof(bzh_expr_op) +
-                      ncols * sizeof(void*) + 1024)))
+    if ((rc = s.begin(((mem == BZH_MEM_HOST ? host_elems + batch * size : 0) + nconst_total) * 32 + nops * sizeof(bzh_expr_op) +
+                      ncols * (sizeof(void*) + sizeof(size_t) + 128) + 1024)))
         return rc;
     std::vector<const uint32_t*> ptrs(ncols);
     for (size_t c = 0; c < ncols; c++) {
         if (mem == BZH_MEM_HOST) {
-            uint32_t* d;
-            if ((rc = s.in(columns[c], size, &d))) return rc;
+            uint32_t* d = s.carve(reps[c] * size * 32);
+            for (size_t v = 0; v < reps[c]; v++)
+                BZH_HIP_TRY(ctx, hipMemcpyAsync(d + v * size * 8, columns[c] + v * strides[c] * 4, size * 32, hipMemcpyHostToDevice,
+                                                ctx->stream));
+            if (form == BZH_FORM_CANONICAL && (rc = field_convert(ctx, field, d, reps[c] * size, 1))) return rc;
             ptrs[c] = d;
+            if (strides[c]) strides[c] = size;
         } else {
             ptrs[c] = (const uint32_t*)columns[c];
         }
     }
     uint32_t* d_consts;
-    if ((rc = s.in(consts, nconsts, &d_consts))) return rc;
+    if ((rc = s.in(consts, nconst_total, &d_consts))) return rc;
     uint32_t* d_prog = s.carve(nops * sizeof(bzh_expr_op));
     uint32_t* d_ptrs = s.carve(ncols * sizeof(void*) + 8);
-    BZH_HIP_TRY(ctx, hipMemcpyAsync(d_prog, prog, nops * sizeof(bzh_expr_op), hipMemcpyHostToDevice, ctx->stream));
-    if (ncols) BZH_HIP_TRY(ctx, hipMemcpyAsync(d_ptrs, ptrs.data(), ncols * sizeof(void*), hipMemcpyHostToDevice, ctx->stream));
-    uint32_t* d_out = mem == BZH_MEM_HOST ? s.carve(size * 32) : (uint32_t*)out;
-    rc = expr_eval(ctx, field, d_prog, (int)nops, (const uint32_t* const*)d_ptrs, d_consts, size, result_slot, d_out);
+    uint32_t* d_strides = s.carve(ncols * sizeof(size_t) + 8);
+    if ((rc = h2d_small(ctx, d_prog, prog, nops * sizeof(bzh_expr_op)))) return rc;
+    if (ncols && (rc = h2d_small(ctx, d_ptrs, ptrs.data(), ncols * sizeof(void*)))) return rc;
+    if (ncols && (rc = h2d_small(ctx, d_strides, strides.data(), ncols * sizeof(size_t)))) return rc;
+    uint32_t* d_out = mem == BZH_MEM_HOST ? s.carve(batch * size * 32) : (uint32_t*)out;
+    rc = expr_eval(ctx, field, d_prog, (int)nops, (const uint32_t* const*)d_ptrs, (const size_t*)d_strides, d_consts, const_stride, size,
+                   result_slot, batch, d_out);
     if (rc) return rc;
-    if (mem == BZH_MEM_HOST) return s.out(out, d_out, size);
-    BZH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // ptrs / prog staging is reused by the next call
-    return BZH_OK;
+    if (mem == BZH_MEM_HOST) return s.out(out, d_out, batch * size);
+    return BZH_OK;  // staging reuse by the next call is stream-ordered
+}
+
+int bzh_expr_eval(bzh_ctx* ctx, int field, const bzh_expr_op* prog, size_t nops, const uint64_t* const* columns, size_t ncols,
+                  const uint64_t* consts, size_t nconsts, unsigned log_size, int result_slot, int form, int mem, uint64_t* out) {
+    return bzh_expr_eval_batch(ctx, field, prog, nops, columns, nullptr, ncols, consts, nconsts, 0, log_size, result_slot, 1, form, mem,
+                               out);
 }
 
 int bzh_ipa_open_batch(bzh_ctx* ctx, const bzh_bases* bases, const uint64_t* polys, int form, int mem, size_t batch,

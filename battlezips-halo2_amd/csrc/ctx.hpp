@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstring>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -39,6 +40,9 @@ struct bzh_ctx {
     uint64_t acc_n[BZH_T_COUNT] = {0};
     double alg_bytes[BZH_T_COUNT] = {0};  // algorithmic bytes of the launches timed while profiling
     int num_cu = 256;
+    // pinned upload ring: small host->device copies stay asynchronous (a pageable hipMemcpyAsync waits for the copy)
+    char* pin = nullptr;
+    size_t pin_bytes = 0, pin_off = 0;
 };
 
 #define BZH_HIP_TRY(ctx, expr)                                                                    \
@@ -66,6 +70,30 @@ inline int ws_ensure(bzh_ctx* ctx, int slot, size_t bytes, void** out) {
         ctx->ws_bytes[slot] = want;
     }
     *out = ctx->ws[slot];
+    return BZH_OK;
+}
+
+// host -> device copy of a small, short-lived host buffer through the pinned ring: returns at once, stream-ordered
+inline int h2d_small(bzh_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    constexpr size_t kRing = (size_t)8 << 20;
+    if (!bytes) return BZH_OK;
+    if (bytes > kRing / 8) {
+        BZH_HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        return BZH_OK;
+    }
+    if (!ctx->pin) {
+        BZH_HIP_TRY(ctx, hipHostMalloc((void**)&ctx->pin, kRing, hipHostMallocDefault));
+        ctx->pin_bytes = kRing;
+        ctx->pin_off = 0;
+    }
+    const size_t need = (bytes + 63) & ~(size_t)63;
+    if (ctx->pin_off + need > ctx->pin_bytes) {  // wrap: everything queued from the ring has to have landed
+        BZH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->pin_off = 0;
+    }
+    memcpy(ctx->pin + ctx->pin_off, src, bytes);
+    BZH_HIP_TRY(ctx, hipMemcpyAsync(dst, ctx->pin + ctx->pin_off, bytes, hipMemcpyHostToDevice, ctx->stream));
+    ctx->pin_off += need;
     return BZH_OK;
 }
 
@@ -113,11 +141,10 @@ int poly_inner_product(bzh_ctx* ctx, int field, const uint32_t* a, const uint32_
 int poly_fold(bzh_ctx* ctx, int field, const uint32_t* in, size_t half, size_t batch, const uint32_t* u, size_t u_stride,
               uint32_t* out);
 int poly_vec_mul(bzh_ctx* ctx, int field, uint32_t* a, const uint32_t* b, size_t count);
-int poly_kate_division(bzh_ctx* ctx, int field, const uint32_t* d_c, size_t n, const uint32_t* d_x, const uint32_t* d_xinv,
-                       int x_is_zero, uint32_t* d_q);
+int poly_kate_division(bzh_ctx* ctx, int field, const uint32_t* d_c, size_t n, size_t batch, const uint32_t* d_xs, uint32_t* d_q);
 // exprvm.hip
-int expr_eval(bzh_ctx* ctx, int field, const void* d_prog, int nops, const uint32_t* const* d_cols, const uint32_t* d_consts,
-              size_t size, int result_slot, uint32_t* d_out);
+int expr_eval(bzh_ctx* ctx, int field, const void* d_prog, int nops, const uint32_t* const* d_cols, const size_t* d_strides,
+              const uint32_t* d_consts, size_t const_stride, size_t size, int result_slot, size_t batch, uint32_t* d_out);
 // ipa.hip
 int random_field(bzh_ctx* ctx, int field, const uint32_t* d_raw, size_t count, uint32_t* d_out);
 int ipa_open(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_polys, size_t batch, const uint64_t* blinds,

@@ -27,56 +27,59 @@ struct ExprOp {  // mirrors bzh_expr_op
 
 template <class P>
 __device__ __forceinline__ Fe<P> expr_operand(int kind, int idx, int rot, const Fe<P>* slots, const uint32_t* const* cols,
-                                               const uint32_t* consts, size_t r, size_t mask) {
+                                               const size_t* strides, const uint32_t* consts, size_t r, size_t mask, size_t v) {
     if (kind == BZH_EXPR_SLOT) return slots[idx];
     if (kind == BZH_EXPR_CONST) return fe_load<P>(consts + (size_t)idx * 8);
     const size_t row = (r + (size_t)(int64_t)rot) & mask;  // two's complement wrap, size is a power of two
-    return fe_load<P>(cols[idx] + row * 8);
+    return fe_load<P>(cols[idx] + (v * strides[idx] + row) * 8);
 }
 
+// grid.y = vector (proof) index v: column c of vector v starts strides[c] elements after vector v-1's (0 = shared by
+// all vectors), its constants const_stride elements after (0 = shared), its output `size` elements after.
 template <class P>
 __global__ void __launch_bounds__(256) k_expr_eval(const ExprOp* __restrict__ prog, int nops, const uint32_t* const* __restrict__ cols,
-                                                     const uint32_t* __restrict__ consts, size_t size, int result_slot,
-                                                     uint32_t* __restrict__ out) {
-    const size_t r = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+                                                     const size_t* __restrict__ strides, const uint32_t* __restrict__ consts,
+                                                     size_t const_stride, size_t size, int result_slot, uint32_t* __restrict__ out) {
+    const size_t r = blockIdx.x * (size_t)blockDim.x + threadIdx.x, v = blockIdx.y;
     if (r >= size) return;
     const size_t mask = size - 1;
+    const uint32_t* cv = consts + v * const_stride * 8;
     Fe<P> slots[kExprSlots];
     for (int i = 0; i < nops; i++) {
         const ExprOp op = prog[i];  // wave-uniform: scalar loads
-        const Fe<P> a = expr_operand<P>(op.a_kind, op.a_idx, op.a_rot, slots, cols, consts, r, mask);
-        Fe<P> v;
+        const Fe<P> a = expr_operand<P>(op.a_kind, op.a_idx, op.a_rot, slots, cols, strides, cv, r, mask, v);
+        Fe<P> val;
         if (op.op == BZH_EXPR_NEG) {
-            v = fe_neg(a);
+            val = fe_neg(a);
         } else if (op.op == BZH_EXPR_COPY) {
-            v = a;
+            val = a;
         } else {
-            const Fe<P> b = expr_operand<P>(op.b_kind, op.b_idx, op.b_rot, slots, cols, consts, r, mask);
-            v = op.op == BZH_EXPR_ADD ? fe_add(a, b) : (op.op == BZH_EXPR_SUB ? fe_sub(a, b) : fe_mul(a, b));
+            const Fe<P> b = expr_operand<P>(op.b_kind, op.b_idx, op.b_rot, slots, cols, strides, cv, r, mask, v);
+            val = op.op == BZH_EXPR_ADD ? fe_add(a, b) : (op.op == BZH_EXPR_SUB ? fe_sub(a, b) : fe_mul(a, b));
         }
-        slots[op.dst] = v;
+        slots[op.dst] = val;
     }
-    fe_store(out + r * 8, slots[result_slot]);
+    fe_store(out + (v * size + r) * 8, slots[result_slot]);
 }
 
 template <class P>
-static int expr_eval_t(bzh_ctx* ctx, const ExprOp* d_prog, int nops, const uint32_t* const* d_cols, const uint32_t* d_consts,
-                       size_t size, int result_slot, uint32_t* d_out) {
+static int expr_eval_t(bzh_ctx* ctx, const ExprOp* d_prog, int nops, const uint32_t* const* d_cols, const size_t* d_strides,
+                       const uint32_t* d_consts, size_t const_stride, size_t size, int result_slot, size_t batch, uint32_t* d_out) {
     ScopedTimer t(ctx, BZH_T_POLY);
-    hipLaunchKernelGGL((k_expr_eval<P>), dim3((unsigned)((size + 255) / 256)), dim3(256), 0, ctx->stream, d_prog, nops, d_cols,
-                       d_consts, size, result_slot, d_out);
+    hipLaunchKernelGGL((k_expr_eval<P>), dim3((unsigned)((size + 255) / 256), (unsigned)batch), dim3(256), 0, ctx->stream, d_prog, nops,
+                       d_cols, d_strides, d_consts, const_stride, size, result_slot, d_out);
     BZH_HIP_TRY(ctx, hipGetLastError());
     return BZH_OK;
 }
 
-int expr_eval(bzh_ctx* ctx, int field, const void* d_prog, int nops, const uint32_t* const* d_cols, const uint32_t* d_consts,
-              size_t size, int result_slot, uint32_t* d_out) {
+int expr_eval(bzh_ctx* ctx, int field, const void* d_prog, int nops, const uint32_t* const* d_cols, const size_t* d_strides,
+              const uint32_t* d_consts, size_t const_stride, size_t size, int result_slot, size_t batch, uint32_t* d_out) {
     const ExprOp* p = (const ExprOp*)d_prog;
     switch (field) {
-        case BZH_FIELD_FP: return expr_eval_t<FpParams>(ctx, p, nops, d_cols, d_consts, size, result_slot, d_out);
-        case BZH_FIELD_FQ: return expr_eval_t<FqParams>(ctx, p, nops, d_cols, d_consts, size, result_slot, d_out);
-        case BZH_FIELD_BN254_FR: return expr_eval_t<BnFrParams>(ctx, p, nops, d_cols, d_consts, size, result_slot, d_out);
-        case BZH_FIELD_BN254_FQ: return expr_eval_t<BnFqParams>(ctx, p, nops, d_cols, d_consts, size, result_slot, d_out);
+        case BZH_FIELD_FP: return expr_eval_t<FpParams>(ctx, p, nops, d_cols, d_strides, d_consts, const_stride, size, result_slot, batch, d_out);
+        case BZH_FIELD_FQ: return expr_eval_t<FqParams>(ctx, p, nops, d_cols, d_strides, d_consts, const_stride, size, result_slot, batch, d_out);
+        case BZH_FIELD_BN254_FR: return expr_eval_t<BnFrParams>(ctx, p, nops, d_cols, d_strides, d_consts, const_stride, size, result_slot, batch, d_out);
+        case BZH_FIELD_BN254_FQ: return expr_eval_t<BnFqParams>(ctx, p, nops, d_cols, d_strides, d_consts, const_stride, size, result_slot, batch, d_out);
     }
     return BZH_E_ARG;
 }

@@ -410,8 +410,7 @@ static int ipa_open_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_po
     std::vector<Fe<SF>> hc(B * kHc, fe_zero<SF>());
     for (size_t b = 0; b < B; b++) hc[b * kHc] = fe_to_mont(h_load<SF>(x3s + 4 * b));
     auto push_hc = [&]() -> int {
-        BZH_HIP_TRY(ctx, hipMemcpyAsync(d_hc, hc.data(), B * kHc * 32, hipMemcpyHostToDevice, st));
-        return BZH_OK;
+        return h2d_small(ctx, d_hc, hc.data(), B * kHc * 32);
     };
     IPA_TRY(push_hc());
     // s(X) -= s(x3)

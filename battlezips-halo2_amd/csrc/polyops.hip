@@ -305,55 +305,49 @@ __device__ __forceinline__ Fe<P> fe_pow_u64(Fe<P> base, size_t e) {
     }
     return acc;
 }
+// x / x^-1 of vector v sit at xs + v*16 / xs + v*16 + 8; vector v's coefficients at c + v*n*8
 template <class P>
-__global__ void __launch_bounds__(kVecThreads) k_kate_pre(const uint32_t* __restrict__ c, size_t n, const uint32_t* __restrict__ xinv,
+__global__ void __launch_bounds__(kVecThreads) k_kate_pre(const uint32_t* __restrict__ c, size_t n, const uint32_t* __restrict__ xs,
                                                             uint32_t* __restrict__ a) {
-    const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x, v = blockIdx.y;
     if (t >= n) return;
-    fe_store(a + t * 8, fe_mul(fe_load<P>(c + (n - 1 - t) * 8), fe_pow_u64(fe_load<P>(xinv), t)));
+    fe_store(a + (v * n + t) * 8, fe_mul(fe_load<P>(c + (v * n + n - 1 - t) * 8), fe_pow_u64(fe_load<P>(xs + v * 16 + 8), t)));
 }
 template <class P>
-__global__ void __launch_bounds__(kVecThreads) k_kate_post(const uint32_t* __restrict__ excl, const uint32_t* __restrict__ a, size_t n,
-                                                             const uint32_t* __restrict__ x, uint32_t* __restrict__ q) {
-    const size_t k = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(kVecThreads) k_kate_post(const uint32_t* __restrict__ c, const uint32_t* __restrict__ excl,
+                                                             const uint32_t* __restrict__ a, size_t n,
+                                                             const uint32_t* __restrict__ xs, uint32_t* __restrict__ q) {
+    const size_t k = blockIdx.x * (size_t)blockDim.x + threadIdx.x, v = blockIdx.y;
     if (k + 1 >= n) return;  // k <= n-2
-    const Fe<P> incl = fe_add(fe_load<P>(excl + k * 8), fe_load<P>(a + k * 8));
-    fe_store(q + (n - 2 - k) * 8, fe_mul(incl, fe_pow_u64(fe_load<P>(x), k)));
-}
-// x == 0: q_(i-1) = c_i
-template <class P>
-__global__ void __launch_bounds__(kVecThreads) k_shift_down(const uint32_t* __restrict__ c, size_t n, uint32_t* __restrict__ q) {
-    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (i + 1 >= n) return;
-    fe_store(q + i * 8, fe_load<P>(c + (i + 1) * 8));
+    const Fe<P> x = fe_load<P>(xs + v * 16);
+    if (fe_is_zero(x)) {  // x == 0: q_i = c_(i+1)
+        fe_store(q + (v * (n - 1) + k) * 8, fe_load<P>(c + (v * n + k + 1) * 8));
+        return;
+    }
+    const Fe<P> incl = fe_add(fe_load<P>(excl + (v * n + k) * 8), fe_load<P>(a + (v * n + k) * 8));
+    fe_store(q + (v * (n - 1) + n - 2 - k) * 8, fe_mul(incl, fe_pow_u64(x, k)));
 }
 
 template <class P>
-static int kate_t(bzh_ctx* ctx, const uint32_t* d_c, size_t n, const uint32_t* d_x, const uint32_t* d_xinv, int x_is_zero,
-                  uint32_t* d_q) {
-    if (n < 2) return BZH_OK;
-    const dim3 grid((unsigned)((n + kVecThreads - 1) / kVecThreads)), block(kVecThreads);
-    if (x_is_zero) {
-        hipLaunchKernelGGL((k_shift_down<P>), grid, block, 0, ctx->stream, d_c, n, d_q);
-        BZH_HIP_TRY(ctx, hipGetLastError());
-        return BZH_OK;
-    }
+static int kate_t(bzh_ctx* ctx, const uint32_t* d_c, size_t n, size_t batch, const uint32_t* d_xs, uint32_t* d_q) {
+    if (n < 2 || !batch) return BZH_OK;
+    if (batch > 65535) return BZH_E_ARG;
+    const dim3 grid((unsigned)((n + kVecThreads - 1) / kVecThreads), (unsigned)batch), block(kVecThreads);
     void* w = nullptr;
-    int rc = ws_ensure(ctx, 1, 2 * n * 32, &w);
+    int rc = ws_ensure(ctx, 1, 2 * n * batch * 32, &w);
     if (rc) return rc;
     uint32_t* a = (uint32_t*)w;
-    uint32_t* sc = a + n * 8;
-    hipLaunchKernelGGL((k_kate_pre<P>), grid, block, 0, ctx->stream, d_c, n, d_xinv, a);
-    BZH_HIP_TRY(ctx, hipMemcpyAsync(sc, a, n * 32, hipMemcpyDeviceToDevice, ctx->stream));
-    rc = prefix_scan_t<P, AddOp<P>>(ctx, sc, n, 1);
+    uint32_t* sc = a + n * batch * 8;
+    hipLaunchKernelGGL((k_kate_pre<P>), grid, block, 0, ctx->stream, d_c, n, d_xs, a);
+    BZH_HIP_TRY(ctx, hipMemcpyAsync(sc, a, n * batch * 32, hipMemcpyDeviceToDevice, ctx->stream));
+    rc = prefix_scan_t<P, AddOp<P>>(ctx, sc, n, batch);
     if (rc) return rc;
-    hipLaunchKernelGGL((k_kate_post<P>), grid, block, 0, ctx->stream, sc, a, n, d_x, d_q);
+    hipLaunchKernelGGL((k_kate_post<P>), grid, block, 0, ctx->stream, d_c, sc, a, n, d_xs, d_q);
     BZH_HIP_TRY(ctx, hipGetLastError());
     return BZH_OK;
 }
-int poly_kate_division(bzh_ctx* ctx, int field, const uint32_t* d_c, size_t n, const uint32_t* d_x, const uint32_t* d_xinv,
-                       int x_is_zero, uint32_t* d_q) {
-#define CALL(PP) kate_t<PP>(ctx, d_c, n, d_x, d_xinv, x_is_zero, d_q)
+int poly_kate_division(bzh_ctx* ctx, int field, const uint32_t* d_c, size_t n, size_t batch, const uint32_t* d_xs, uint32_t* d_q) {
+#define CALL(PP) kate_t<PP>(ctx, d_c, n, batch, d_xs, d_q)
     BZH_FIELD_SWITCH(field, CALL)
 #undef CALL
 }

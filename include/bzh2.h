@@ -172,6 +172,9 @@ int bzh_vec_mul(bzh_ctx* ctx, int field, uint64_t* a, const uint64_t* b, size_t 
  * the remainder p(x) is dropped.  x: 4 limbs in `form` (host). */
 int bzh_kate_division(bzh_ctx* ctx, int field, const uint64_t* coeffs, size_t n, const uint64_t* x, int form, int mem,
                       uint64_t* out);
+/* `batch` divisions in one pass: vector v = coeffs + v*n elements is divided by (X - xs[v]); out holds batch x (n-1). */
+int bzh_kate_division_batch(bzh_ctx* ctx, int field, const uint64_t* coeffs, size_t n, size_t batch, const uint64_t* xs, int form,
+                            int mem, uint64_t* out);
 /* lookup::prover::permute_expression_pair (host: one sort per lookup argument): over the first usable_rows rows,
  * out_input = the input column sorted by canonical value; out_table holds the input value wherever a new run of
  * equal inputs starts and the table's unused values elsewhere (ascending, filled from the last repeated row
@@ -213,6 +216,14 @@ typedef struct {
 } bzh_expr_op;
 int bzh_expr_eval(bzh_ctx* ctx, int field, const bzh_expr_op* prog, size_t nops, const uint64_t* const* columns, size_t ncols,
                   const uint64_t* consts, size_t nconsts, unsigned log_size, int result_slot, int form, int mem, uint64_t* out);
+
+/* The same program over `batch` vectors (independent proofs) in one launch: vector v reads column c at
+ * columns[c] + v * column_strides[c] elements (0, or column_strides == NULL: the column is shared, e.g. fixed /
+ * permutation columns of the proving key) and its constants at consts + v * const_stride elements (0: shared;
+ * otherwise >= nconsts, e.g. per-proof challenges); out holds batch x 2^log_size results. */
+int bzh_expr_eval_batch(bzh_ctx* ctx, int field, const bzh_expr_op* prog, size_t nops, const uint64_t* const* columns,
+                        const size_t* column_strides, size_t ncols, const uint64_t* consts, size_t nconsts, size_t const_stride,
+                        unsigned log_size, int result_slot, size_t batch, int form, int mem, uint64_t* out);
 
 /* ---- inner-product-argument opening (halo2_proofs poly::commitment::{create_proof, verify_proof}) --
  * Step 9 of plonk::create_proof and the heart of verify_proof (benches/board.rs:80-86).

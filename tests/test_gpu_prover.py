@@ -118,3 +118,67 @@ def test_battlezips_shaped_circuit_proof_matches_oracle(stream_ctx, oracle_c):
     adv_dev = [pk.ops.upload(col) for col in adv]          # witness resident in HBM, as in bench.py
     got = D.create_proof(pk, adv_dev, inst, rbytes, bzh2.Transcript(bzh2.FIELD_FP))
     assert got == want
+
+
+@pytest.mark.parametrize("k,with_lookup,degree,batch", [(4, False, None, 2), (5, True, None, 3), (6, True, 9, 3)])
+def test_lockstep_batch_prover_each_proof_matches_oracle(stream_ctx, oracle_c, k, with_lookup, degree, batch):
+    """bzh2/prover_batch.create_proofs: `batch` different witnesses of one circuit proven in lockstep (one launch per
+    kernel class per phase for all of them); proof b must be byte-identical to the oracle's proof of witness b under
+    proof b's own randomness stream."""
+    import torch
+    import bzh2
+    from bzh2 import prover as P, prover_batch as PB, prover_dev as D
+    cv, F = O.VESTA, O.FP
+    cases = [S.build(k=k, seed=300 + 7 * b + k, with_lookup=with_lookup, degree=degree) for b in range(batch)]
+    cs, fixed, copies = cases[0][:3]
+    assert all(cse[1] == fixed and cse[2] == copies for cse in cases)        # one circuit, different witnesses
+    rng = random.Random(3000 + k)
+    g = [cv.random_point(rng) for _ in range(cs.n)]
+    w, u = cv.random_point(rng), cv.random_point(rng)
+    ndraws = 4000 + 3 * cs.n
+    keys = H.Keys(cs, H.Domain(cs, F), cv, g, w, u, fixed, copies)
+    rbs, want = [], []
+    for b in range(batch):
+        rbytes = bytes(rng.getrandbits(8) for _ in range(64 * ndraws))
+        rs = [O.from_u512(rbytes[64 * i:64 * (i + 1)], F) for i in range(ndraws)]
+        want.append(H.create_proof(keys, cases[b][3], cases[b][4], rs, O.Blake2bTranscript(F)))
+        rbs.append(rbytes)
+    circ = P.Circuit(cs.k, cs.num_advice, cs.num_fixed, cs.num_instance, cs.gates, cs.perm_columns, cs.lookups, fixed, copies,
+                     degree=degree)
+    pk = D.DeviceProvingKey(stream_ctx, circ, bzh2.CURVE_VESTA, g, w, u, torch.device("cuda", 0))
+    bp = PB.BatchProver(pk)
+    for _ in range(2):                                                        # second pass runs on the cached programs
+        got = PB.create_proofs(bp, [cse[3] for cse in cases], [cse[4] for cse in cases], rbs,
+                               [bzh2.Transcript(bzh2.FIELD_FP) for _ in range(batch)])
+        assert got == want
+    assert len(set(got)) == batch
+    for b in range(batch):
+        assert H.verify_proof(keys, cases[b][4], got[b], O.Blake2bTranscript(F))
+
+
+def test_lockstep_batch_prover_battlezips_shaped(stream_ctx, oracle_c):
+    """The benchmark circuit at k = 7, two witnesses in lockstep with the witness tensor resident in HBM (bench.py's path)."""
+    import torch
+    import bzh2
+    from bzh2 import prover_batch as PB, prover_dev as D, synth
+    cv, F = O.VESTA, O.FP
+    built = [synth.battlezips_shaped(7, seed=40 + b) for b in range(2)]
+    circ = built[0][0]
+    assert built[1][0].fixed == circ.fixed and built[1][0].copies == circ.copies
+    cs = H.ConstraintSystem(circ.k, 11, 8, 1, circ.gates, circ.perm_columns, circ.lookups, degree=9)
+    rng = random.Random(78)
+    g = [cv.random_point(rng) for _ in range(cs.n)]
+    w, u = cv.random_point(rng), cv.random_point(rng)
+    keys = H.Keys(cs, H.Domain(cs, F), cv, g, w, u, circ.fixed, circ.copies)
+    ndraws = 6000
+    rbs, want = [], []
+    for b in range(2):
+        rbytes = bytes(rng.getrandbits(8) for _ in range(64 * ndraws))
+        rs = [O.from_u512(rbytes[64 * i:64 * (i + 1)], F) for i in range(ndraws)]
+        want.append(H.create_proof(keys, built[b][1], built[b][2], rs, O.Blake2bTranscript(F)))
+        rbs.append(rbytes)
+    pk = D.DeviceProvingKey(stream_ctx, circ, bzh2.CURVE_VESTA, g, w, u, torch.device("cuda", 0))
+    adv = torch.stack([torch.stack([pk.ops.upload(col) for col in built[b][1]]) for b in range(2)])
+    got = PB.create_proofs(PB.BatchProver(pk), adv, [built[b][2] for b in range(2)], rbs,
+                           [bzh2.Transcript(bzh2.FIELD_FP) for _ in range(2)])
+    assert got == want
