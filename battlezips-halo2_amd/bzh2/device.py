@@ -44,9 +44,14 @@ class DeviceOps:
 
     def upload(self, ints) -> torch.Tensor:
         """canonical ints -> Montgomery tensor (len, 4) int64 on the device"""
-        buf = b"".join(self.mont(int(v)).to_bytes(32, "little") for v in ints)
-        a = np.frombuffer(buf, dtype=np.int64).reshape(-1, 4)
-        return torch.from_numpy(a.copy()).to(self.dev)
+        buf = b"".join([int(v).to_bytes(32, "little") for v in ints])
+        if not buf:
+            return self.zeros(0)
+        t = torch.frombuffer(bytearray(buf), dtype=torch.int64).view(-1, 4).to(self.dev)
+        if t.shape[0]:      # Montgomery conversion on the device (one multiplication by R^2 per element)
+            self._chk(self.L.bzh_field_convert(self.ctx.handle, self.field, _VP(t.data_ptr()), t.shape[0], 1, MEM_DEVICE),
+                      "bzh_field_convert")
+        return t
 
     def download(self, t: torch.Tensor):
         b = t.contiguous().cpu().numpy().tobytes()

@@ -298,7 +298,7 @@ def _lagrange_interpolate(points, evals, p):
                 continue
             num = [(-xm * num[0]) % p] + [(num[i - 1] - xm * num[i]) % p for i in range(1, len(num))] + [num[-1]]
             den = den * (xj - xm) % p
-        cf = yj * pow(den, p - 2, p) % p
+        cf = yj * pow(den, -1, p) % p
         for i, v in enumerate(num):
             res[i] = (res[i] + cf * v) % p
     return res

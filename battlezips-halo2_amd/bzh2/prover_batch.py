@@ -22,7 +22,7 @@ from . import expr as X
 from .prover import _lagrange_interpolate, _query_sets, _Rng
 from .prover_dev import DeviceProvingKey, _horner
 
-_POOL = ThreadPoolExecutor(max_workers=8)
+_POOL = ThreadPoolExecutor(max_workers=16)
 
 
 class _Cols:
@@ -86,6 +86,13 @@ class BatchProver:
         self.pk = pk
         self._progs = {}
         self._open = None
+        self.trace = None        # set to a list to collect (phase, seconds) with a device sync at every phase boundary
+
+    def _mark(self, name):
+        if self.trace is not None:
+            import time
+            torch.cuda.synchronize()
+            self.trace.append((name, time.perf_counter()))
 
     # ---- compiled programs -------------------------------------------------------------------
     def _program(self, key, build):
@@ -199,6 +206,11 @@ def create_proofs(bp: BatchProver, advice, instances, rng_list, transcripts) -> 
     for T in Ts:
         T.common_scalar(pk.vk_repr)
 
+    def draw_rows(count):
+        """the next `count` Field::random draws of every proof, reduced on the device -> (B * count, 4)"""
+        return ops.random_field(b"".join([rngs[b].take(count) for b in R]), B * count)
+
+    bp._mark('start')
     # ---- instance columns ----------------------------------------------------------------------
     ni = len(instances[0])
     inst = ops.zeros(B, ni, n)
@@ -212,8 +224,8 @@ def create_proofs(bp: BatchProver, advice, instances, rng_list, transcripts) -> 
         for b in R:
             for i in range(ni):
                 Ts[b].common_point(pts[b * ni + i])
-    inst_cosets = bp.to_extended(inst_polys)
 
+    bp._mark('instance')
     # ---- advice columns ------------------------------------------------------------------------
     if isinstance(advice, torch.Tensor):
         adv = advice.clone()
@@ -221,15 +233,21 @@ def create_proofs(bp: BatchProver, advice, instances, rng_list, transcripts) -> 
         adv = torch.stack([torch.stack([col.to(dev) if isinstance(col, torch.Tensor) else up(list(col) + [0] * (n - len(col)))
                                         for col in cols]) for cols in advice])
     na = adv.shape[1]
-    adv[:, :, usable:] = up([rngs[b].scalar() for b in R for _ in range(na) for _ in range(usable, n)]).view(B, na, n - usable, 4)
+    adv[:, :, usable:] = draw_rows(na * (n - usable)).view(B, na, n - usable, 4)
     adv_blinds = [[rngs[b].scalar() for _ in range(na)] for b in R]
     adv_polys = bp.to_coeff(adv)
     pts = bp.commit(adv_polys, [v for b in R for v in adv_blinds[b]])
     for b in R:
         for i in range(na):
             Ts[b].write_point(cv, pts[b * na + i])
-    adv_cosets = bp.to_extended(adv_polys)
     env = [{'theta': Ts[b].squeeze_challenge()} for b in R]
+    cosets = {}
+
+    def extend_witness():
+        # queued late on purpose: with lookups these transforms run on the device while the host sorts
+        if not cosets:
+            cosets['inst'] = bp.to_extended(inst_polys)
+            cosets['adv'] = bp.to_extended(adv_polys)
 
     def lag_registry():
         reg = _Cols()
@@ -241,6 +259,7 @@ def create_proofs(bp: BatchProver, advice, instances, rng_list, transcripts) -> 
             reg.add_batched(('instance', i), inst, i)
         return reg
 
+    bp._mark('advice')
     # ---- lookups: compress, permute (host sort), commit -------------------------------------------
     TH = X.Symbol('theta')
     nl = len(c.lookups)
@@ -251,12 +270,13 @@ def create_proofs(bp: BatchProver, advice, instances, rng_list, transcripts) -> 
         s_c = bp._run(('lk_tab', li), lambda: _horner([_lower(e, reg, 1) for e in tabs], TH), reg, env, n)
         ah = a_c.cpu().numpy().view(np.uint64)
         sh = s_c.cpu().numpy().view(np.uint64)
+        extend_witness()
         # the sort runs on the host, one task per proof (the C call releases the GIL)
         res = list(_POOL.map(lambda b: permute_expression_pair(pk.field, ah[b], sh[b], usable, FORM_MONTGOMERY), R))
         a_s = ops.zeros(B, 2, n)
         a_s[:, 0, :usable] = torch.from_numpy(np.stack([r[0] for r in res]).view(np.int64)).to(dev)
         a_s[:, 1, :usable] = torch.from_numpy(np.stack([r[1] for r in res]).view(np.int64)).to(dev)
-        a_s[:, :, usable:] = up([rngs[b].scalar() for b in R for _ in range(2 * (bf + 1))]).view(B, 2, bf + 1, 4)
+        a_s[:, :, usable:] = draw_rows(2 * (bf + 1)).view(B, 2, bf + 1, 4)
         blinds = [(rngs[b].scalar(), rngs[b].scalar()) for b in R]
         polys = bp.to_coeff(a_s)
         pts = bp.commit(polys, [v for b in R for v in blinds[b]])
@@ -264,11 +284,14 @@ def create_proofs(bp: BatchProver, advice, instances, rng_list, transcripts) -> 
             Ts[b].write_point(cv, pts[2 * b])
             Ts[b].write_point(cv, pts[2 * b + 1])
         lk.append({'a_c': a_c, 's_c': s_c, 'as': a_s, 'polys': polys, 'blinds': blinds})
+    extend_witness()
+    inst_cosets, adv_cosets = cosets['inst'], cosets['adv']
     for b in R:
         env[b]['beta'] = Ts[b].squeeze_challenge()
         env[b]['gamma'] = Ts[b].squeeze_challenge()
     BETA, GAMMA = X.Symbol('beta'), X.Symbol('gamma')
 
+    bp._mark('lookup')
     # ---- permutation and lookup grand products -----------------------------------------------------
     nsets = (len(c.perm_columns) + c.chunk_len - 1) // c.chunk_len if c.perm_columns else 0
     nz = nsets + nl
@@ -295,7 +318,7 @@ def create_proofs(bp: BatchProver, advice, instances, rng_list, transcripts) -> 
         if prev_slot is not None:   # chain the sets: start from the previous set's hand-over value z[usable]
             last = zs[:, prev_slot, usable:usable + 1].expand(B, n, 4).contiguous()
             ops.vec_mul_(z, last)
-        z[:, n - bf:] = up([rngs[b].scalar() for b in R for _ in range(bf)]).view(B, bf, 4)
+        z[:, n - bf:] = draw_rows(bf).view(B, bf, 4)
         for b in R:
             z_blinds[b].append(rngs[b].scalar())
         zs[:, slot] = z
@@ -338,6 +361,7 @@ def create_proofs(bp: BatchProver, advice, instances, rng_list, transcripts) -> 
     for d in lk:
         d['cosets'] = bp.to_extended(d['polys'])
 
+    bp._mark('grand_products')
     # ---- vanishing argument ----------------------------------------------------------------------
     random_poly = ops.random_field(b"".join(rngs[b].take(n) for b in R), B * n).view(B, n, 4)
     random_blinds = [rngs[b].scalar() for b in R]
@@ -401,6 +425,7 @@ def create_proofs(bp: BatchProver, advice, instances, rng_list, transcripts) -> 
             terms.append(X.Product(X.Product(active, X.Sum(a_p, X.Negated(s_p))), X.Sum(a_p, X.Negated(a_m1))))
         return X.Product(_horner(terms, X.Symbol('y')), reg.q('tinv'))
 
+    bp._mark('vanishing_setup')
     h = bp._run('quotient', build_quotient, reg, env, en)
     ops.ntt_(h, c.extended_k, B, pk.eomega, pk.zeta, True)
     npieces = c.degree - 1
@@ -421,6 +446,7 @@ def create_proofs(bp: BatchProver, advice, instances, rng_list, transcripts) -> 
             wp[r] = pow(pk.omega, r % n, p)
         return xs[b] * wp[r] % p
 
+    bp._mark('quotient+h_commit')
     # ---- evaluations: one gather of (polynomial, rotation) jobs out of the table of all committed polynomials ----
     nf, ns = len(pk.fixed_polys), len(pk.sigma_polys)
     if not hasattr(pk, '_fixed_stack'):
@@ -473,6 +499,7 @@ def create_proofs(bp: BatchProver, advice, instances, rng_list, transcripts) -> 
         for v in vals[b * J:(b + 1) * J]:
             Ts[b].write_scalar(v)
 
+    bp._mark('evaluations')
     # ---- h(X) = sum_i x^(n i) h_i(X) ---------------------------------------------------------------
     regh = _Cols()
     for i in range(npieces):
@@ -485,6 +512,7 @@ def create_proofs(bp: BatchProver, advice, instances, rng_list, transcripts) -> 
             acc = (acc * env[b]['xn'] + v) % p
         h_blind.append(acc)
 
+    bp._mark('h_poly')
     # ---- multiopen ------------------------------------------------------------------------------
     rot_sets, groups = bp._open_structure(nsets, nl)
     blind_of = []
@@ -565,6 +593,7 @@ def create_proofs(bp: BatchProver, advice, instances, rng_list, transcripts) -> 
         for r in rs:
             arr = ops.kate_batch(arr, [rot(b, r) for b in R])
         f_parts[:, si, :arr.shape[1]] = arr
+    bp._mark('multiopen_q_kate')
     regf = _Cols()
     for si in range(nq):
         regf.add_batched(si, f_parts, si)
@@ -594,7 +623,9 @@ def create_proofs(bp: BatchProver, advice, instances, rng_list, transcripts) -> 
         for v in q_blinds[b]:
             acc = (acc * env[b]['x4'] + v) % p
         p_blinds.append(acc)
+    bp._mark('multiopen_f_p')
     need = 64 * (n + 1 + 2 * c.k)
     rests = [rngs[b].rest()[:need] for b in R]
     ops.ipa_open_batch(pk.bases, p_poly, p_blinds, x3s, rests, Ts)
+    bp._mark('ipa')
     return [T.proof() for T in Ts]

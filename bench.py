@@ -49,6 +49,10 @@ def parse():
                              "proof_k11", "proof_k12", "proof_k14", "proof_k8"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-precompute", action="store_true", help="plain bases: no fixed-base window table for the SRS")
+    ap.add_argument("--batch", type=int, default=1,
+                    help="proof_k* workloads: proofs advanced in lockstep per step (bzh2/prover_batch.py: one launch per kernel "
+                         "class per phase for the whole batch); 1 = the single-proof latency path (bzh2/prover_dev.py)")
+    ap.add_argument("--window-bits", type=int, default=0, help="SRS window-table width (0: 8 for --batch 1, else the planner's)")
     ap.add_argument("--concurrency", type=int, default=1,
                     help="proof_k* workloads: independent proofs in flight per GPU (host threads, one ctx + stream each)")
     return ap.parse_args()
@@ -85,7 +89,7 @@ def make_bases(ctx, curve, n, seed):
 class Workload:
     """Device-resident inputs + the list of library calls that make one step."""
 
-    def __init__(self, name, ctx, device, seed, precompute=True, concurrency=1):
+    def __init__(self, name, ctx, device, seed, precompute=True, concurrency=1, batch=1, window_bits=0):
         self.name, self.ctx = name, ctx
         gen = torch.Generator(device=device)
         gen.manual_seed(seed)
@@ -137,7 +141,9 @@ class Workload:
             pts = make_bases(ctx, self.curve, n + 2, seed + 1)
             as_pt = lambda a: (bzh2.limbs_to_int(a[:4]), bzh2.limbs_to_int(a[4:]))
             g = [as_pt(a) for a in pts]
-            self.pk = D.DeviceProvingKey(ctx, circ, self.curve, g[:n], g[n + 1], g[n], device)
+            wb = window_bits or (8 if batch == 1 else 0)
+            self.pk = D.DeviceProvingKey(ctx, circ, self.curve, g[:n], g[n + 1], g[n], device, window_bits=wb)
+            self.window_bits = wb
             self.adv_dev = [self.pk.ops.upload(col) for col in adv]
             self.inst = inst
             self.circ = circ
@@ -185,6 +191,41 @@ class Workload:
                 for t in ths:
                     t.join()
             self.calls = [("create_proof", prove)]
+            if batch > 1:
+                # lockstep batch: the same witness columns for every proof of the batch (each proof still draws its own
+                # blinding randomness, so the proofs differ), stacked once and resident in HBM
+                # `concurrency` such batches run side by side (host threads, one ctx + stream each): one batch's host
+                # phases (transcripts, lookup sort, challenge uploads) overlap the other's kernels
+                from bzh2 import prover_batch as PB
+                bps = [PB.BatchProver(wpk) for _, wpk in self.workers]
+                adv_b = torch.stack(self.adv_dev).unsqueeze(0).repeat(batch, 1, 1, 1).contiguous()
+                self.units_per_step = batch * concurrency
+                self.rng_pool = [np.random.default_rng(seed + 100 + i).bytes(64 * ndraws) for i in range(batch * concurrency + 3)]
+                self.distinct = 0
+
+                def prove_batch_one(wi, step_no):
+                    rbs = [self.rng_pool[(step_no + wi * batch + b) % len(self.rng_pool)] for b in range(batch)]
+                    st = self.workers[wi][0]
+                    trs = [bzh2.Transcript(bzh2.FIELD_FP) for _ in range(batch)]
+                    if st is None:
+                        proofs = PB.create_proofs(bps[wi], adv_b, [self.inst] * batch, rbs, trs)
+                        self.last_proof = proofs[0]
+                        self.distinct = len(set(proofs))
+                    else:
+                        with torch.cuda.stream(st):
+                            PB.create_proofs(bps[wi], adv_b, [self.inst] * batch, rbs, trs)
+                        st.synchronize()
+
+                def prove_batch():
+                    sn = self.step_no
+                    self.step_no += 1
+                    ths = [threading.Thread(target=prove_batch_one, args=(wi, sn)) for wi in range(1, concurrency)]
+                    for t in ths:
+                        t.start()
+                    prove_batch_one(0, sn)
+                    for t in ths:
+                        t.join()
+                self.calls = [("create_proofs", prove_batch)]
             self.alg_bytes_msm_launch = 0
             self.alg_bytes_step = 0  # filled from the library's own counters (bzh_ctx_work) after the timed region
             self.desc = {"k": k, "circuit": "synthetic, BattleZips-shaped: 11 advice / 8 fixed / 1 instance, 24 gates, degree 9, "
@@ -283,7 +324,8 @@ def main():
 
     stream = torch.cuda.current_stream(device)
     ctx = bzh2.Context(local_rank, stream=stream.cuda_stream)
-    wl = Workload(args.workload, ctx, device, seed=1234 + rank, precompute=not args.no_precompute, concurrency=args.concurrency)
+    wl = Workload(args.workload, ctx, device, seed=1234 + rank, precompute=not args.no_precompute, concurrency=args.concurrency, batch=args.batch,
+                  window_bits=args.window_bits)
 
     def barrier():
         torch.cuda.synchronize(device)
@@ -332,7 +374,7 @@ def main():
             # rounds): average the bytes the library counted per launch (bzh_ctx_work) over the same launches
             dom_ms = acc["ms"] / max(acc["launches"], 1)
             alg = acc["algorithmic_bytes"] / max(acc["launches"], 1)
-            dom_name = "k_msm_accumulate (mean over the %d launches of one proof)" % (acc["launches"] // max(units, 1))
+            dom_name = "k_msm_accumulate (mean over the %d launches of one step)" % (acc["launches"] // max(args.steps, 1))
             wl.alg_bytes_step = (acc["algorithmic_bytes"] + nt["algorithmic_bytes"]) / max(args.steps, 1)
         else:
             dom_ms = acc["ms"] / max(acc["launches"], 1)
@@ -376,7 +418,12 @@ def main():
             line["config"]["stages"] = ("complete create_proof: commitments, lookup, permutation, vanishing, quotient, evaluations, "
                                         "multiopen, IPA, transcript; witness synthesis excluded (columns resident in HBM)")
             line["config"]["proof_bytes"] = len(wl.last_proof)
-            line["config"]["proofs_in_flight_per_gpu"] = args.concurrency
+            line["config"]["proofs_in_flight_per_gpu"] = args.concurrency * args.batch
+            line["config"]["concurrent_batches"] = args.concurrency
+            line["config"]["batch"] = args.batch
+            line["config"]["srs_window_bits"] = wl.window_bits or "planner"
+            if args.batch > 1:
+                line["config"]["distinct_proofs_in_last_batch"] = wl.distinct
         if world == 1 and (is_proof or is_full) and not args.no_cpu_baseline and args.workload != "shot_k11_batch":
             line["cpu_baseline"] = cpu_baseline(args.workload, wl.k)
             if is_full:
