@@ -127,6 +127,8 @@ struct ScopedTimer {
 // implemented in msm.hip / ntt.hip
 int msm_run(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_scalars, size_t n, size_t batch, int form,
             uint32_t* d_out_xyz);
+int msm_run_paired(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_scalars, size_t n_pair, unsigned log_m, size_t batch,
+                   int form, uint32_t* d_out_xyz);
 int ntt_run(bzh_ctx* ctx, int field, uint32_t* d_data, unsigned log_n, size_t batch, const uint64_t* omega,
             const uint64_t* coset_shift, int inverse, int form);
 int bases_to_montgomery(bzh_ctx* ctx, int curve, uint32_t* d_xy, size_t n);

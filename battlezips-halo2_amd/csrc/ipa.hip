@@ -305,6 +305,31 @@ __global__ void __launch_bounds__(256) k_ipa_round_vectors(const uint32_t* __res
     }
 }
 
+// The same scalars as ONE dense vector per proof for msm_run_paired (L and R have disjoint supports):
+//   LR[idx] = p[(r + m/2) mod m] * s[t]  (class = r >= m/2),  LR[n..n+1] = (vl z, l_rand),  LR[n+2..n+3] = (vr z, r_rand)
+template <class P>
+__global__ void __launch_bounds__(256) k_ipa_round_vectors_paired(const uint32_t* __restrict__ p, const uint32_t* __restrict__ s,
+                                                                    size_t n, unsigned log_m, const uint32_t* __restrict__ vlr,
+                                                                    const uint32_t* __restrict__ hc,
+                                                                    const uint32_t* __restrict__ rands, size_t nrand,
+                                                                    unsigned round, uint32_t* __restrict__ lr) {
+    const size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x, b = blockIdx.y;
+    const size_t m = (size_t)1 << log_m, half = m >> 1;
+    uint32_t* V = lr + b * (n + 4) * 8;
+    if (g < n) {
+        const size_t r = g & (m - 1), t = g >> log_m;
+        const size_t src = r < half ? r + half : r - half;
+        fe_store(V + g * 8, fe_mul(fe_load<P>(p + (b * m + src) * 8), fe_load<P>(s + (b * (n >> log_m) + t) * 8)));
+    } else if (g == n) {
+        const Fe<P> zz = fe_load<P>(hc + (b * kHc + 2) * 8);
+        const uint32_t* rd = rands + (b * nrand + n + 1 + 2 * (size_t)round) * 8;
+        fe_store(V + n * 8, fe_mul(fe_load<P>(vlr + b * 16), zz));
+        fe_store(V + (n + 1) * 8, fe_load<P>(rd));
+        fe_store(V + (n + 2) * 8, fe_mul(fe_load<P>(vlr + b * 16 + 8), zz));
+        fe_store(V + (n + 3) * 8, fe_load<P>(rd + 8));
+    }
+}
+
 // one launch per round: p' = p_lo + u^-1 p_hi, b' = b_lo + u b_hi (i < half), s'[2t + beta] = s[t] u^beta (t < cnt)
 template <class P>
 __global__ void __launch_bounds__(256) k_ipa_round_fold(const uint32_t* __restrict__ p, const uint32_t* __restrict__ bv,
@@ -366,7 +391,7 @@ static int ipa_open_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_po
     hipStream_t st = ctx->stream;
 
     // device arena (workspace slot 4), per proof: raw rng | rand scalars | s_poly | p x2 | b x2 | s x2 | LR | S scalars | small
-    const size_t per = nrand * 16 + nrand * 8 + n * 8 + 2 * n * 8 + 2 * n * 8 + 2 * n * 8 + 2 * (n + 2) * 8 + (n + 2) * 8 +
+    const size_t per = nrand * 16 + nrand * 8 + n * 8 + 2 * n * 8 + 2 * n * 8 + 2 * n * 8 + 2 * (n + 4) * 8 + (n + 2) * 8 +
                        (kHc + 4) * 8;
     void* arena = nullptr;
     IPA_TRY(ws_ensure(ctx, 4, B * per * 4 + 256, &arena));
@@ -385,7 +410,8 @@ static int ipa_open_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_po
     uint32_t* b_nxt = take(B * n * 8);
     uint32_t* s_cur = take(B * n * 8);
     uint32_t* s_nxt = take(B * n * 8);
-    uint32_t* d_lr = take(B * 2 * (n + 2) * 8);
+    uint32_t* d_lr = take(B * 2 * (n + 4) * 8);
+    const bool paired = bases->pre_c != 0 && k >= 1;  // window table: L_j and R_j of a proof share one dense vector
     uint32_t* d_commit = take(B * (n + 2) * 8);
     uint32_t* d_hc = take(B * kHc * 8);
     uint32_t* d_dv = take(B * 8);       // s(x3) / v per proof
@@ -449,10 +475,17 @@ static int ipa_open_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_po
     for (unsigned j = 0; j < k; j++) {
         const size_t m = n >> j, half = m >> 1, cnt = (size_t)1 << j;
         hipLaunchKernelGGL((k_ipa_inner2<SF>), dim3((unsigned)B, 2), dim3(256), 0, st, p_cur, b_cur, half, d_vlr);
-        hipLaunchKernelGGL((k_ipa_round_vectors<SF>), grid2(n + 1), dim3(g256), 0, st, p_cur, s_cur, n, k - j, d_vlr, d_hc, d_rand,
-                           nrand, j, d_lr);
-        BZH_HIP_TRY(ctx, hipGetLastError());
-        IPA_TRY(msm_run(ctx, bases, d_lr, n + 2, 2 * B, BZH_FORM_MONTGOMERY, (uint32_t*)d_out));
+        if (paired) {
+            hipLaunchKernelGGL((k_ipa_round_vectors_paired<SF>), grid2(n + 1), dim3(g256), 0, st, p_cur, s_cur, n, k - j, d_vlr, d_hc,
+                               d_rand, nrand, j, d_lr);
+            BZH_HIP_TRY(ctx, hipGetLastError());
+            IPA_TRY(msm_run_paired(ctx, bases, d_lr, n, k - j, B, BZH_FORM_MONTGOMERY, (uint32_t*)d_out));
+        } else {
+            hipLaunchKernelGGL((k_ipa_round_vectors<SF>), grid2(n + 1), dim3(g256), 0, st, p_cur, s_cur, n, k - j, d_vlr, d_hc,
+                               d_rand, nrand, j, d_lr);
+            BZH_HIP_TRY(ctx, hipGetLastError());
+            IPA_TRY(msm_run(ctx, bases, d_lr, n + 2, 2 * B, BZH_FORM_MONTGOMERY, (uint32_t*)d_out));
+        }
         BZH_HIP_TRY(ctx, hipMemcpyAsync(jac.data(), d_out, 2 * B * 96, hipMemcpyDeviceToHost, st));
         BZH_HIP_TRY(ctx, hipStreamSynchronize(st));
         h_jac_batch_to_affine_canonical<PB>(jac.data(), 2 * B, xy.data());

@@ -90,13 +90,26 @@ struct DigitOffset {
 // keeps the unsigned remainder (<= 2^(c-1) because c*nwin >= 256 > bits(s)).
 // u16 encoding: bit 15 = sign, bits 0..14 = magnitude (0 = skip).
 // ---------------------------------------------------------------------------
+// Paired vectors (MsmPair, the IPA rounds): entry i of a vector belongs to result class 0 or 1
+// (class = bit (log_m - 1) of i for i < n_pair; past that, the last two entries are class 1); class-1
+// magnitudes are shifted up by M so that the accumulate kernel files them in a second bucket set.
+struct MsmPair {
+    unsigned log_m;
+    size_t n_pair;
+    uint32_t M;
+};
 template <class SF>
 __global__ void __launch_bounds__(256) k_msm_digits(const uint32_t* __restrict__ scalars, size_t n, size_t total,
                                                       int form, int c, int nwin, DigitOffset off,
-                                                      uint16_t* __restrict__ digits) {
+                                                      uint16_t* __restrict__ digits, MsmPair pair) {
     size_t gid = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (gid >= total) return;
     size_t b = gid / n, i = gid - b * n;
+    uint32_t cls_off = 0;
+    if (pair.M) {
+        const bool hi = i < pair.n_pair ? ((i >> (pair.log_m - 1)) & 1) != 0 : (i >= pair.n_pair + 2);
+        cls_off = hi ? pair.M : 0u;
+    }
     Fe<SF> s = fe_load<SF>(scalars + gid * 8);
     if (form == BZH_FORM_MONTGOMERY) s = fe_from_mont(s);
     uint32_t l[8];
@@ -118,13 +131,18 @@ __global__ void __launch_bounds__(256) k_msm_digits(const uint32_t* __restrict__
         while (bits >= c && w < nwin - 1) {
             int d = (int)((uint32_t)acc & mask) - (int)H;
             uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
+            if (mag) mag += cls_off;
             out[(size_t)w * n] = (uint16_t)(mag | (d < 0 ? 0x8000u : 0u));
             acc >>= c;
             bits -= c;
             w++;
         }
     }
-    out[(size_t)w * n] = (uint16_t)((uint32_t)acc & 0x7fffu);  // top window, unsigned
+    {
+        uint32_t mag = (uint32_t)acc & 0x7fffu;  // top window, unsigned
+        if (mag) mag += cls_off;
+        out[(size_t)w * n] = (uint16_t)mag;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -215,7 +233,7 @@ __global__ void __launch_bounds__(T) k_msm_accumulate(const uint32_t* __restrict
                                                                   const uint16_t* __restrict__ digits, size_t n, int nwin,
                                                                   int M, size_t chunk, uint4* __restrict__ buckets,
                                                                   uint4* __restrict__ partials, size_t row_len,
-                                                                  size_t row_stride) {
+                                                                  size_t row_stride, size_t dup_from) {
     using P = typename C::Base;
     extern __shared__ __align__(16) uint32_t lds[];
     uint32_t* cnt = lds;  // index m in [0, M]; cnt[0] stays 0
@@ -311,7 +329,9 @@ __global__ void __launch_bounds__(T) k_msm_accumulate(const uint32_t* __restrict
             size_t pidx = (size_t)(e & 0x7fffu);
             if (remap) {
                 const size_t g = c0 + pidx, row = g / row_len;
-                pidx = row * row_stride + (g - row * row_len) - c0;
+                size_t col = g - row * row_len;
+                if (dup_from && col >= dup_from) col -= 2;  // the last two table columns appear twice (paired vectors)
+                pidx = row * row_stride + col - c0;
             }
             return pidx;
         };
@@ -412,19 +432,22 @@ __device__ __forceinline__ Xyzz<P> block_tree_sum(Xyzz<P> v, uint4* buf, int T) 
 }
 
 template <class C>
-__global__ void __launch_bounds__(256) k_msm_reduce(const uint4* __restrict__ buckets, int M, uint4* __restrict__ winsums) {
+__global__ void __launch_bounds__(256) k_msm_reduce(const uint4* __restrict__ buckets, int M, int nclass, size_t spv,
+                                                      uint4* __restrict__ winsums) {
     using P = typename C::Base;
     extern __shared__ __align__(16) uint32_t lds[];
     uint4* bufA = reinterpret_cast<uint4*>(lds);
     const int T = blockDim.x, tid = threadIdx.x;
     uint4* bufB = bufA + (size_t)T * 8;
-    const size_t segi = blockIdx.x;
-    const uint4* seg = buckets + segi * (size_t)M * 8;
+    // accumulate segment blockIdx.x / nclass holds nclass bucket sets side by side in each plane
+    const size_t aseg = blockIdx.x / nclass, cls = blockIdx.x - aseg * nclass, MS = (size_t)M * nclass;
+    const size_t segi = ((aseg / spv) * nclass + cls) * spv + aseg % spv;  // result vectors are class-major
+    const uint4* seg = buckets + aseg * MS * 8 + cls * M;
     const int L = M / T;  // host guarantees T <= M, both powers of two
 
     Xyzz<P> S = xyzz_identity<P>(), W = xyzz_identity<P>();
     for (int k = L; k >= 1; k--) {
-        Xyzz<P> bkt = planes_get<P>(seg, (size_t)M, (size_t)(tid * L + k - 1));
+        Xyzz<P> bkt = planes_get<P>(seg, MS, (size_t)(tid * L + k - 1));
         xyzz_add(S, bkt);
         xyzz_add(W, S);
     }
@@ -472,16 +495,18 @@ __device__ __forceinline__ Xyzz<P> xyzz_shfl_down(const Xyzz<P>& v, int d) {
 }
 
 template <class C>
-__global__ void __launch_bounds__(64) k_msm_reduce_wave(const uint4* __restrict__ buckets, int M, uint4* __restrict__ winsums) {
+__global__ void __launch_bounds__(64) k_msm_reduce_wave(const uint4* __restrict__ buckets, int M, int nclass, size_t spv,
+                                                         uint4* __restrict__ winsums) {
     using P = typename C::Base;
     const int lane = threadIdx.x;
-    const size_t segi = blockIdx.x;
-    const uint4* seg = buckets + segi * (size_t)M * 8;
+    const size_t aseg = blockIdx.x / nclass, cls = blockIdx.x - aseg * nclass, MS = (size_t)M * nclass;
+    const size_t segi = ((aseg / spv) * nclass + cls) * spv + aseg % spv;
+    const uint4* seg = buckets + aseg * MS * 8 + cls * M;
     const int L = M >> 6;  // host guarantees M >= 64, a power of two
 
     Xyzz<P> S = xyzz_identity<P>(), W = xyzz_identity<P>();
     for (int k = L; k >= 1; k--) {
-        Xyzz<P> bkt = planes_get<P>(seg, (size_t)M, (size_t)(lane * L + k - 1));
+        Xyzz<P> bkt = planes_get<P>(seg, MS, (size_t)(lane * L + k - 1));
         xyzz_add(S, bkt);
         xyzz_add(W, S);
     }
@@ -583,7 +608,11 @@ __global__ void __launch_bounds__(256) k_expand_bases(uint32_t* __restrict__ tab
 // ---------------------------------------------------------------------------
 template <class C, class SF>
 static int msm_run_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_scalars, size_t n, size_t batch, int form,
-                     uint32_t* d_out) {
+                     uint32_t* d_out, const MsmPair* pair_in) {
+    // paired vectors: `n` counts the dense entries (n_pair + 4, the two tail columns of the table addressed twice);
+    // every input vector yields two results (class 0, class 1), d_out holds 2 * batch points
+    const int nclass = pair_in ? 2 : 1;
+    if (pair_in && (!bases->pre_c || n != pair_in->n_pair + 4 || n - 2 > bases->n)) return BZH_E_ARG;
     if (n == 0) {
         BZH_HIP_TRY(ctx, hipMemsetAsync(d_out, 0, batch * 96, ctx->stream));
         return BZH_OK;
@@ -621,8 +650,15 @@ static int msm_run_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_sca
         row_stride = bases->n;
     }
     acc_nwin = pre ? 1 : p.nwin;
+    MsmPair pair{0, 0, 0};
+    if (pair_in) {
+        if (2 * (size_t)p.M > 0x7fffu) return BZH_E_ARG;
+        pair = *pair_in;
+        pair.M = (uint32_t)p.M;
+    }
+    const int M_acc = p.M * nclass;  // buckets per accumulate segment
     // slice the batch so the bucket workspace stays bounded
-    const size_t seg_bytes = (size_t)p.M * 128;
+    const size_t seg_bytes = (size_t)M_acc * 128;
     const size_t segs_per_vec = (size_t)acc_nwin * p.nchunks;
     const size_t budget = (size_t)2 << 30;
     size_t slice = budget / (segs_per_vec * (seg_bytes + (size_t)2 * 1024 * 128));
@@ -648,9 +684,9 @@ static int msm_run_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_sca
     if ((rc = ws_ensure(ctx, 0, slice * (size_t)p.nwin * n * sizeof(uint16_t), &d_digits))) return rc;
     if ((rc = ws_ensure(ctx, 1, slice * segs_per_vec * (seg_bytes + part_bytes), &d_buckets))) return rc;
     uint4* d_partials = (uint4*)((char*)d_buckets + slice * segs_per_vec * seg_bytes);
-    if ((rc = ws_ensure(ctx, 2, slice * segs_per_vec * 128, &d_winsums))) return rc;
+    if ((rc = ws_ensure(ctx, 2, slice * segs_per_vec * nclass * 128, &d_winsums))) return rc;
 
-    const size_t acc_lds = ((size_t)p.M + 2 + 32 + acc_threads) * 4 + p.chunk * 2 + 16;
+    const size_t acc_lds = ((size_t)M_acc + 2 + 32 + acc_threads) * 4 + p.chunk * 2 + 16;
     int red_threads = p.M < 256 ? p.M : 256;
     const size_t red_lds = (size_t)red_threads * 128 * 2;
     static bool attr_set[3] = {false, false, false};
@@ -672,7 +708,7 @@ static int msm_run_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_sca
         {
             ScopedTimer t(ctx, BZH_T_MSM_DIGITS);
             hipLaunchKernelGGL((k_msm_digits<SF>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
-                               d_scalars + b0 * n * 8, n, total, form, p.c, p.nwin, off, (uint16_t*)d_digits);
+                               d_scalars + b0 * n * 8, n, total, form, p.c, p.nwin, off, (uint16_t*)d_digits, pair);
         }
         {
             ScopedTimer t(ctx, BZH_T_MSM_ACCUMULATE);
@@ -680,8 +716,8 @@ static int msm_run_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_sca
             const dim3 grid((unsigned)p.nchunks, (unsigned)acc_nwin, (unsigned)nb);
 #define BZH_LAUNCH_ACC(TT)                                                                                              \
     hipLaunchKernelGGL((k_msm_accumulate<C, TT>), grid, dim3(TT), acc_lds, ctx->stream, bases->d_xy,                      \
-                       (const uint16_t*)d_digits, n_eff, acc_nwin, p.M, p.chunk, (uint4*)d_buckets, d_partials, row_len, \
-                       row_stride)
+                       (const uint16_t*)d_digits, n_eff, acc_nwin, M_acc, p.chunk, (uint4*)d_buckets, d_partials, row_len, \
+                       row_stride, pair_in ? n - 2 : (size_t)0)
             if (acc_threads == 1024) BZH_LAUNCH_ACC(1024);
             else if (acc_threads == 512) BZH_LAUNCH_ACC(512);
             else BZH_LAUNCH_ACC(256);
@@ -690,18 +726,19 @@ static int msm_run_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_sca
         const size_t nseg = nb * segs_per_vec;
         {
             ScopedTimer t(ctx, BZH_T_MSM_REDUCE);
-            if (p.M >= 64 && nseg >= 256) {
-                hipLaunchKernelGGL((k_msm_reduce_wave<C>), dim3((unsigned)nseg), dim3(64), 0, ctx->stream,
-                                   (const uint4*)d_buckets, p.M, (uint4*)d_winsums);
+            if (p.M >= 64 && nseg * nclass >= 256) {
+                hipLaunchKernelGGL((k_msm_reduce_wave<C>), dim3((unsigned)(nseg * nclass)), dim3(64), 0, ctx->stream,
+                                   (const uint4*)d_buckets, p.M, nclass, segs_per_vec, (uint4*)d_winsums);
             } else {
-                hipLaunchKernelGGL((k_msm_reduce<C>), dim3((unsigned)nseg), dim3(red_threads), red_lds, ctx->stream,
-                                   (const uint4*)d_buckets, p.M, (uint4*)d_winsums);
+                hipLaunchKernelGGL((k_msm_reduce<C>), dim3((unsigned)(nseg * nclass)), dim3(red_threads), red_lds, ctx->stream,
+                                   (const uint4*)d_buckets, p.M, nclass, segs_per_vec, (uint4*)d_winsums);
             }
         }
         {
             ScopedTimer t(ctx, BZH_T_MSM_FINALIZE);
-            hipLaunchKernelGGL((k_msm_finalize<C>), dim3((unsigned)nb), dim3(64), 0, ctx->stream,
-                               (const uint4*)d_winsums, nseg, acc_nwin, p.nchunks, pre ? 0 : p.c, form, d_out + b0 * 24);
+            hipLaunchKernelGGL((k_msm_finalize<C>), dim3((unsigned)(nb * nclass)), dim3(64), 0, ctx->stream,
+                               (const uint4*)d_winsums, nseg * nclass, acc_nwin, p.nchunks, pre ? 0 : p.c, form,
+                               d_out + b0 * nclass * 24);
         }
         BZH_HIP_TRY(ctx, hipGetLastError());
     }
@@ -712,11 +749,31 @@ int msm_run(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_scalars, siz
             uint32_t* d_out_xyz) {
     switch (bases->curve) {
         case BZH_CURVE_VESTA:
-            return msm_run_t<VestaCurve, FpParams>(ctx, bases, d_scalars, n, batch, form, d_out_xyz);
+            return msm_run_t<VestaCurve, FpParams>(ctx, bases, d_scalars, n, batch, form, d_out_xyz, nullptr);
         case BZH_CURVE_PALLAS:
-            return msm_run_t<PallasCurve, FqParams>(ctx, bases, d_scalars, n, batch, form, d_out_xyz);
+            return msm_run_t<PallasCurve, FqParams>(ctx, bases, d_scalars, n, batch, form, d_out_xyz, nullptr);
         case BZH_CURVE_BN254:
-            return msm_run_t<Bn254Curve, BnFrParams>(ctx, bases, d_scalars, n, batch, form, d_out_xyz);
+            return msm_run_t<Bn254Curve, BnFrParams>(ctx, bases, d_scalars, n, batch, form, d_out_xyz, nullptr);
+    }
+    return BZH_E_ARG;
+}
+
+// Paired MSM against a window table of n_pair + 2 points: each of the `batch` dense vectors of n_pair + 4 scalars
+//   [ v_0 .. v_(n_pair-1) | a_0 a_1 | b_0 b_1 ]
+// yields TWO sums: class 0 takes v_i with bit (log_m - 1) of i clear plus a_0, a_1 on the last two table points,
+// class 1 the v_i with that bit set plus b_0, b_1 on the same two points (the L_j / R_j of one IPA round, whose
+// scalar vectors have disjoint supports).  d_out_xyz: 2 * batch points, [class 0, class 1] per vector.
+int msm_run_paired(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_scalars, size_t n_pair, unsigned log_m, size_t batch,
+                   int form, uint32_t* d_out_xyz) {
+    if (!bases->pre_c || bases->n != n_pair + 2 || log_m < 1) return BZH_E_ARG;
+    const MsmPair pair{log_m, n_pair, 0};
+    switch (bases->curve) {
+        case BZH_CURVE_VESTA:
+            return msm_run_t<VestaCurve, FpParams>(ctx, bases, d_scalars, n_pair + 4, batch, form, d_out_xyz, &pair);
+        case BZH_CURVE_PALLAS:
+            return msm_run_t<PallasCurve, FqParams>(ctx, bases, d_scalars, n_pair + 4, batch, form, d_out_xyz, &pair);
+        case BZH_CURVE_BN254:
+            return msm_run_t<Bn254Curve, BnFrParams>(ctx, bases, d_scalars, n_pair + 4, batch, form, d_out_xyz, &pair);
     }
     return BZH_E_ARG;
 }
