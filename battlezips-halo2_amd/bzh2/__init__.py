@@ -434,6 +434,7 @@ class Transcript:
 
 # ---- IPA opening --------------------------------------------------------------------------------
 EXPORTS += ["bzh_ipa_open", "bzh_ipa_open_batch", "bzh_ipa_verify"]
+EXPORTS += ["bzh_pk_create", "bzh_pk_free", "bzh_pk_info", "bzh_prove_batch"]
 E_VERIFY = -6
 
 

@@ -1,0 +1,80 @@
+"""Binding of the native whole-proof entry points (include/bzh2.h: bzh_pk_create / bzh_prove_batch).
+
+The reference-side call this stands behind is halo2_proofs::plonk::{keygen_pk, create_proof} (benches/shot.rs:58-71,
+benches/board.rs:51-71); the circuit crosses the boundary as data (bzh2.prover.serialize_circuit)."""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import CURVE_SCALAR_FIELD, FORM_CANONICAL, FORM_MONTGOMERY, MEM_DEVICE, MEM_HOST, Bases, Context, int_to_limbs, load
+from .prover import MODULI, Circuit, serialize_circuit
+
+_VP = ctypes.c_void_p
+
+
+def _bind():
+    L = load()
+    if getattr(L, "_bzh_native_bound", False):
+        return L
+    L.bzh_pk_create.argtypes = [_VP, _VP, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(_VP)]
+    L.bzh_pk_free.argtypes = [_VP, _VP]
+    L.bzh_pk_info.argtypes = [_VP, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_uint32),
+                              ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]
+    L.bzh_prove_batch.argtypes = [_VP, _VP, ctypes.c_size_t, _VP, ctypes.c_int, ctypes.c_int, _VP, ctypes.c_size_t, ctypes.c_char_p,
+                                  ctypes.c_size_t, _VP, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+    L._bzh_native_bound = True
+    return L
+
+
+class NativeProvingKey:
+    """keygen_pk on the device.  g: the n SRS points, w / u: Params.w / Params.u (affine canonical int pairs)."""
+
+    def __init__(self, ctx: Context, circuit: Circuit, curve: int, g, w, u, vk_repr: int = 0x1234, window_bits: int = 0):
+        self.ctx, self.c, self.curve = ctx, circuit, curve
+        self.field = CURVE_SCALAR_FIELD[curve]
+        self.p = MODULI[self.field]
+        tbl = np.stack([np.concatenate([int_to_limbs(pt[0]), int_to_limbs(pt[1])]) for pt in list(g) + [u, w]])
+        self.bases: Bases = ctx.upload_bases(curve, tbl).precompute(window_bits)
+        blob = serialize_circuit(circuit, self.p, vk_repr)
+        L = _bind()
+        h = _VP()
+        ctx._check(L.bzh_pk_create(ctx.handle, self.bases.handle, blob, len(blob), ctypes.byref(h)), "bzh_pk_create")
+        self.handle = h
+        rb, mp = ctypes.c_size_t(), ctypes.c_size_t()
+        na, nr, ur = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32()
+        ctx._check(L.bzh_pk_info(h, ctypes.byref(rb), ctypes.byref(mp), ctypes.byref(na), ctypes.byref(nr), ctypes.byref(ur)), "bzh_pk_info")
+        self.rng_bytes, self.max_proof_bytes, self.num_advice, self.n, self.usable_rows = rb.value, mp.value, na.value, nr.value, ur.value
+
+    def close(self):
+        if self.handle is not None:
+            _bind().bzh_pk_free(self.ctx.handle, self.handle)
+            self.handle = None
+            self.bases.free()
+
+    def prove_batch(self, advice, instances, rng_list, device_ptr: int | None = None) -> list:
+        """advice: (B, num_advice, n, 4) uint64 canonical host array (or, with device_ptr, a device pointer to Montgomery
+        limbs of that shape); instances: B lists of instance columns (equal lengths); rng_list: B byte strings."""
+        L = _bind()
+        B = len(rng_list)
+        stride = len(rng_list[0])
+        assert all(len(r) == stride for r in rng_list) and stride >= self.rng_bytes, (stride, self.rng_bytes)
+        rows = max([len(col) for cols in instances for col in cols] + [0])
+        inst = np.zeros((B, max(len(instances[0]), 1), max(rows, 1), 4), dtype=np.uint64)
+        for b, cols in enumerate(instances):
+            for i, col in enumerate(cols):
+                for r, v in enumerate(col):
+                    inst[b, i, r] = int_to_limbs(int(v) % self.p)
+        proofs = np.zeros((B, self.max_proof_bytes), dtype=np.uint8)
+        lens = (ctypes.c_size_t * B)()
+        if device_ptr is not None:
+            adv_p, form, mem = _VP(device_ptr), FORM_MONTGOMERY, MEM_DEVICE
+        else:
+            a = np.ascontiguousarray(advice, dtype=np.uint64)
+            assert a.shape == (B, self.num_advice, self.n, 4), a.shape
+            adv_p, form, mem = _VP(a.ctypes.data), FORM_CANONICAL, MEM_HOST
+        rc = L.bzh_prove_batch(self.ctx.handle, self.handle, B, adv_p, form, mem, _VP(inst.ctypes.data), rows, b"".join(rng_list), stride,
+                               _VP(proofs.ctypes.data), self.max_proof_bytes, lens)
+        self.ctx._check(rc, "bzh_prove_batch")
+        return [bytes(proofs[b, :lens[b]]) for b in range(B)]

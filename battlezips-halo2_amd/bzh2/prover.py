@@ -83,6 +83,57 @@ class Circuit:
         self.extended_k = k + max(1, (self.degree - 2).bit_length())
 
 
+_KIND_TAG = {'advice': 0, 'fixed': 1, 'instance': 2}
+
+
+def _ser_expr(e, p, out):
+    t = e[0]
+    if t == 'const':
+        out.append(b"\x00" + (e[1] % p).to_bytes(32, "little"))
+    elif t in _KIND_TAG:
+        out.append(bytes([1 + _KIND_TAG[t]]) + int(e[1]).to_bytes(4, "little") + int(e[2]).to_bytes(4, "little", signed=True))
+    elif t == 'neg':
+        out.append(b"\x04")
+        _ser_expr(e[1], p, out)
+    elif t in ('add', 'mul'):
+        out.append(b"\x05" if t == 'add' else b"\x06")
+        _ser_expr(e[1], p, out)
+        _ser_expr(e[2], p, out)
+    elif t == 'scale':
+        out.append(b"\x07")
+        _ser_expr(e[1], p, out)
+        out.append((e[2] % p).to_bytes(32, "little"))
+    else:
+        raise ValueError("unknown expression tag %r" % (t,))
+
+
+def serialize_circuit(c: "Circuit", p: int, vk_repr: int = 0x1234, min_degree: int | None = None) -> bytes:
+    """The circuit blob of bzh_pk_create (format: csrc/prove.hip)."""
+    u32 = lambda v: int(v).to_bytes(4, "little")
+    out = [b"BZC1", u32(c.k), u32(c.num_advice), u32(c.num_fixed), u32(c.num_instance),
+           u32(c.degree if min_degree is None else min_degree), (vk_repr % p).to_bytes(32, "little")]
+    out.append(u32(len(c.gates)))
+    for g in c.gates:
+        _ser_expr(g, p, out)
+    out.append(u32(len(c.perm_columns)))
+    for kind, idx in c.perm_columns:
+        out.append(bytes([_KIND_TAG[kind]]) + u32(idx))
+    out.append(u32(len(c.lookups)))
+    for ins, tabs in c.lookups:
+        assert len(ins) == len(tabs)
+        out.append(u32(len(ins)))
+        for e in ins + tabs:
+            _ser_expr(e, p, out)
+    out.append(u32(len(c.copies)))
+    for (lc, lr), (rc, rr) in c.copies:
+        out.append(u32(lc) + u32(lr) + u32(rc) + u32(rr))
+    for col in c.fixed:
+        col = list(col)[:c.n]
+        out.append(u32(len(col)))
+        out.append(b"".join((int(v) % p).to_bytes(32, "little") for v in col))
+    return b"".join(out)
+
+
 def _degree(e):
     t = e[0]
     if t == 'const':

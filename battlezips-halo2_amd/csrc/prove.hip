@@ -1,0 +1,1786 @@
+// Whole-proof entry points: bzh_pk_create / bzh_prove_batch (boundary row b:
+// "a coarser seam (whole create_proof) is what batching needs").
+//
+// Native counterpart of halo2_proofs 0.2.0 `plonk::{keygen_pk, create_proof}` (UPSTREAM, un-vendored:
+// Cargo.lock:382-385) as called by the reference at benches/shot.rs:58-71, benches/board.rs:51-71,
+// src/circuits/shot.rs:915-930, src/circuits/board.rs:907-922: one call proves `batch` independent
+// witnesses of one circuit in lockstep -- every MSM, NTT, gate evaluation, scan and IPA round is ONE launch
+// carrying all of them -- with the protocol, message order and randomness draw order per proof of
+// create_proof, so each proof is byte-identical to the single-proof drivers (bzh2/prover_dev.py,
+// oracle/halo2_oracle.py) under the same randomness stream.
+//
+// The circuit arrives as DATA (serialised constraint system + fixed assignment, format below): the reference's
+// own constraint systems include 19 gates of the halo2_gadgets crate that is not on disk.  Host work left:
+// transcripts (Blake2b), the lookup sort, challenges and blinds; everything else runs on the device out of
+// one grow-only arena owned by the proving key.
+//
+// Circuit blob, little-endian:
+//   u32 magic "BZC1" | u32 k | u32 num_advice | u32 num_fixed | u32 num_instance | u32 min_degree | u8[32] vk_repr
+//   u32 ngates, ngates x expr
+//   u32 nperm, nperm x (u8 kind {0 advice, 1 fixed, 2 instance}, u32 index)
+//   u32 nlookups, per lookup: u32 m, m x expr (inputs), m x expr (table)
+//   u32 ncopies, ncopies x (u32 col_a, u32 row_a, u32 col_b, u32 row_b)        (indices into the permutation columns)
+//   num_fixed x (u32 len, len x u8[32] canonical values)                        (rows past len are zero)
+//   expr := u8 tag, then  0 const: u8[32] | 1 advice / 2 fixed / 3 instance: u32 column, i32 rotation
+//                       | 4 neg: expr | 5 add: expr expr | 6 mul: expr expr | 7 scale: expr, u8[32]
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <thread>
+#include <vector>
+
+#include "ctx.hpp"
+#include "curve.cuh"
+
+namespace bzh {
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------
+// v[b][i] *= s[b * s_stride]   (chain the permutation sets: start from the previous set's hand-over value)
+template <class P>
+__global__ void __launch_bounds__(256) k_scale_rows(uint32_t* __restrict__ v, size_t n, const uint32_t* __restrict__ s,
+                                                      size_t s_stride) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (i >= n) return;
+    uint32_t* e = v + (b * n + i) * 8;
+    fe_store(e, fe_mul(fe_load<P>(e), fe_load<P>(s + b * s_stride * 8)));
+}
+
+// flag |= any word of rows[b][0 .. words) non-zero
+__global__ void __launch_bounds__(256) k_any_nonzero(const uint32_t* __restrict__ p, size_t words, size_t row_stride_words,
+                                                       uint32_t* __restrict__ flag) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (i < words && p[b * row_stride_words + i]) atomicOr(flag, 1u);
+}
+
+// dst[b][j][0..n) = srcs[j] + b * strides[j]   (gather of (polynomial, proof) rows for the batched evaluations)
+__global__ void __launch_bounds__(256) k_gather_rows(uint4* __restrict__ dst, const uint4* const* __restrict__ srcs,
+                                                       const size_t* __restrict__ strides, size_t n, size_t J) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x, j = blockIdx.y, b = blockIdx.z;
+    if (i >= 2 * n) return;
+    dst[((b * J + j) * n) * 2 + i] = srcs[j][b * strides[j] * 2 + i];
+}
+
+// ---------------------------------------------------------------------------
+// host field helpers (portable Fe<P> arithmetic, Montgomery form unless noted)
+// ---------------------------------------------------------------------------
+template <class P>
+static Fe<P> h_load(const uint64_t* p) {
+    Fe<P> v;
+    for (int i = 0; i < 4; i++) {
+        v.l[2 * i] = (uint32_t)p[i];
+        v.l[2 * i + 1] = (uint32_t)(p[i] >> 32);
+    }
+    return v;
+}
+template <class P>
+static void h_store(uint64_t* p, const Fe<P>& v) {
+    for (int i = 0; i < 4; i++) p[i] = (uint64_t)v.l[2 * i] | ((uint64_t)v.l[2 * i + 1] << 32);
+}
+template <class P>
+static Fe<P> h_from_bytes(const uint8_t* b) {  // canonical little-endian -> Montgomery
+    uint64_t l[4];
+    memcpy(l, b, 32);
+    return fe_to_mont(h_load<P>(l));
+}
+template <class P>
+static Fe<P> h_pow_u64(Fe<P> base, uint64_t e) {
+    Fe<P> acc = fe_one<P>();
+    for (; e; e >>= 1) {
+        if (e & 1) acc = fe_mul(acc, base);
+        base = fe_sqr(base);
+    }
+    return acc;
+}
+// Field::random: 64 bytes little-endian mod p (Montgomery out)
+template <class P>
+static Fe<P> h_from_u512(const uint8_t* b) {
+    uint64_t lo[4], hi[4];
+    memcpy(lo, b, 32);
+    memcpy(hi, b + 32, 32);
+    const Fe<P> r2 = fe_r2<P>();
+    return fe_add(fe_mul(h_load<P>(lo), r2), fe_mul(fe_mul(h_load<P>(hi), r2), r2));
+}
+
+template <class P>
+struct FieldMeta;
+template <>
+struct FieldMeta<FpParams> {
+    static constexpr unsigned S = 32;
+    static constexpr uint32_t gen = 5;
+    static constexpr int id = BZH_FIELD_FP;
+};
+template <>
+struct FieldMeta<FqParams> {
+    static constexpr unsigned S = 32;
+    static constexpr uint32_t gen = 5;
+    static constexpr int id = BZH_FIELD_FQ;
+};
+
+// ---------------------------------------------------------------------------
+// circuit expressions (as serialised) and evaluator expressions (over a column registry)
+// ---------------------------------------------------------------------------
+enum { CX_CONST = 0, CX_ADVICE = 1, CX_FIXED = 2, CX_INSTANCE = 3, CX_NEG = 4, CX_ADD = 5, CX_MUL = 6, CX_SCALE = 7 };
+struct CNode {
+    uint8_t tag;
+    uint32_t col = 0;
+    int32_t rot = 0;
+    uint32_t val[8] = {0};  // Montgomery
+    int a = -1, b = -1;
+};
+
+enum { EX_CONST, EX_SYMBOL, EX_QUERY, EX_NEG, EX_ADD, EX_MUL, EX_SCALE };
+struct ENode {
+    uint8_t tag;
+    int32_t col = 0, rot = 0;  // EX_QUERY: registry index, rotation; EX_SYMBOL: col = symbol id
+    uint32_t val[8] = {0};
+    int a = -1, b = -1;
+};
+// challenge symbols bound per proof
+enum { SY_THETA, SY_BETA, SY_GAMMA, SY_Y, SY_XN, SY_X1, SY_X2, SY_X4, SY_BD0 /* + permutation column index */ };
+
+struct ConstEnt {
+    int sym = -1;  // >= 0: symbol id, else literal
+    uint32_t val[8] = {0};
+};
+struct Program {
+    std::vector<bzh_expr_op> ops;
+    std::vector<ConstEnt> consts;
+    int result_slot = 0;
+};
+
+struct EPool {
+    std::vector<ENode> n;
+    int push(const ENode& e) {
+        n.push_back(e);
+        return (int)n.size() - 1;
+    }
+    template <class F>
+    int cnst(const F& v) {
+        ENode e;
+        e.tag = EX_CONST;
+        memcpy(e.val, v.l, 32);
+        return push(e);
+    }
+    int sym(int id) {
+        ENode e;
+        e.tag = EX_SYMBOL;
+        e.col = id;
+        return push(e);
+    }
+    int query(int col, int rot = 0) {
+        ENode e;
+        e.tag = EX_QUERY;
+        e.col = col;
+        e.rot = rot;
+        return push(e);
+    }
+    int un(uint8_t tag, int a) {
+        ENode e;
+        e.tag = tag;
+        e.a = a;
+        return push(e);
+    }
+    int bin(uint8_t tag, int a, int b) {
+        ENode e;
+        e.tag = tag;
+        e.a = a;
+        e.b = b;
+        return push(e);
+    }
+    int neg(int a) { return un(EX_NEG, a); }
+    int add(int a, int b) { return bin(EX_ADD, a, b); }
+    int sub(int a, int b) { return add(a, neg(b)); }
+    int mul(int a, int b) { return bin(EX_MUL, a, b); }
+    int horner(const std::vector<int>& terms, int ch) {  // ((t0 * ch + t1) * ch + t2) ...
+        int acc = terms[0];
+        for (size_t i = 1; i < terms.size(); i++) acc = add(mul(acc, ch), terms[i]);
+        return acc;
+    }
+};
+
+// Sethi-Ullman ordered emission into at most BZH_EXPR_MAX_SLOTS live intermediates (bzh2/expr.py is the
+// Python twin); leaves are free operands
+struct Compiler {
+    const EPool& pool;
+    Program prog;
+    std::vector<int> free_slots, depth;
+    bool overflow = false;
+    explicit Compiler(const EPool& p) : pool(p), depth(p.n.size(), -1) {
+        for (int s = BZH_EXPR_MAX_SLOTS - 1; s >= 0; s--) free_slots.push_back(s);
+    }
+    int depth_of(int i) {
+        if (depth[i] >= 0) return depth[i];
+        const ENode& e = pool.n[i];
+        int d;
+        if (e.tag == EX_CONST || e.tag == EX_SYMBOL || e.tag == EX_QUERY) d = 0;
+        else if (e.tag == EX_NEG || e.tag == EX_SCALE) d = std::max(1, depth_of(e.a));
+        else {
+            const int da = depth_of(e.a), db = depth_of(e.b);
+            d = da != db ? std::max(da, db) : da + 1;
+        }
+        return depth[i] = d;
+    }
+    int alloc() {
+        if (free_slots.empty()) {
+            overflow = true;
+            return 0;
+        }
+        const int s = free_slots.back();
+        free_slots.pop_back();
+        return s;
+    }
+    int const_index(int sym, const uint32_t* val) {
+        for (size_t i = 0; i < prog.consts.size(); i++) {
+            const ConstEnt& c = prog.consts[i];
+            if (sym >= 0 ? c.sym == sym : (c.sym < 0 && !memcmp(c.val, val, 32))) return (int)i;
+        }
+        ConstEnt c;
+        c.sym = sym;
+        if (sym < 0) memcpy(c.val, val, 32);
+        prog.consts.push_back(c);
+        return (int)prog.consts.size() - 1;
+    }
+    struct Opnd {
+        int kind, idx, rot, release;
+    };
+    Opnd operand(int i) {
+        const ENode& e = pool.n[i];
+        if (e.tag == EX_CONST) return {BZH_EXPR_CONST, const_index(-1, e.val), 0, -1};
+        if (e.tag == EX_SYMBOL) return {BZH_EXPR_CONST, const_index(e.col, nullptr), 0, -1};
+        if (e.tag == EX_QUERY) return {BZH_EXPR_COLUMN, e.col, e.rot, -1};
+        const int s = emit(i);
+        return {BZH_EXPR_SLOT, s, 0, s};
+    }
+    void push(int op, int dst, const Opnd& a, const Opnd& b) {
+        bzh_expr_op o;
+        o.op = (uint8_t)op;
+        o.dst = (uint8_t)dst;
+        o.a_kind = (uint8_t)a.kind;
+        o.b_kind = (uint8_t)b.kind;
+        o.a_idx = a.idx;
+        o.b_idx = b.idx;
+        o.a_rot = a.rot;
+        o.b_rot = b.rot;
+        prog.ops.push_back(o);
+    }
+    int emit(int i) {
+        const ENode& e = pool.n[i];
+        const Opnd none{BZH_EXPR_SLOT, 0, 0, -1};
+        if (e.tag == EX_CONST || e.tag == EX_SYMBOL || e.tag == EX_QUERY) {
+            const Opnd a = operand(i);
+            const int d = alloc();
+            push(BZH_EXPR_COPY, d, a, none);
+            return d;
+        }
+        if (e.tag == EX_NEG) {
+            const Opnd a = operand(e.a);
+            const int d = a.release >= 0 ? a.release : alloc();
+            push(BZH_EXPR_NEG, d, a, none);
+            return d;
+        }
+        if (e.tag == EX_SCALE) {
+            const Opnd a = operand(e.a);
+            const int d = a.release >= 0 ? a.release : alloc();
+            push(BZH_EXPR_MUL, d, a, Opnd{BZH_EXPR_CONST, const_index(-1, e.val), 0, -1});
+            return d;
+        }
+        // the deeper child first, so that the shallower one never needs more slots than are left
+        Opnd a, b;
+        if (depth_of(e.b) > depth_of(e.a)) {
+            b = operand(e.b);
+            a = operand(e.a);
+        } else {
+            a = operand(e.a);
+            b = operand(e.b);
+        }
+        const int d = a.release >= 0 ? a.release : (b.release >= 0 ? b.release : alloc());
+        push(e.tag == EX_ADD ? BZH_EXPR_ADD : BZH_EXPR_MUL, d, a, b);
+        if (a.release >= 0 && a.release != d) free_slots.push_back(a.release);
+        if (b.release >= 0 && b.release != d) free_slots.push_back(b.release);
+        return d;
+    }
+};
+
+// column registry of one batched evaluation: (device pointer, elements between consecutive proofs; 0 = shared)
+struct Cols {
+    std::vector<const uint32_t*> ptr;
+    std::vector<size_t> stride;
+    std::map<uint64_t, int> index;
+    int add(uint64_t key, const uint32_t* p, size_t s) {
+        auto it = index.find(key);
+        if (it != index.end()) return it->second;
+        const int i = (int)ptr.size();
+        index[key] = i;
+        ptr.push_back(p);
+        stride.push_back(s);
+        return i;
+    }
+    int at(uint64_t key) const { return index.at(key); }
+};
+// registry keys
+enum { K_ADV = 1, K_FIX, K_INST, K_SIGMA, K_IDENT, K_PZ, K_LA, K_LS, K_LZ, K_MISC };
+enum { M_L0, M_LLAST, M_LBLIND, M_X, M_TINV, M_AC, M_SC, M_A, M_S, M_ACC, M_Q, M_R, M_F, M_H0 /* + i */ };
+static inline uint64_t key(int kind, uint64_t i) { return ((uint64_t)kind << 32) | i; }
+
+// device arena: grow-only blocks, reset at the start of every call
+struct Arena {
+    struct Block {
+        char* p;
+        size_t size, used;
+    };
+    std::vector<Block> blocks;
+    int device = 0;
+    void reset() {
+        for (auto& b : blocks) b.used = 0;
+    }
+    void release() {
+        for (auto& b : blocks) (void)hipFree(b.p);
+        blocks.clear();
+    }
+    void* alloc(size_t bytes) {
+        bytes = (bytes + 255) & ~(size_t)255;
+        for (auto& b : blocks)
+            if (b.size - b.used >= bytes) {
+                void* r = b.p + b.used;
+                b.used += bytes;
+                return r;
+            }
+        Block nb;
+        nb.size = std::max(bytes, (size_t)256 << 20);
+        if (hipMalloc((void**)&nb.p, nb.size) != hipSuccess) return nullptr;
+        nb.used = bytes;
+        blocks.push_back(nb);
+        return nb.p;
+    }
+};
+
+struct Reader {
+    const uint8_t* p;
+    const uint8_t* end;
+    bool ok = true;
+    uint32_t u32() {
+        if (end - p < 4) {
+            ok = false;
+            return 0;
+        }
+        uint32_t v;
+        memcpy(&v, p, 4);
+        p += 4;
+        return v;
+    }
+    uint8_t u8() {
+        if (end - p < 1) {
+            ok = false;
+            return 0;
+        }
+        return *p++;
+    }
+    const uint8_t* bytes(size_t n) {
+        if ((size_t)(end - p) < n) {
+            ok = false;
+            return nullptr;
+        }
+        const uint8_t* r = p;
+        p += n;
+        return r;
+    }
+};
+
+}  // namespace
+
+}  // namespace bzh
+
+// ---------------------------------------------------------------------------
+// the proving key
+// ---------------------------------------------------------------------------
+struct bzh_pk {
+    int curve = 0, field = 0, device = 0;
+    unsigned k = 0, ek = 0;
+    size_t n = 0, en = 0, ext = 0;
+    int na = 0, nf = 0, ni = 0, degree = 0, bf = 0, chunk_len = 0, nsets = 0, nl = 0, npieces = 0;
+    size_t usable = 0;
+    uint64_t vk_repr[4] = {0};
+    const bzh_bases* srs = nullptr;
+    std::vector<bzh::CNode> cx;
+    std::vector<int> gates;
+    std::vector<std::pair<int, int>> perm_columns;  // (kind tag CX_*, index)
+    std::vector<std::pair<std::vector<int>, std::vector<int>>> lookups;
+    std::vector<std::pair<int, int>> advice_queries, fixed_queries, instance_queries;
+    uint64_t omega[4], eomega[4], zeta[4];  // Montgomery limbs for ntt_run
+    uint32_t delta[8];                      // Montgomery
+    // device, one allocation
+    void* dev = nullptr;
+    uint32_t *fixed = nullptr, *fixed_polys = nullptr, *fixed_cosets = nullptr, *sigma = nullptr, *ident = nullptr, *sigma_polys = nullptr,
+             *sigma_cosets = nullptr, *l0 = nullptr, *l_last = nullptr, *l_blind = nullptr, *x_col = nullptr, *tinv_col = nullptr;
+    std::map<uint64_t, bzh::Program> progs;
+    // multiopen structure: rotation sets and the commitments grouped under each
+    std::vector<std::vector<int>> rot_sets;
+    std::vector<std::vector<uint64_t>> groups;
+    bzh::Arena arena;
+    size_t rng_bytes = 0;
+};
+
+namespace bzh {
+namespace {
+
+static int cx_degree(const bzh_pk& pk, int i) {
+    const CNode& e = pk.cx[i];
+    switch (e.tag) {
+        case CX_CONST: return 0;
+        case CX_ADVICE:
+        case CX_FIXED:
+        case CX_INSTANCE: return 1;
+        case CX_NEG:
+        case CX_SCALE: return cx_degree(pk, e.a);
+        case CX_ADD: return std::max(cx_degree(pk, e.a), cx_degree(pk, e.b));
+        default: return cx_degree(pk, e.a) + cx_degree(pk, e.b);
+    }
+}
+struct Query3 {
+    int tag, col, rot;
+    bool operator==(const Query3& o) const { return tag == o.tag && col == o.col && rot == o.rot; }
+};
+static void cx_queries(const bzh_pk& pk, int i, std::vector<Query3>& out) {
+    const CNode& e = pk.cx[i];
+    if (e.tag >= CX_ADVICE && e.tag <= CX_INSTANCE) {
+        const Query3 q{e.tag, (int)e.col, e.rot};
+        if (std::find(out.begin(), out.end(), q) == out.end()) out.push_back(q);
+    } else if (e.tag == CX_NEG || e.tag == CX_SCALE) {
+        cx_queries(pk, e.a, out);
+    } else if (e.tag == CX_ADD || e.tag == CX_MUL) {
+        cx_queries(pk, e.a, out);
+        cx_queries(pk, e.b, out);
+    }
+}
+
+template <class SF>
+static int parse_expr(Reader& r, bzh_pk& pk, int depth = 0) {
+    if (depth > 4096) {
+        r.ok = false;
+        return -1;
+    }
+    CNode nd;
+    nd.tag = r.u8();
+    if (!r.ok) return -1;
+    switch (nd.tag) {
+        case CX_CONST: {
+            const uint8_t* b = r.bytes(32);
+            if (!b) return -1;
+            const Fe<SF> v = h_from_bytes<SF>(b);
+            memcpy(nd.val, v.l, 32);
+            break;
+        }
+        case CX_ADVICE:
+        case CX_FIXED:
+        case CX_INSTANCE:
+            nd.col = r.u32();
+            nd.rot = (int32_t)r.u32();
+            if ((nd.tag == CX_ADVICE && nd.col >= (uint32_t)pk.na) || (nd.tag == CX_FIXED && nd.col >= (uint32_t)pk.nf) ||
+                (nd.tag == CX_INSTANCE && nd.col >= (uint32_t)pk.ni))
+                r.ok = false;
+            break;
+        case CX_NEG: nd.a = parse_expr<SF>(r, pk, depth + 1); break;
+        case CX_ADD:
+        case CX_MUL:
+            nd.a = parse_expr<SF>(r, pk, depth + 1);
+            nd.b = parse_expr<SF>(r, pk, depth + 1);
+            break;
+        case CX_SCALE: {
+            nd.a = parse_expr<SF>(r, pk, depth + 1);
+            const uint8_t* b = r.bytes(32);
+            if (!b) return -1;
+            const Fe<SF> v = h_from_bytes<SF>(b);
+            memcpy(nd.val, v.l, 32);
+            break;
+        }
+        default: r.ok = false;
+    }
+    if (!r.ok) return -1;
+    pk.cx.push_back(nd);
+    return (int)pk.cx.size() - 1;
+}
+
+// circuit expression -> evaluator expression over `reg` (columns looked up by (kind, index))
+static int lower(const bzh_pk& pk, int i, EPool& ep, const Cols& reg, int rot_scale) {
+    const CNode& e = pk.cx[i];
+    switch (e.tag) {
+        case CX_CONST: {
+            ENode nd;
+            nd.tag = EX_CONST;
+            memcpy(nd.val, e.val, 32);
+            return ep.push(nd);
+        }
+        case CX_ADVICE: return ep.query(reg.at(key(K_ADV, e.col)), e.rot * rot_scale);
+        case CX_FIXED: return ep.query(reg.at(key(K_FIX, e.col)), e.rot * rot_scale);
+        case CX_INSTANCE: return ep.query(reg.at(key(K_INST, e.col)), e.rot * rot_scale);
+        case CX_NEG: return ep.neg(lower(pk, e.a, ep, reg, rot_scale));
+        case CX_SCALE: {
+            ENode nd;
+            nd.tag = EX_SCALE;
+            nd.a = lower(pk, e.a, ep, reg, rot_scale);
+            memcpy(nd.val, e.val, 32);
+            return ep.push(nd);
+        }
+        case CX_ADD: {
+            const int a = lower(pk, e.a, ep, reg, rot_scale), b = lower(pk, e.b, ep, reg, rot_scale);
+            return ep.add(a, b);
+        }
+        default: {
+            const int a = lower(pk, e.a, ep, reg, rot_scale), b = lower(pk, e.b, ep, reg, rot_scale);
+            return ep.mul(a, b);
+        }
+    }
+}
+
+#define PV_TRY(expr)           \
+    do {                       \
+        int rc__ = (expr);     \
+        if (rc__) return rc__; \
+    } while (0)
+
+template <class C>
+struct CurveScalar;
+template <>
+struct CurveScalar<VestaCurve> {
+    using SF = FpParams;
+};
+template <>
+struct CurveScalar<PallasCurve> {
+    using SF = FqParams;
+};
+
+// ---------------------------------------------------------------------------
+// keygen
+// ---------------------------------------------------------------------------
+template <class C>
+static int pk_create_t(bzh_ctx* ctx, const bzh_bases* srs, const uint8_t* blob, size_t len, bzh_pk** out) {
+    using SF = typename CurveScalar<C>::SF;
+    using FM = FieldMeta<SF>;
+    std::unique_ptr<bzh_pk> pkp(new bzh_pk());
+    bzh_pk& pk = *pkp;
+    Reader r{blob, blob + len};
+    if (r.u32() != 0x31435A42u) return BZH_E_ARG;  // "BZC1"
+    pk.curve = C::id;
+    pk.field = FM::id;
+    pk.device = ctx->device;
+    pk.srs = srs;
+    pk.k = r.u32();
+    pk.na = (int)r.u32();
+    pk.nf = (int)r.u32();
+    pk.ni = (int)r.u32();
+    const int min_degree = (int)r.u32();
+    const uint8_t* vk = r.bytes(32);
+    if (!r.ok || pk.k < 1 || pk.k > 24 || pk.na > 4096 || pk.nf > 4096 || pk.ni > 4096) return BZH_E_ARG;
+    memcpy(pk.vk_repr, vk, 32);
+    pk.n = (size_t)1 << pk.k;
+    if (srs->n != pk.n + 2 || srs->curve != C::id) return BZH_E_ARG;
+    const uint32_t ngates = r.u32();
+    for (uint32_t g = 0; g < ngates && r.ok; g++) pk.gates.push_back(parse_expr<SF>(r, pk));
+    const uint32_t nperm = r.u32();
+    for (uint32_t j = 0; j < nperm && r.ok; j++) {
+        const int kind = r.u8() + CX_ADVICE;
+        const int idx = (int)r.u32();
+        if (kind > CX_INSTANCE || idx < 0 || idx >= (kind == CX_ADVICE ? pk.na : (kind == CX_FIXED ? pk.nf : pk.ni))) return BZH_E_ARG;
+        pk.perm_columns.push_back({kind, idx});
+    }
+    const uint32_t nlk = r.u32();
+    for (uint32_t l = 0; l < nlk && r.ok; l++) {
+        const uint32_t m = r.u32();
+        if (!m || m > 64) return BZH_E_ARG;
+        std::vector<int> ins, tabs;
+        for (uint32_t i = 0; i < m && r.ok; i++) ins.push_back(parse_expr<SF>(r, pk));
+        for (uint32_t i = 0; i < m && r.ok; i++) tabs.push_back(parse_expr<SF>(r, pk));
+        pk.lookups.push_back({ins, tabs});
+    }
+    const uint32_t ncopies = r.u32();
+    struct Copy {
+        uint32_t lc, lr, rc, rr;
+    };
+    std::vector<Copy> copies;
+    for (uint32_t i = 0; i < ncopies && r.ok; i++) {
+        Copy c{r.u32(), r.u32(), r.u32(), r.u32()};
+        if (c.lc >= nperm || c.rc >= nperm || c.lr >= pk.n || c.rr >= pk.n) return BZH_E_ARG;
+        copies.push_back(c);
+    }
+    if (!r.ok) return BZH_E_ARG;
+    const size_t n = pk.n;
+    std::vector<Fe<SF>> fixed_h((size_t)pk.nf * n, fe_zero<SF>());
+    for (int f = 0; f < pk.nf; f++) {
+        const uint32_t fl = r.u32();
+        if (!r.ok || fl > n) return BZH_E_ARG;
+        const uint8_t* b = r.bytes((size_t)fl * 32);
+        if (!b) return BZH_E_ARG;
+        for (uint32_t i = 0; i < fl; i++) fixed_h[(size_t)f * n + i] = h_from_bytes<SF>(b + 32 * (size_t)i);
+    }
+    if (!r.ok) return BZH_E_ARG;
+
+    // derived shape: queries in first-use order, degree, blinding factors (upstream ConstraintSystem)
+    std::vector<Query3> qs;
+    for (int g : pk.gates) cx_queries(pk, g, qs);
+    for (auto& lk : pk.lookups) {
+        for (int e : lk.first) cx_queries(pk, e, qs);
+        for (int e : lk.second) cx_queries(pk, e, qs);
+    }
+    for (auto& pc : pk.perm_columns) {
+        const Query3 q{pc.first, pc.second, 0};
+        if (std::find(qs.begin(), qs.end(), q) == qs.end()) qs.push_back(q);
+    }
+    std::map<int, int> per_col;
+    for (auto& q : qs) {
+        if (q.tag == CX_ADVICE) {
+            pk.advice_queries.push_back({q.col, q.rot});
+            per_col[q.col]++;
+        } else if (q.tag == CX_FIXED) {
+            pk.fixed_queries.push_back({q.col, q.rot});
+        } else {
+            pk.instance_queries.push_back({q.col, q.rot});
+        }
+    }
+    int deg = 3;
+    for (int g : pk.gates) deg = std::max(deg, cx_degree(pk, g));
+    for (auto& lk : pk.lookups) {
+        int di = 1, dt = 1;
+        for (int e : lk.first) di = std::max(di, cx_degree(pk, e));
+        for (int e : lk.second) dt = std::max(dt, cx_degree(pk, e));
+        deg = std::max(deg, std::max(4, 2 + di + dt));
+    }
+    pk.degree = std::max(deg, min_degree);
+    int maxq = 1;
+    for (auto& kv : per_col) maxq = std::max(maxq, kv.second);
+    pk.bf = std::max(3, maxq) + 2;
+    if ((size_t)pk.bf + 2 > n) return BZH_E_ARG;
+    pk.usable = n - (size_t)(pk.bf + 1);
+    pk.chunk_len = pk.degree - 2;
+    unsigned bl = 0;
+    for (int v = pk.degree - 2; v; v >>= 1) bl++;
+    pk.ek = pk.k + std::max(1u, bl);
+    if (pk.ek > FM::S) return BZH_E_RANGE;
+    pk.en = (size_t)1 << pk.ek;
+    pk.ext = pk.en / n;
+    pk.nl = (int)pk.lookups.size();
+    pk.nsets = nperm ? (int)((nperm + pk.chunk_len - 1) / pk.chunk_len) : 0;
+    pk.npieces = pk.degree - 1;
+    if ((size_t)pk.npieces * n > pk.en) return BZH_E_ARG;
+
+    // domain constants
+    uint32_t e[8];
+    {  // (p - 1) >> S
+        uint32_t pm1[8];
+        for (int i = 0; i < 8; i++) pm1[i] = SF::mod(i);
+        pm1[0] -= 1;  // p is odd
+        for (int i = 0; i < 8; i++) {
+            const unsigned s = FM::S, src = i + s / 32;
+            const uint64_t lo = src < 8 ? pm1[src] : 0, hi = src + 1 < 8 ? pm1[src + 1] : 0;
+            e[i] = (s % 32) ? (uint32_t)(((lo | (hi << 32)) >> (s % 32)) & 0xffffffffu) : (uint32_t)lo;
+        }
+    }
+    const Fe<SF> gen = fe_from_u32<SF>(FM::gen);
+    const Fe<SF> root = fe_pow(gen, e);
+    auto pow2 = [](Fe<SF> v, unsigned times) {
+        for (unsigned i = 0; i < times; i++) v = fe_sqr(v);
+        return v;
+    };
+    const Fe<SF> omega = pow2(root, FM::S - pk.k), eomega = pow2(root, FM::S - pk.ek);
+    const Fe<SF> delta = pow2(gen, FM::S);
+    Fe<SF> zeta;
+    {  // g^((p-1)/3)
+        uint32_t q[8];
+        uint64_t rem = 0;
+        uint32_t pm1[8];
+        for (int i = 0; i < 8; i++) pm1[i] = SF::mod(i);
+        pm1[0] -= 1;
+        for (int i = 7; i >= 0; i--) {
+            const uint64_t cur = (rem << 32) | pm1[i];
+            q[i] = (uint32_t)(cur / 3);
+            rem = cur % 3;
+        }
+        if (rem) return BZH_E_RANGE;  // no cube root of unity: the coset fast path needs 3 | p - 1
+        zeta = fe_pow(gen, q);
+    }
+    h_store<SF>(pk.omega, omega);
+    h_store<SF>(pk.eomega, eomega);
+    h_store<SF>(pk.zeta, zeta);
+    memcpy(pk.delta, delta.l, 32);
+
+    // permutation cycles (upstream permutation::keygen::Assembly::copy)
+    const size_t m = nperm;
+    std::vector<uint32_t> map_c(m * n), map_r(m * n), aux_c(m * n), aux_r(m * n), sizes(m * n, 1);
+    for (size_t c = 0; c < m; c++)
+        for (size_t rr = 0; rr < n; rr++) {
+            map_c[c * n + rr] = aux_c[c * n + rr] = (uint32_t)c;
+            map_r[c * n + rr] = aux_r[c * n + rr] = (uint32_t)rr;
+        }
+    for (auto& cp : copies) {
+        size_t li = cp.lc * n + cp.lr, ri = cp.rc * n + cp.rr;
+        uint32_t lc = aux_c[li], lr = aux_r[li], rc = aux_c[ri], rr = aux_r[ri];
+        if (lc == rc && lr == rr) continue;
+        if (sizes[lc * n + lr] < sizes[rc * n + rr]) {
+            std::swap(lc, rc);
+            std::swap(lr, rr);
+        }
+        sizes[lc * n + lr] += sizes[rc * n + rr];
+        uint32_t ic = rc, ir = rr;
+        do {
+            const size_t ii = ic * n + ir;
+            aux_c[ii] = lc;
+            aux_r[ii] = lr;
+            const uint32_t nc = map_c[ii], nr = map_r[ii];
+            ic = nc;
+            ir = nr;
+        } while (!(ic == rc && ir == rr));
+        std::swap(map_c[li], map_c[ri]);
+        std::swap(map_r[li], map_r[ri]);
+    }
+
+    // device allocation: fixed / sigma / ident columns in the three forms, l0 / l_last / l_blind, X and 1/(X^n - 1)
+    const size_t en = pk.en, nf = pk.nf;
+    const size_t words = (2 * nf * n + nf * en + 3 * m * n + m * en + 3 * en + 2 * en + 3 * n) * 8;
+    BZH_HIP_TRY(ctx, hipMalloc(&pk.dev, words * 4 + 256));
+    uint32_t* cur = (uint32_t*)pk.dev;
+    auto take = [&](size_t elems) {
+        uint32_t* p = cur;
+        cur += elems * 8;
+        return p;
+    };
+    pk.fixed = take(nf * n);
+    pk.fixed_polys = take(nf * n);
+    pk.fixed_cosets = take(nf * en);
+    pk.sigma = take(m * n);
+    pk.ident = take(m * n);
+    pk.sigma_polys = take(m * n);
+    pk.sigma_cosets = take(m * en);
+    pk.l0 = take(en);
+    pk.l_last = take(en);
+    pk.l_blind = take(en);
+    pk.x_col = take(en);
+    pk.tinv_col = take(en);
+    uint32_t* l_tmp = take(3 * n);
+    hipStream_t st = ctx->stream;
+    std::vector<Fe<SF>> wp(n), host(std::max(std::max(m * n, en), 3 * n));
+    wp[0] = fe_one<SF>();
+    for (size_t i = 1; i < n; i++) wp[i] = fe_mul(wp[i - 1], omega);
+    std::vector<Fe<SF>> dpow(m ? m : 1);
+    dpow[0] = fe_one<SF>();
+    for (size_t j = 1; j < m; j++) dpow[j] = fe_mul(dpow[j - 1], delta);
+    auto up = [&](uint32_t* dst, const Fe<SF>* src, size_t elems) -> int {
+        if (!elems) return BZH_OK;
+        BZH_HIP_TRY(ctx, hipMemcpyAsync(dst, src, elems * 32, hipMemcpyHostToDevice, st));
+        BZH_HIP_TRY(ctx, hipStreamSynchronize(st));
+        return BZH_OK;
+    };
+    auto to_coeff = [&](uint32_t* dst, const uint32_t* src, size_t count) -> int {
+        if (!count) return BZH_OK;
+        BZH_HIP_TRY(ctx, hipMemcpyAsync(dst, src, count * n * 32, hipMemcpyDeviceToDevice, st));
+        return ntt_run(ctx, pk.field, dst, pk.k, count, pk.omega, nullptr, 1, BZH_FORM_MONTGOMERY);
+    };
+    auto to_extended = [&](uint32_t* dst, const uint32_t* polys, size_t count) -> int {
+        if (!count) return BZH_OK;
+        BZH_HIP_TRY(ctx, hipMemsetAsync(dst, 0, count * en * 32, st));
+        BZH_HIP_TRY(ctx, hipMemcpy2DAsync(dst, en * 32, polys, n * 32, n * 32, count, hipMemcpyDeviceToDevice, st));
+        return ntt_run(ctx, pk.field, dst, pk.ek, count, pk.eomega, pk.zeta, 0, BZH_FORM_MONTGOMERY);
+    };
+    PV_TRY(up(pk.fixed, fixed_h.data(), nf * n));
+    PV_TRY(to_coeff(pk.fixed_polys, pk.fixed, nf));
+    PV_TRY(to_extended(pk.fixed_cosets, pk.fixed_polys, nf));
+    for (size_t j = 0; j < m; j++)
+        for (size_t rr = 0; rr < n; rr++) host[j * n + rr] = fe_mul(dpow[j], wp[rr]);
+    PV_TRY(up(pk.ident, host.data(), m * n));
+    for (size_t j = 0; j < m; j++)
+        for (size_t rr = 0; rr < n; rr++) host[j * n + rr] = fe_mul(dpow[map_c[j * n + rr]], wp[map_r[j * n + rr]]);
+    PV_TRY(up(pk.sigma, host.data(), m * n));
+    PV_TRY(to_coeff(pk.sigma_polys, pk.sigma, m));
+    PV_TRY(to_extended(pk.sigma_cosets, pk.sigma_polys, m));
+    for (size_t i = 0; i < 3 * n; i++) host[i] = fe_zero<SF>();
+    host[0] = fe_one<SF>();
+    host[n + pk.usable] = fe_one<SF>();
+    for (size_t i = pk.usable + 1; i < n; i++) host[2 * n + i] = fe_one<SF>();
+    PV_TRY(up(l_tmp, host.data(), 3 * n));
+    PV_TRY(ntt_run(ctx, pk.field, l_tmp, pk.k, 3, pk.omega, nullptr, 1, BZH_FORM_MONTGOMERY));
+    PV_TRY(to_extended(pk.l0, l_tmp, 3));  // l0, l_last, l_blind are consecutive
+    {
+        Fe<SF> x = zeta;
+        for (size_t i = 0; i < en; i++) {
+            host[i] = x;
+            x = fe_mul(x, eomega);
+        }
+        PV_TRY(up(pk.x_col, host.data(), en));
+        std::vector<Fe<SF>> tinv(pk.ext);
+        for (size_t i = 0; i < pk.ext; i++) tinv[i] = fe_inv(fe_sub(h_pow_u64(host[i], n), fe_one<SF>()));
+        for (size_t i = 0; i < en; i++) host[i] = tinv[i % pk.ext];
+        PV_TRY(up(pk.tinv_col, host.data(), en));
+    }
+
+    // multiopen structure (rotations stand in for the points: distinct rotations <-> distinct points x * omega^r)
+    {
+        struct Q {
+            uint64_t cid;
+            int rot;
+        };
+        std::vector<Q> q;
+        const int last_rot = -(pk.bf + 1);
+        for (auto& a : pk.instance_queries) q.push_back({key(K_INST, a.first), a.second});
+        for (auto& a : pk.advice_queries) q.push_back({key(K_ADV, a.first), a.second});
+        for (int i = 0; i < pk.nsets; i++) {
+            q.push_back({key(K_PZ, i), 0});
+            q.push_back({key(K_PZ, i), 1});
+            if (i != pk.nsets - 1) q.push_back({key(K_PZ, i), last_rot});
+        }
+        for (int i = 0; i < pk.nl; i++) {
+            q.push_back({key(K_LZ, i), 0});
+            q.push_back({key(K_LA, i), 0});
+            q.push_back({key(K_LS, i), 0});
+            q.push_back({key(K_LA, i), -1});
+            q.push_back({key(K_LZ, i), 1});
+        }
+        for (auto& a : pk.fixed_queries) q.push_back({key(K_FIX, a.first), a.second});
+        for (size_t j = 0; j < m; j++) q.push_back({key(K_SIGMA, j), 0});
+        q.push_back({key(K_MISC, M_H0), 0});
+        q.push_back({key(K_MISC, M_F), 0});  // the random polynomial
+        std::vector<uint64_t> order;
+        std::map<uint64_t, std::vector<int>> pts_of;
+        for (auto& e2 : q) {
+            auto it = pts_of.find(e2.cid);
+            if (it == pts_of.end()) {
+                order.push_back(e2.cid);
+                it = pts_of.insert({e2.cid, {}}).first;
+            }
+            if (std::find(it->second.begin(), it->second.end(), e2.rot) == it->second.end()) it->second.push_back(e2.rot);
+        }
+        for (uint64_t cid : order) {
+            std::vector<int> ks = pts_of[cid];
+            std::sort(ks.begin(), ks.end());
+            size_t si = 0;
+            for (; si < pk.rot_sets.size(); si++)
+                if (pk.rot_sets[si] == ks) break;
+            if (si == pk.rot_sets.size()) {
+                pk.rot_sets.push_back(ks);
+                pk.groups.push_back({});
+            }
+            pk.groups[si].push_back(cid);
+        }
+    }
+    // randomness per proof: blinding rows and blinds in create_proof's draw order, then the IPA opening
+    {
+        const size_t bf1 = (size_t)pk.bf + 1;
+        size_t draws = (size_t)pk.na * bf1 + pk.na;
+        draws += (size_t)pk.nl * (2 * bf1 + 2);
+        draws += (size_t)(pk.nsets + pk.nl) * ((size_t)pk.bf + 1);
+        draws += n + 1;                 // random polynomial + its blind
+        draws += (size_t)pk.npieces;    // h pieces
+        draws += 1;                     // f blind
+        draws += n + 1 + 2 * (size_t)pk.k;
+        pk.rng_bytes = draws * 64;
+    }
+    pk.arena.device = ctx->device;
+    BZH_HIP_TRY(ctx, hipStreamSynchronize(st));
+    *out = pkp.release();
+    return BZH_OK;
+}
+
+// ---------------------------------------------------------------------------
+// the lockstep prover
+// ---------------------------------------------------------------------------
+template <class C>
+struct Prover {
+    using SF = typename CurveScalar<C>::SF;
+    using PB = typename C::Base;
+    bzh_ctx* ctx;
+    bzh_pk& pk;
+    const size_t B;
+    hipStream_t st;
+    const size_t n, en, usable;
+    const int field;
+    std::vector<bzh_transcript*> T;
+    std::vector<const uint8_t*> rng;  // per-proof cursor into the caller's randomness
+    std::vector<std::map<int, Fe<SF>>> env;
+
+    Prover(bzh_ctx* c, bzh_pk& p, size_t batch)
+        : ctx(c), pk(p), B(batch), st(c->stream), n(p.n), en(p.en), usable(p.usable), field(p.field), T(batch, nullptr), rng(batch),
+          env(batch) {}
+    ~Prover() {
+        for (auto t : T)
+            if (t) bzh_transcript_free(t);
+    }
+
+    uint32_t* dalloc(size_t elems) { return (uint32_t*)pk.arena.alloc(elems * 32); }
+    int zero(uint32_t* p, size_t elems) {
+        BZH_HIP_TRY(ctx, hipMemsetAsync(p, 0, elems * 32, st));
+        return BZH_OK;
+    }
+    // strided device copy of `rows` rows of `width` elements
+    int copy2d(uint32_t* dst, size_t dpitch, const uint32_t* src, size_t spitch, size_t width, size_t rows) {
+        if (!rows || !width) return BZH_OK;
+        BZH_HIP_TRY(ctx, hipMemcpy2DAsync(dst, dpitch * 32, src, spitch * 32, width * 32, rows, hipMemcpyDeviceToDevice, st));
+        return BZH_OK;
+    }
+    // host Montgomery elements -> device
+    int upload(uint32_t* dst, const Fe<SF>* src, size_t elems) { return h2d_small(ctx, dst, src, elems * 32); }
+
+    Fe<SF> draw(size_t b) {
+        const Fe<SF> v = h_from_u512<SF>(rng[b]);
+        rng[b] += 64;
+        return v;
+    }
+    // the next `count` draws of every proof, reduced on the device into dst (B x count, proof-major)
+    int draw_rows(size_t count, uint32_t* dst) {
+        if (!count) return BZH_OK;
+        uint32_t* raw = (uint32_t*)pk.arena.alloc(B * count * 64);
+        if (!raw) return BZH_E_OOM;
+        std::vector<uint8_t> stage(B * count * 64);  // one upload for the whole batch
+        for (size_t b = 0; b < B; b++) {
+            memcpy(&stage[b * count * 64], rng[b], count * 64);
+            rng[b] += count * 64;
+        }
+        PV_TRY(h2d_small(ctx, raw, stage.data(), stage.size()));
+        if (stage.size() > ((size_t)1 << 20)) BZH_HIP_TRY(ctx, hipStreamSynchronize(st));  // direct copy from `stage`
+        return random_field(ctx, field, raw, B * count, dst);
+    }
+    Fe<SF> squeeze(size_t b) {
+        uint64_t ch[4];
+        bzh_transcript_squeeze_challenge(T[b], ch);
+        return fe_to_mont(h_load<SF>(ch));
+    }
+    void write_scalar(size_t b, const Fe<SF>& v) {
+        uint64_t s[4];
+        h_store<SF>(s, fe_from_mont(v));
+        bzh_transcript_write_scalar(T[b], s);
+    }
+
+    // ---- transforms ------------------------------------------------------------------------------
+    int to_coeff(uint32_t* dst, const uint32_t* src, size_t count) {
+        if (!count) return BZH_OK;
+        BZH_HIP_TRY(ctx, hipMemcpyAsync(dst, src, count * n * 32, hipMemcpyDeviceToDevice, st));
+        return ntt_run(ctx, field, dst, pk.k, count, pk.omega, nullptr, 1, BZH_FORM_MONTGOMERY);
+    }
+    int to_extended(uint32_t* dst, const uint32_t* polys, size_t count) {
+        if (!count) return BZH_OK;
+        PV_TRY(zero(dst, count * en));
+        PV_TRY(copy2d(dst, en, polys, n, n, count));
+        return ntt_run(ctx, field, dst, pk.ek, count, pk.eomega, pk.zeta, 0, BZH_FORM_MONTGOMERY);
+    }
+    // Params::commit for `count` polynomials (rows of `pitch` elements): affine canonical points out
+    int commit(const uint32_t* polys, size_t pitch, size_t count, const std::vector<Fe<SF>>& blinds, std::vector<uint64_t>& xy) {
+        xy.assign(count * 8, 0);
+        if (!count) return BZH_OK;
+        uint32_t* sc = dalloc(count * (n + 2));
+        uint32_t* bl = dalloc(count);
+        uint32_t* d_out = dalloc(count * 3);
+        if (!sc || !bl || !d_out) return BZH_E_OOM;
+        PV_TRY(zero(sc, count * (n + 2)));
+        PV_TRY(copy2d(sc, n + 2, polys, pitch, n, count));
+        PV_TRY(upload(bl, blinds.data(), count));
+        PV_TRY(copy2d(sc + (n + 1) * 8, n + 2, bl, 1, 1, count));
+        PV_TRY(msm_run(ctx, pk.srs, sc, n + 2, count, BZH_FORM_MONTGOMERY, d_out));
+        std::vector<uint64_t> jac(count * 12);
+        BZH_HIP_TRY(ctx, hipMemcpyAsync(jac.data(), d_out, count * 96, hipMemcpyDeviceToHost, st));
+        BZH_HIP_TRY(ctx, hipStreamSynchronize(st));
+        // Jacobian (Montgomery) -> affine canonical, one inversion
+        std::vector<Fe<PB>> pre(count + 1);
+        pre[0] = fe_one<PB>();
+        for (size_t i = 0; i < count; i++) {
+            const Fe<PB> Z = h_load<PB>(&jac[i * 12 + 8]);
+            pre[i + 1] = fe_is_zero(Z) ? pre[i] : fe_mul(pre[i], Z);
+        }
+        Fe<PB> inv = fe_inv(pre[count]);
+        for (size_t i = count; i-- > 0;) {
+            const Fe<PB> Z = h_load<PB>(&jac[i * 12 + 8]);
+            if (fe_is_zero(Z)) continue;
+            const Fe<PB> zi = fe_mul(inv, pre[i]);
+            inv = fe_mul(inv, Z);
+            const Fe<PB> zi2 = fe_sqr(zi), zi3 = fe_mul(zi2, zi);
+            h_store<PB>(&xy[i * 8], fe_from_mont(fe_mul(h_load<PB>(&jac[i * 12]), zi2)));
+            h_store<PB>(&xy[i * 8 + 4], fe_from_mont(fe_mul(h_load<PB>(&jac[i * 12 + 4]), zi3)));
+        }
+        return BZH_OK;
+    }
+    // evaluate `count` polynomials (contiguous, n coefficients each) at one point each
+    int evals(const uint32_t* stacked, size_t count, const std::vector<Fe<SF>>& points, std::vector<Fe<SF>>& out) {
+        out.resize(count);
+        if (!count) return BZH_OK;
+        uint32_t* xs = dalloc(count);
+        uint32_t* res = dalloc(count);
+        if (!xs || !res) return BZH_E_OOM;
+        PV_TRY(upload(xs, points.data(), count));
+        PV_TRY(poly_eval(ctx, field, stacked, n, count, xs, 1, res));
+        BZH_HIP_TRY(ctx, hipMemcpyAsync(out.data(), res, count * 32, hipMemcpyDeviceToHost, st));
+        BZH_HIP_TRY(ctx, hipStreamSynchronize(st));
+        return BZH_OK;
+    }
+
+    // ---- compiled programs -------------------------------------------------------------------------
+    template <class Build>
+    int run(uint64_t pkey, Build build, const Cols& reg, size_t size, uint32_t* d_out) {
+        auto it = pk.progs.find(pkey);
+        if (it == pk.progs.end()) {
+            EPool ep;
+            const int root = build(ep);
+            Compiler cc(ep);
+            cc.prog.result_slot = cc.emit(root);
+            if (cc.overflow) return BZH_E_RANGE;
+            it = pk.progs.insert({pkey, std::move(cc.prog)}).first;
+        }
+        const Program& pg = it->second;
+        const size_t nc = pg.consts.size(), ncols = reg.ptr.size();
+        bool per_proof = false;
+        for (auto& c : pg.consts) per_proof |= c.sym >= 0;
+        const size_t rows = per_proof ? B : 1;
+        std::vector<uint32_t> cv(std::max<size_t>(rows * nc, 1) * 8);
+        for (size_t b = 0; b < rows; b++)
+            for (size_t i = 0; i < nc; i++) {
+                const ConstEnt& c = pg.consts[i];
+                if (c.sym >= 0) {
+                    auto f = env[b].find(c.sym);
+                    if (f == env[b].end()) return BZH_E_ARG;
+                    memcpy(&cv[(b * nc + i) * 8], f->second.l, 32);
+                } else {
+                    memcpy(&cv[(b * nc + i) * 8], c.val, 32);
+                }
+            }
+        char* stage = (char*)pk.arena.alloc(cv.size() * 4 + pg.ops.size() * sizeof(bzh_expr_op) + ncols * 16 + 1024);
+        if (!stage) return BZH_E_OOM;
+        uint32_t* d_consts = (uint32_t*)stage;
+        char* d_prog = stage + ((cv.size() * 4 + 255) & ~(size_t)255);
+        char* d_ptrs = d_prog + ((pg.ops.size() * sizeof(bzh_expr_op) + 255) & ~(size_t)255);
+        char* d_strides = d_ptrs + ((ncols * 8 + 255) & ~(size_t)255);
+        PV_TRY(h2d_small(ctx, d_consts, cv.data(), cv.size() * 4));
+        PV_TRY(h2d_small(ctx, d_prog, pg.ops.data(), pg.ops.size() * sizeof(bzh_expr_op)));
+        PV_TRY(h2d_small(ctx, d_ptrs, reg.ptr.data(), ncols * 8));
+        PV_TRY(h2d_small(ctx, d_strides, reg.stride.data(), ncols * 8));
+        return expr_eval(ctx, field, d_prog, (int)pg.ops.size(), (const uint32_t* const*)d_ptrs, (const size_t*)d_strides, d_consts,
+                         per_proof ? nc : 0, size, pg.result_slot, B, d_out);
+    }
+
+    int prove(const uint32_t* d_advice_in, const uint64_t* instances, size_t inst_rows, uint8_t* proofs, size_t proof_stride,
+              size_t* proof_lens);
+};
+
+template <class C>
+int Prover<C>::prove(const uint32_t* d_advice_in, const uint64_t* instances, size_t inst_rows, uint8_t* proofs, size_t proof_stride,
+                     size_t* proof_lens) {
+    const int na = pk.na, nf = pk.nf, ni = pk.ni, bf = pk.bf, nsets = pk.nsets, nl = pk.nl, npieces = pk.npieces;
+    const size_t bf1 = (size_t)bf + 1, m = pk.perm_columns.size(), ext = pk.ext;
+    const int nz = nsets + nl;
+    std::vector<uint64_t> xy;
+    std::vector<Fe<SF>> blinds;
+    for (size_t b = 0; b < B; b++) {
+        PV_TRY(bzh_transcript_new(field, &T[b]));
+        bzh_transcript_common_scalar(T[b], pk.vk_repr);
+    }
+
+    // ---- instance columns ----------------------------------------------------------------------
+    uint32_t* inst = dalloc(B * std::max(ni, 1) * n);
+    uint32_t* inst_polys = dalloc(B * std::max(ni, 1) * n);
+    if (!inst || !inst_polys) return BZH_E_OOM;
+    if (ni) {
+        PV_TRY(zero(inst, B * ni * n));
+        if (inst_rows) {
+            std::vector<Fe<SF>> hv(B * ni * inst_rows);
+            for (size_t i = 0; i < hv.size(); i++) hv[i] = fe_to_mont(h_load<SF>(instances + 4 * i));
+            uint32_t* tmp = dalloc(hv.size());
+            if (!tmp) return BZH_E_OOM;
+            PV_TRY(upload(tmp, hv.data(), hv.size()));
+            PV_TRY(copy2d(inst, n, tmp, inst_rows, inst_rows, B * ni));
+        }
+        PV_TRY(to_coeff(inst_polys, inst, B * ni));
+        blinds.assign(B * ni, fe_one<SF>());
+        PV_TRY(commit(inst_polys, n, B * ni, blinds, xy));
+        for (size_t b = 0; b < B; b++)
+            for (int i = 0; i < ni; i++) bzh_transcript_common_point(T[b], &xy[(b * ni + i) * 8]);
+    }
+
+    // ---- advice columns ------------------------------------------------------------------------
+    uint32_t* adv = dalloc(B * na * n);
+    uint32_t* adv_polys = dalloc(B * na * n);
+    if (!adv || !adv_polys) return BZH_E_OOM;
+    BZH_HIP_TRY(ctx, hipMemcpyAsync(adv, d_advice_in, B * na * n * 32, hipMemcpyDeviceToDevice, st));
+    {
+        uint32_t* rows = dalloc(B * na * bf1);
+        if (!rows) return BZH_E_OOM;
+        PV_TRY(draw_rows(na * bf1, rows));
+        PV_TRY(copy2d(adv + usable * 8, n, rows, bf1, bf1, B * na));
+    }
+    std::vector<Fe<SF>> adv_blinds(B * na);
+    for (size_t b = 0; b < B; b++)
+        for (int i = 0; i < na; i++) adv_blinds[b * na + i] = draw(b);
+    PV_TRY(to_coeff(adv_polys, adv, B * na));
+    PV_TRY(commit(adv_polys, n, B * na, adv_blinds, xy));
+    for (size_t b = 0; b < B; b++) {
+        for (int i = 0; i < na; i++) bzh_transcript_write_point(T[b], C::id, &xy[(b * na + i) * 8]);
+        env[b][SY_THETA] = squeeze(b);
+    }
+    uint32_t *inst_cosets = nullptr, *adv_cosets = nullptr;
+    auto extend_witness = [&]() -> int {  // queued late on purpose: runs on the device while the host sorts the lookups
+        if (adv_cosets) return BZH_OK;
+        inst_cosets = dalloc(B * std::max(ni, 1) * en);
+        adv_cosets = dalloc(B * na * en);
+        if (!inst_cosets || !adv_cosets) return BZH_E_OOM;
+        PV_TRY(to_extended(inst_cosets, inst_polys, B * ni));
+        return to_extended(adv_cosets, adv_polys, B * na);
+    };
+    auto lag_registry = [&](Cols& reg) {
+        for (int i = 0; i < na; i++) reg.add(key(K_ADV, i), adv + (size_t)i * n * 8, (size_t)na * n);
+        for (int i = 0; i < nf; i++) reg.add(key(K_FIX, i), pk.fixed + (size_t)i * n * 8, 0);
+        for (int i = 0; i < ni; i++) reg.add(key(K_INST, i), inst + (size_t)i * n * 8, (size_t)ni * n);
+    };
+
+    // ---- lookups: compress, permute (host sort), commit -------------------------------------------
+    struct Lk {
+        uint32_t *a_c, *s_c, *as, *polys, *cosets;
+        std::vector<Fe<SF>> blinds;  // (a, s) per proof
+    };
+    std::vector<Lk> lk(nl);
+    for (int li = 0; li < nl; li++) {
+        Lk& d = lk[li];
+        d.a_c = dalloc(B * n);
+        d.s_c = dalloc(B * n);
+        d.as = dalloc(B * 2 * n);
+        d.polys = dalloc(B * 2 * n);
+        if (!d.a_c || !d.s_c || !d.as || !d.polys) return BZH_E_OOM;
+        Cols reg;
+        lag_registry(reg);
+        for (int side = 0; side < 2; side++) {
+            const std::vector<int>& es = side ? pk.lookups[li].second : pk.lookups[li].first;
+            PV_TRY(run(key(20 + side, li), [&](EPool& ep) {
+                std::vector<int> terms;
+                for (int e : es) terms.push_back(lower(pk, e, ep, reg, 1));
+                return ep.horner(terms, ep.sym(SY_THETA));
+            }, reg, n, side ? d.s_c : d.a_c));
+        }
+        std::vector<uint64_t> ah(B * n * 4), sh(B * n * 4), pa(B * usable * 4), ps(B * usable * 4);
+        BZH_HIP_TRY(ctx, hipMemcpyAsync(ah.data(), d.a_c, B * n * 32, hipMemcpyDeviceToHost, st));
+        BZH_HIP_TRY(ctx, hipMemcpyAsync(sh.data(), d.s_c, B * n * 32, hipMemcpyDeviceToHost, st));
+        BZH_HIP_TRY(ctx, hipStreamSynchronize(st));
+        PV_TRY(extend_witness());
+        {  // one sort per proof on host threads
+            const size_t nthreads = std::min<size_t>(B, std::max(1u, std::thread::hardware_concurrency()));
+            std::vector<int> rcs(B, BZH_OK);
+            std::vector<std::thread> th;
+            for (size_t t = 0; t < nthreads; t++)
+                th.emplace_back([&, t]() {
+                    for (size_t b = t; b < B; b += nthreads)
+                        rcs[b] = bzh_permute_expression_pair(field, &ah[b * n * 4], &sh[b * n * 4], usable, BZH_FORM_MONTGOMERY,
+                                                             &pa[b * usable * 4], &ps[b * usable * 4]);
+                });
+            for (auto& t : th) t.join();
+            for (int rc : rcs)
+                if (rc) return rc;
+        }
+        PV_TRY(zero(d.as, B * 2 * n));
+        BZH_HIP_TRY(ctx, hipMemcpy2DAsync(d.as, 2 * n * 32, pa.data(), usable * 32, usable * 32, B, hipMemcpyHostToDevice, st));
+        BZH_HIP_TRY(ctx, hipMemcpy2DAsync(d.as + n * 8, 2 * n * 32, ps.data(), usable * 32, usable * 32, B, hipMemcpyHostToDevice, st));
+        BZH_HIP_TRY(ctx, hipStreamSynchronize(st));  // pa / ps are locals
+        {
+            uint32_t* rows = dalloc(B * 2 * bf1);
+            if (!rows) return BZH_E_OOM;
+            PV_TRY(draw_rows(2 * bf1, rows));
+            PV_TRY(copy2d(d.as + usable * 8, n, rows, bf1, bf1, B * 2));
+        }
+        d.blinds.resize(B * 2);
+        for (size_t b = 0; b < B; b++) {
+            d.blinds[2 * b] = draw(b);
+            d.blinds[2 * b + 1] = draw(b);
+        }
+        PV_TRY(to_coeff(d.polys, d.as, B * 2));
+        PV_TRY(commit(d.polys, n, B * 2, d.blinds, xy));
+        for (size_t b = 0; b < B; b++) {
+            bzh_transcript_write_point(T[b], C::id, &xy[(2 * b) * 8]);
+            bzh_transcript_write_point(T[b], C::id, &xy[(2 * b + 1) * 8]);
+        }
+    }
+    PV_TRY(extend_witness());
+    for (size_t b = 0; b < B; b++) {
+        env[b][SY_BETA] = squeeze(b);
+        env[b][SY_GAMMA] = squeeze(b);
+    }
+
+    // ---- permutation and lookup grand products -----------------------------------------------------
+    uint32_t* zs = dalloc(B * std::max(nz, 1) * n);
+    uint32_t* z_polys = dalloc(B * std::max(nz, 1) * n);
+    uint32_t* z_cosets = dalloc(B * std::max(nz, 1) * en);
+    uint32_t* den = dalloc(B * n);
+    uint32_t* zt = dalloc(B * n);
+    if (!zs || !z_polys || !z_cosets || !den || !zt) return BZH_E_OOM;
+    std::vector<Fe<SF>> z_blinds(B * std::max(nz, 1));
+    auto finish_product = [&](int slot, int prev_slot) -> int {
+        PV_TRY(poly_batch_invert(ctx, field, den, B * n));
+        PV_TRY(poly_vec_mul(ctx, field, zt, den, B * n));
+        PV_TRY(poly_prefix_product(ctx, field, zt, n, B));
+        if (prev_slot >= 0)
+            hipLaunchKernelGGL((k_scale_rows<SF>), dim3((unsigned)((n + 255) / 256), (unsigned)B), dim3(256), 0, st, zt, n,
+                               zs + ((size_t)prev_slot * n + usable) * 8, (size_t)nz * n);
+        uint32_t* rows = dalloc(B * bf);
+        if (!rows) return BZH_E_OOM;
+        PV_TRY(draw_rows(bf, rows));
+        PV_TRY(copy2d(zt + (n - bf) * 8, n, rows, bf, bf, B));
+        for (size_t b = 0; b < B; b++) z_blinds[b * nz + slot] = draw(b);
+        return copy2d(zs + (size_t)slot * n * 8, (size_t)nz * n, zt, n, n, B);
+    };
+    auto lag_col = [&](Cols& reg, std::pair<int, int> col) {
+        if (col.first == CX_ADVICE) return reg.add(key(K_ADV, col.second), adv + (size_t)col.second * n * 8, (size_t)na * n);
+        if (col.first == CX_FIXED) return reg.add(key(K_FIX, col.second), pk.fixed + (size_t)col.second * n * 8, 0);
+        return reg.add(key(K_INST, col.second), inst + (size_t)col.second * n * 8, (size_t)ni * n);
+    };
+    for (int i = 0; i < nsets; i++) {
+        const size_t c0 = (size_t)i * pk.chunk_len, c1 = std::min(m, c0 + pk.chunk_len);
+        Cols reg;
+        for (size_t gj = c0; gj < c1; gj++) {
+            lag_col(reg, pk.perm_columns[gj]);
+            reg.add(key(K_SIGMA, gj), pk.sigma + gj * n * 8, 0);
+            reg.add(key(K_IDENT, gj), pk.ident + gj * n * 8, 0);
+        }
+        for (int which = 0; which < 2; which++) {  // 0: denominator, 1: numerator
+            PV_TRY(run(key(30 + which, i), [&](EPool& ep) {
+                int acc = -1;
+                for (size_t gj = c0; gj < c1; gj++) {
+                    const int v = ep.query(lag_col(reg, pk.perm_columns[gj]));
+                    const int f = which == 0 ? ep.add(ep.add(ep.mul(ep.sym(SY_BETA), ep.query(reg.at(key(K_SIGMA, gj)))), ep.sym(SY_GAMMA)), v)
+                                             : ep.add(ep.add(ep.mul(ep.query(reg.at(key(K_IDENT, gj))), ep.sym(SY_BETA)), ep.sym(SY_GAMMA)), v);
+                    acc = acc < 0 ? f : ep.mul(acc, f);
+                }
+                return acc;
+            }, reg, n, which == 0 ? den : zt));
+        }
+        PV_TRY(finish_product(i, i ? i - 1 : -1));
+    }
+    for (int li = 0; li < nl; li++) {
+        Cols reg;
+        reg.add(key(K_MISC, M_AC), lk[li].a_c, n);
+        reg.add(key(K_MISC, M_SC), lk[li].s_c, n);
+        reg.add(key(K_MISC, M_A), lk[li].as, 2 * n);
+        reg.add(key(K_MISC, M_S), lk[li].as + n * 8, 2 * n);
+        PV_TRY(run(key(32, li), [&](EPool& ep) {
+            return ep.mul(ep.add(ep.query(0), ep.sym(SY_BETA)), ep.add(ep.query(1), ep.sym(SY_GAMMA)));
+        }, reg, n, zt));
+        PV_TRY(run(key(33, li), [&](EPool& ep) {
+            return ep.mul(ep.add(ep.query(2), ep.sym(SY_BETA)), ep.add(ep.query(3), ep.sym(SY_GAMMA)));
+        }, reg, n, den));
+        PV_TRY(finish_product(nsets + li, -1));
+    }
+    if (nz) {
+        PV_TRY(to_coeff(z_polys, zs, B * nz));
+        PV_TRY(commit(z_polys, n, B * nz, z_blinds, xy));
+        for (size_t b = 0; b < B; b++)
+            for (int i = 0; i < nz; i++) bzh_transcript_write_point(T[b], C::id, &xy[(b * nz + i) * 8]);
+        PV_TRY(to_extended(z_cosets, z_polys, B * nz));
+    }
+    for (auto& d : lk) {
+        d.cosets = dalloc(B * 2 * en);
+        if (!d.cosets) return BZH_E_OOM;
+        PV_TRY(to_extended(d.cosets, d.polys, B * 2));
+    }
+
+    // ---- vanishing argument ----------------------------------------------------------------------
+    uint32_t* random_poly = dalloc(B * n);
+    if (!random_poly) return BZH_E_OOM;
+    PV_TRY(draw_rows(n, random_poly));
+    std::vector<Fe<SF>> random_blinds(B);
+    for (size_t b = 0; b < B; b++) random_blinds[b] = draw(b);
+    PV_TRY(commit(random_poly, n, B, random_blinds, xy));
+    const Fe<SF> delta = [&] {
+        Fe<SF> d;
+        memcpy(d.l, pk.delta, 32);
+        return d;
+    }();
+    for (size_t b = 0; b < B; b++) {
+        bzh_transcript_write_point(T[b], C::id, &xy[b * 8]);
+        env[b][SY_Y] = squeeze(b);
+        Fe<SF> bd = env[b][SY_BETA];
+        for (size_t gj = 0; gj < m; gj++) {
+            env[b][SY_BD0 + (int)gj] = bd;
+            bd = fe_mul(bd, delta);
+        }
+    }
+    const int last_rot = -(bf + 1);
+    uint32_t* h = dalloc(B * en);
+    if (!h) return BZH_E_OOM;
+    {
+        Cols reg;
+        for (int i = 0; i < na; i++) reg.add(key(K_ADV, i), adv_cosets + (size_t)i * en * 8, (size_t)na * en);
+        for (int i = 0; i < nf; i++) reg.add(key(K_FIX, i), pk.fixed_cosets + (size_t)i * en * 8, 0);
+        for (int i = 0; i < ni; i++) reg.add(key(K_INST, i), inst_cosets + (size_t)i * en * 8, (size_t)ni * en);
+        for (size_t j = 0; j < m; j++) reg.add(key(K_SIGMA, j), pk.sigma_cosets + j * en * 8, 0);
+        for (int i = 0; i < nsets; i++) reg.add(key(K_PZ, i), z_cosets + (size_t)i * en * 8, (size_t)nz * en);
+        for (int i = 0; i < nl; i++) {
+            reg.add(key(K_LA, i), lk[i].cosets, 2 * en);
+            reg.add(key(K_LS, i), lk[i].cosets + en * 8, 2 * en);
+            reg.add(key(K_LZ, i), z_cosets + (size_t)(nsets + i) * en * 8, (size_t)nz * en);
+        }
+        reg.add(key(K_MISC, M_L0), pk.l0, 0);
+        reg.add(key(K_MISC, M_LLAST), pk.l_last, 0);
+        reg.add(key(K_MISC, M_LBLIND), pk.l_blind, 0);
+        reg.add(key(K_MISC, M_X), pk.x_col, 0);
+        reg.add(key(K_MISC, M_TINV), pk.tinv_col, 0);
+        const int e = (int)ext;
+        PV_TRY(run(key(40, 0), [&](EPool& ep) {
+            auto Q = [&](uint64_t kk, int rot = 0) { return ep.query(reg.at(kk), rot); };
+            auto col_q = [&](std::pair<int, int> col) {
+                return Q(key(col.first == CX_ADVICE ? K_ADV : (col.first == CX_FIXED ? K_FIX : K_INST), col.second));
+            };
+            const Fe<SF> onef = fe_one<SF>();
+            auto one = [&] { return ep.cnst(onef); };
+            auto l0 = [&] { return Q(key(K_MISC, M_L0)); };
+            auto l_last = [&] { return Q(key(K_MISC, M_LLAST)); };
+            auto active = [&] { return ep.sub(one(), ep.add(l_last(), Q(key(K_MISC, M_LBLIND)))); };
+            std::vector<int> terms;
+            for (int g : pk.gates) terms.push_back(lower(pk, g, ep, reg, e));
+            if (nsets) {
+                terms.push_back(ep.mul(l0(), ep.sub(one(), Q(key(K_PZ, 0)))));
+                const uint64_t zl = key(K_PZ, nsets - 1);
+                terms.push_back(ep.mul(l_last(), ep.sub(ep.mul(Q(zl), Q(zl)), Q(zl))));
+                for (int i = 1; i < nsets; i++) terms.push_back(ep.mul(l0(), ep.sub(Q(key(K_PZ, i)), Q(key(K_PZ, i - 1), last_rot * e))));
+                for (int i = 0; i < nsets; i++) {
+                    const size_t c0 = (size_t)i * pk.chunk_len, c1 = std::min(m, c0 + pk.chunk_len);
+                    int left = Q(key(K_PZ, i), e), right = Q(key(K_PZ, i));
+                    for (size_t gj = c0; gj < c1; gj++) {
+                        left = ep.mul(left, ep.add(ep.add(col_q(pk.perm_columns[gj]), ep.mul(ep.sym(SY_BETA), Q(key(K_SIGMA, gj)))), ep.sym(SY_GAMMA)));
+                        const int cur = ep.mul(ep.sym(SY_BD0 + (int)gj), Q(key(K_MISC, M_X)));
+                        right = ep.mul(right, ep.add(ep.add(col_q(pk.perm_columns[gj]), cur), ep.sym(SY_GAMMA)));
+                    }
+                    terms.push_back(ep.mul(active(), ep.sub(left, right)));
+                }
+            }
+            for (int i = 0; i < nl; i++) {
+                auto z0 = [&] { return Q(key(K_LZ, i)); };
+                auto a_p = [&] { return Q(key(K_LA, i)); };
+                auto s_p = [&] { return Q(key(K_LS, i)); };
+                auto comp = [&](const std::vector<int>& es) {
+                    std::vector<int> t;
+                    for (int x : es) t.push_back(lower(pk, x, ep, reg, e));
+                    return ep.horner(t, ep.sym(SY_THETA));
+                };
+                terms.push_back(ep.mul(l0(), ep.sub(one(), z0())));
+                terms.push_back(ep.mul(l_last(), ep.sub(ep.mul(z0(), z0()), z0())));
+                const int lhs = ep.mul(ep.mul(Q(key(K_LZ, i), e), ep.add(a_p(), ep.sym(SY_BETA))), ep.add(s_p(), ep.sym(SY_GAMMA)));
+                const int rhs = ep.mul(ep.mul(z0(), ep.add(comp(pk.lookups[i].first), ep.sym(SY_BETA))),
+                                       ep.add(comp(pk.lookups[i].second), ep.sym(SY_GAMMA)));
+                terms.push_back(ep.mul(active(), ep.sub(lhs, rhs)));
+                terms.push_back(ep.mul(l0(), ep.sub(a_p(), s_p())));
+                terms.push_back(ep.mul(ep.mul(active(), ep.sub(a_p(), s_p())), ep.sub(a_p(), Q(key(K_LA, i), -e))));
+            }
+            return ep.mul(ep.horner(terms, ep.sym(SY_Y)), Q(key(K_MISC, M_TINV)));
+        }, reg, en, h));
+    }
+    PV_TRY(ntt_run(ctx, field, h, pk.ek, B, pk.eomega, pk.zeta, 1, BZH_FORM_MONTGOMERY));
+    uint32_t* d_flag = (uint32_t*)pk.arena.alloc(256);
+    if (!d_flag) return BZH_E_OOM;
+    uint32_t h_flag = 0;
+    if ((size_t)npieces * n < en) {
+        BZH_HIP_TRY(ctx, hipMemsetAsync(d_flag, 0, 4, st));
+        const size_t words = (en - (size_t)npieces * n) * 8;
+        hipLaunchKernelGGL(k_any_nonzero, dim3((unsigned)((words + 255) / 256), (unsigned)B), dim3(256), 0, st,
+                           h + (size_t)npieces * n * 8, words, en * 8, d_flag);
+        BZH_HIP_TRY(ctx, hipMemcpyAsync(&h_flag, d_flag, 4, hipMemcpyDeviceToHost, st));  // read after the commit's sync
+    }
+    std::vector<Fe<SF>> h_blinds(B * npieces);
+    for (size_t b = 0; b < B; b++)
+        for (int i = 0; i < npieces; i++) h_blinds[b * npieces + i] = draw(b);
+    {
+        // pieces of proof b: h[b][i*n .. (i+1)*n) -> (B * npieces) rows; piece rows are n apart inside a proof, proofs en apart
+        uint32_t* pieces = dalloc(B * npieces * n);
+        if (!pieces) return BZH_E_OOM;
+        PV_TRY(copy2d(pieces, (size_t)npieces * n, h, en, (size_t)npieces * n, B));
+        PV_TRY(commit(pieces, n, B * npieces, h_blinds, xy));
+    }
+    if (h_flag) {
+        ctx->last_error = "quotient has higher degree than expected: a witness does not satisfy the constraints";
+        return BZH_E_RANGE;
+    }
+    std::vector<Fe<SF>> xs(B);
+    Fe<SF> omega_m;
+    {
+        uint64_t t[4];
+        memcpy(t, pk.omega, 32);
+        omega_m = h_load<SF>(t);
+    }
+    const Fe<SF> omega_inv = fe_inv(omega_m);
+    for (size_t b = 0; b < B; b++) {
+        for (int i = 0; i < npieces; i++) bzh_transcript_write_point(T[b], C::id, &xy[(b * npieces + i) * 8]);
+        xs[b] = squeeze(b);
+        env[b][SY_XN] = h_pow_u64(xs[b], n);
+    }
+    std::map<int, Fe<SF>> wp;
+    auto rot = [&](size_t b, int r) {
+        auto it = wp.find(r);
+        if (it == wp.end()) it = wp.insert({r, r >= 0 ? h_pow_u64(omega_m, (uint64_t)r) : h_pow_u64(omega_inv, (uint64_t)(-(int64_t)r))}).first;
+        return fe_mul(xs[b], it->second);
+    };
+
+    // ---- evaluations: one gather of (polynomial, rotation) jobs ----------------------------------------
+    // where each committed polynomial lives: (pointer of proof 0, elements between proofs)
+    std::map<uint64_t, std::pair<const uint32_t*, size_t>> where;
+    for (int i = 0; i < ni; i++) where[key(K_INST, i)] = {inst_polys + (size_t)i * n * 8, (size_t)ni * n};
+    for (int i = 0; i < na; i++) where[key(K_ADV, i)] = {adv_polys + (size_t)i * n * 8, (size_t)na * n};
+    for (int i = 0; i < nf; i++) where[key(K_FIX, i)] = {pk.fixed_polys + (size_t)i * n * 8, 0};
+    for (size_t j = 0; j < m; j++) where[key(K_SIGMA, j)] = {pk.sigma_polys + j * n * 8, 0};
+    where[key(K_MISC, M_F)] = {random_poly, n};
+    for (int i = 0; i < nsets; i++) where[key(K_PZ, i)] = {z_polys + (size_t)i * n * 8, (size_t)nz * n};
+    for (int i = 0; i < nl; i++) {
+        where[key(K_LZ, i)] = {z_polys + (size_t)(nsets + i) * n * 8, (size_t)nz * n};
+        where[key(K_LA, i)] = {lk[i].polys, 2 * n};
+        where[key(K_LS, i)] = {lk[i].polys + n * 8, 2 * n};
+    }
+    auto gather = [&](const std::vector<std::pair<const uint32_t*, size_t>>& srcs, uint32_t* dst) -> int {
+        const size_t J = srcs.size();
+        std::vector<const uint32_t*> ps(J);
+        std::vector<size_t> ss(J);
+        for (size_t j = 0; j < J; j++) {
+            ps[j] = srcs[j].first;
+            ss[j] = srcs[j].second;
+        }
+        char* stage = (char*)pk.arena.alloc(J * 16 + 512);
+        if (!stage) return BZH_E_OOM;
+        char* d_ss = stage + ((J * 8 + 255) & ~(size_t)255);
+        PV_TRY(h2d_small(ctx, stage, ps.data(), J * 8));
+        PV_TRY(h2d_small(ctx, d_ss, ss.data(), J * 8));
+        hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((2 * n + 255) / 256), (unsigned)J, (unsigned)B), dim3(256), 0, st, (uint4*)dst,
+                           (const uint4* const*)stage, (const size_t*)d_ss, n, J);
+        BZH_HIP_TRY(ctx, hipGetLastError());
+        return BZH_OK;
+    };
+    {
+        std::vector<std::pair<uint64_t, int>> jobs;
+        for (auto& a : pk.instance_queries) jobs.push_back({key(K_INST, a.first), a.second});
+        for (auto& a : pk.advice_queries) jobs.push_back({key(K_ADV, a.first), a.second});
+        for (auto& a : pk.fixed_queries) jobs.push_back({key(K_FIX, a.first), a.second});
+        jobs.push_back({key(K_MISC, M_F), 0});
+        for (size_t j = 0; j < m; j++) jobs.push_back({key(K_SIGMA, j), 0});
+        for (int i = 0; i < nsets; i++) {
+            jobs.push_back({key(K_PZ, i), 0});
+            jobs.push_back({key(K_PZ, i), 1});
+            if (i != nsets - 1) jobs.push_back({key(K_PZ, i), last_rot});
+        }
+        for (int i = 0; i < nl; i++) {
+            jobs.push_back({key(K_LZ, i), 0});
+            jobs.push_back({key(K_LZ, i), 1});
+            jobs.push_back({key(K_LA, i), 0});
+            jobs.push_back({key(K_LA, i), -1});
+            jobs.push_back({key(K_LS, i), 0});
+        }
+        const size_t J = jobs.size();
+        std::vector<std::pair<const uint32_t*, size_t>> srcs(J);
+        for (size_t j = 0; j < J; j++) srcs[j] = where.at(jobs[j].first);
+        uint32_t* gathered = dalloc(B * J * n);
+        if (!gathered) return BZH_E_OOM;
+        PV_TRY(gather(srcs, gathered));
+        std::vector<Fe<SF>> pts(B * J), vals;
+        for (size_t b = 0; b < B; b++)
+            for (size_t j = 0; j < J; j++) pts[b * J + j] = rot(b, jobs[j].second);
+        PV_TRY(evals(gathered, B * J, pts, vals));
+        for (size_t b = 0; b < B; b++)
+            for (size_t j = 0; j < J; j++) write_scalar(b, vals[b * J + j]);
+    }
+
+    // ---- h(X) = sum_i x^(n i) h_i(X): Horner from the top piece ---------------------------------------
+    uint32_t* h_poly = dalloc(B * n);
+    if (!h_poly) return BZH_E_OOM;
+    {
+        Cols reg;
+        for (int i = 0; i < npieces; i++) reg.add(key(K_MISC, M_H0 + i), h + (size_t)i * n * 8, en);
+        PV_TRY(run(key(41, 0), [&](EPool& ep) {
+            std::vector<int> t;
+            for (int i = npieces - 1; i >= 0; i--) t.push_back(ep.query(i));
+            return ep.horner(t, ep.sym(SY_XN));
+        }, reg, n, h_poly));
+    }
+    std::vector<Fe<SF>> h_blind(B);
+    for (size_t b = 0; b < B; b++) {
+        Fe<SF> acc = fe_zero<SF>();
+        for (int i = npieces - 1; i >= 0; i--) acc = fe_add(fe_mul(acc, env[b][SY_XN]), h_blinds[b * npieces + i]);
+        h_blind[b] = acc;
+    }
+    where[key(K_MISC, M_H0)] = {h_poly, n};
+
+    // ---- multiopen ------------------------------------------------------------------------------
+    auto blind_of = [&](size_t b, uint64_t cid) -> Fe<SF> {
+        const int kind = (int)(cid >> 32);
+        const size_t i = (size_t)(cid & 0xffffffffu);
+        switch (kind) {
+            case K_ADV: return adv_blinds[b * na + i];
+            case K_PZ: return z_blinds[b * nz + i];
+            case K_LZ: return z_blinds[b * nz + nsets + i];
+            case K_LA: return lk[i].blinds[2 * b];
+            case K_LS: return lk[i].blinds[2 * b + 1];
+            case K_MISC: return i == M_H0 ? h_blind[b] : random_blinds[b];
+            default: return fe_one<SF>();  // instance, fixed, sigma
+        }
+    };
+    for (size_t b = 0; b < B; b++) {
+        env[b][SY_X1] = squeeze(b);
+        env[b][SY_X2] = squeeze(b);
+    }
+    const size_t nq = pk.rot_sets.size();
+    uint32_t* q_polys = dalloc(B * nq * n);
+    uint32_t* acc_a = dalloc(B * n);
+    uint32_t* acc_b = dalloc(B * n);
+    if (!q_polys || !acc_a || !acc_b) return BZH_E_OOM;
+    std::vector<Fe<SF>> q_blinds(B * nq);
+    for (size_t si = 0; si < nq; si++) {
+        const std::vector<uint64_t>& cids = pk.groups[si];
+        for (size_t b = 0; b < B; b++) {
+            Fe<SF> acc = fe_zero<SF>();
+            for (uint64_t cid : cids) acc = fe_add(fe_mul(acc, env[b][SY_X1]), blind_of(b, cid));
+            q_blinds[b * nq + si] = acc;
+        }
+        // Horner in x1 over the group's polynomials, in chunks that fit the evaluator's slot file
+        uint32_t* prev = nullptr;
+        for (size_t s0 = 0; s0 < cids.size(); s0 += 16) {
+            const size_t s1 = std::min(cids.size(), s0 + 16);
+            Cols reg;
+            if (prev) reg.add(key(K_MISC, M_ACC), prev, n);
+            for (size_t c = s0; c < s1; c++) {
+                const auto& w = where.at(cids[c]);
+                reg.add(cids[c], w.first, w.second);
+            }
+            uint32_t* outp = prev == acc_a ? acc_b : acc_a;
+            PV_TRY(run(key(50 + si, s0), [&](EPool& ep) {
+                std::vector<int> t;
+                for (size_t c = 0; c < reg.ptr.size(); c++) t.push_back(ep.query((int)c));
+                return ep.horner(t, ep.sym(SY_X1));
+            }, reg, n, outp));
+            prev = outp;
+        }
+        PV_TRY(copy2d(q_polys + si * n * 8, nq * n, prev, n, n, B));
+    }
+    // evaluations of the q polynomials at their own points, remainders r(X), quotients by prod (X - point)
+    {
+        std::vector<std::pair<size_t, int>> ev_jobs;
+        for (size_t si = 0; si < nq; si++)
+            for (int r : pk.rot_sets[si]) ev_jobs.push_back({si, r});
+        const size_t J2 = ev_jobs.size();
+        std::vector<std::pair<const uint32_t*, size_t>> srcs(J2);
+        for (size_t j = 0; j < J2; j++) srcs[j] = {q_polys + ev_jobs[j].first * n * 8, nq * n};
+        uint32_t* gathered = dalloc(B * J2 * n);
+        if (!gathered) return BZH_E_OOM;
+        PV_TRY(gather(srcs, gathered));
+        std::vector<Fe<SF>> pts(B * J2), ev;
+        for (size_t b = 0; b < B; b++)
+            for (size_t j = 0; j < J2; j++) pts[b * J2 + j] = rot(b, ev_jobs[j].second);
+        PV_TRY(evals(gathered, B * J2, pts, ev));
+        size_t maxpts = 1;
+        for (auto& rs : pk.rot_sets) maxpts = std::max(maxpts, rs.size());
+        std::vector<Fe<SF>> r_small(B * nq * maxpts, fe_zero<SF>());
+        for (size_t b = 0; b < B; b++) {
+            size_t o2 = 0;
+            for (size_t si = 0; si < nq; si++) {
+                const size_t np = pk.rot_sets[si].size();
+                // Lagrange interpolation through (points, evals): coefficient vector of length np
+                std::vector<Fe<SF>> res(np, fe_zero<SF>());
+                for (size_t j = 0; j < np; j++) {
+                    std::vector<Fe<SF>> num{fe_one<SF>()};
+                    Fe<SF> dn = fe_one<SF>();
+                    const Fe<SF> xj = pts[b * J2 + o2 + j];
+                    for (size_t mm = 0; mm < np; mm++) {
+                        if (mm == j) continue;
+                        const Fe<SF> xm = pts[b * J2 + o2 + mm];
+                        std::vector<Fe<SF>> nx(num.size() + 1);
+                        nx[0] = fe_neg(fe_mul(xm, num[0]));
+                        for (size_t i = 1; i < num.size(); i++) nx[i] = fe_sub(num[i - 1], fe_mul(xm, num[i]));
+                        nx[num.size()] = num.back();
+                        num.swap(nx);
+                        dn = fe_mul(dn, fe_sub(xj, xm));
+                    }
+                    const Fe<SF> cf = fe_mul(ev[b * J2 + o2 + j], fe_inv(dn));
+                    for (size_t i = 0; i < num.size(); i++) res[i] = fe_add(res[i], fe_mul(cf, num[i]));
+                }
+                for (size_t i = 0; i < np; i++) r_small[(b * nq + si) * maxpts + i] = res[i];
+                o2 += np;
+            }
+        }
+        uint32_t* rcols = dalloc(B * nq * n);
+        uint32_t* rs_dev = dalloc(B * nq * maxpts);
+        uint32_t* f_parts = dalloc(B * nq * n);
+        uint32_t* k_a = dalloc(B * n);
+        uint32_t* k_b = dalloc(B * n);
+        if (!rcols || !rs_dev || !f_parts || !k_a || !k_b) return BZH_E_OOM;
+        PV_TRY(zero(rcols, B * nq * n));
+        PV_TRY(zero(f_parts, B * nq * n));
+        PV_TRY(upload(rs_dev, r_small.data(), r_small.size()));
+        PV_TRY(copy2d(rcols, n, rs_dev, maxpts, maxpts, B * nq));
+        for (size_t si = 0; si < nq; si++) {
+            Cols reg;
+            reg.add(key(K_MISC, M_Q), q_polys + si * n * 8, nq * n);
+            reg.add(key(K_MISC, M_R), rcols + si * n * 8, nq * n);
+            PV_TRY(run(key(42, 0), [&](EPool& ep) { return ep.sub(ep.query(0), ep.query(1)); }, reg, n, k_a));
+            uint32_t* cur = k_a;
+            uint32_t* nxt = k_b;
+            size_t len = n;
+            for (int r : pk.rot_sets[si]) {
+                // [x, x^-1] per proof, one inversion for the batch
+                std::vector<Fe<SF>> xv(2 * B), pre(B + 1);
+                pre[0] = fe_one<SF>();
+                for (size_t b = 0; b < B; b++) {
+                    xv[2 * b] = rot(b, r);
+                    pre[b + 1] = fe_is_zero(xv[2 * b]) ? pre[b] : fe_mul(pre[b], xv[2 * b]);
+                }
+                Fe<SF> inv = fe_inv(pre[B]);
+                for (size_t b = B; b-- > 0;) {
+                    xv[2 * b + 1] = fe_zero<SF>();
+                    if (fe_is_zero(xv[2 * b])) continue;
+                    xv[2 * b + 1] = fe_mul(inv, pre[b]);
+                    inv = fe_mul(inv, xv[2 * b]);
+                }
+                uint32_t* d_x = dalloc(2 * B);
+                if (!d_x) return BZH_E_OOM;
+                PV_TRY(upload(d_x, xv.data(), 2 * B));
+                PV_TRY(poly_kate_division(ctx, field, cur, len, B, d_x, nxt));
+                std::swap(cur, nxt);
+                len--;
+            }
+            PV_TRY(copy2d(f_parts + si * n * 8, nq * n, cur, len, len, B));
+        }
+        // f = sum_si x2^(..) f_si (Horner), commit, x3, q evaluations, x4, the opened polynomial
+        uint32_t* f_poly = dalloc(B * n);
+        uint32_t* p_poly = dalloc(B * n);
+        if (!f_poly || !p_poly) return BZH_E_OOM;
+        if (nq == 1) {
+            PV_TRY(copy2d(f_poly, n, f_parts, n, n, B));
+        } else {
+            Cols reg;
+            for (size_t si = 0; si < nq; si++) reg.add(key(K_MISC, M_H0 + si), f_parts + si * n * 8, nq * n);
+            PV_TRY(run(key(43, 0), [&](EPool& ep) {
+                std::vector<int> t;
+                for (size_t si = 0; si < nq; si++) t.push_back(ep.query((int)si));
+                return ep.horner(t, ep.sym(SY_X2));
+            }, reg, n, f_poly));
+        }
+        std::vector<Fe<SF>> f_blinds(B), x3s(B);
+        for (size_t b = 0; b < B; b++) f_blinds[b] = draw(b);
+        PV_TRY(commit(f_poly, n, B, f_blinds, xy));
+        for (size_t b = 0; b < B; b++) {
+            bzh_transcript_write_point(T[b], C::id, &xy[b * 8]);
+            x3s[b] = squeeze(b);
+        }
+        std::vector<Fe<SF>> p3(B * nq), v3;
+        for (size_t b = 0; b < B; b++)
+            for (size_t si = 0; si < nq; si++) p3[b * nq + si] = x3s[b];
+        PV_TRY(evals(q_polys, B * nq, p3, v3));
+        for (size_t b = 0; b < B; b++) {
+            for (size_t si = 0; si < nq; si++) write_scalar(b, v3[b * nq + si]);
+            env[b][SY_X4] = squeeze(b);
+        }
+        {
+            Cols reg;
+            reg.add(key(K_MISC, M_F), f_poly, n);
+            for (size_t si = 0; si < nq; si++) reg.add(key(K_MISC, M_H0 + si), q_polys + si * n * 8, nq * n);
+            PV_TRY(run(key(44, 0), [&](EPool& ep) {
+                std::vector<int> t;
+                for (size_t c = 0; c <= nq; c++) t.push_back(ep.query((int)c));
+                return ep.horner(t, ep.sym(SY_X4));
+            }, reg, n, p_poly));
+        }
+        std::vector<uint64_t> p_blinds(B * 4), x3c(B * 4), out_v(B * 4);
+        for (size_t b = 0; b < B; b++) {
+            Fe<SF> acc = f_blinds[b];
+            for (size_t si = 0; si < nq; si++) acc = fe_add(fe_mul(acc, env[b][SY_X4]), q_blinds[b * nq + si]);
+            h_store<SF>(&p_blinds[4 * b], fe_from_mont(acc));
+            h_store<SF>(&x3c[4 * b], fe_from_mont(x3s[b]));
+        }
+        // the opening draws from each proof's own cursor: a zero stride is not possible, so pass proof 0's cursor and the
+        // common distance between the per-proof streams
+        const size_t need = 64 * (n + 1 + 2 * (size_t)pk.k);
+        std::vector<uint8_t> ipa_rng(B * need);
+        for (size_t b = 0; b < B; b++) memcpy(&ipa_rng[b * need], rng[b], need);
+        PV_TRY(ipa_open(ctx, pk.srs, p_poly, B, p_blinds.data(), x3c.data(), ipa_rng.data(), need, T.data(), out_v.data()));
+    }
+    for (size_t b = 0; b < B; b++) {
+        const uint8_t* data = nullptr;
+        size_t plen = 0;
+        PV_TRY(bzh_transcript_proof(T[b], &data, &plen));
+        if (plen > proof_stride) return BZH_E_ARG;
+        memcpy(proofs + b * proof_stride, data, plen);
+        proof_lens[b] = plen;
+    }
+    return BZH_OK;
+}
+
+template <class C>
+static int prove_batch_t(bzh_ctx* ctx, bzh_pk* pk, size_t batch, const uint32_t* d_advice, const uint64_t* instances, size_t inst_rows,
+                         const uint8_t* rng, size_t rng_stride, uint8_t* proofs, size_t proof_stride, size_t* proof_lens) {
+    pk->arena.reset();
+    Prover<C> pv(ctx, *pk, batch);
+    for (size_t b = 0; b < batch; b++) pv.rng[b] = rng + b * rng_stride;
+    const int rc = pv.prove(d_advice, instances, inst_rows, proofs, proof_stride, proof_lens);
+    (void)hipStreamSynchronize(ctx->stream);
+    return rc;
+}
+
+}  // namespace
+}  // namespace bzh
+
+extern "C" {
+
+int bzh_pk_create(bzh_ctx* ctx, const bzh_bases* srs, const uint8_t* circuit, size_t circuit_len, bzh_pk** out) {
+    if (!ctx || !srs || !circuit || !out || srs->device != ctx->device) return BZH_E_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    BZH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    switch (srs->curve) {
+        case BZH_CURVE_VESTA: return bzh::pk_create_t<bzh::VestaCurve>(ctx, srs, circuit, circuit_len, out);
+        case BZH_CURVE_PALLAS: return bzh::pk_create_t<bzh::PallasCurve>(ctx, srs, circuit, circuit_len, out);
+    }
+    return BZH_E_ARG;  // BN254 has no cube root of unity in Fr's multiplicative generator convention used here
+}
+
+int bzh_pk_free(bzh_ctx* ctx, bzh_pk* pk) {
+    if (!ctx || !pk) return BZH_E_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (pk->dev) (void)hipFree(pk->dev);
+    pk->arena.release();
+    delete pk;
+    return BZH_OK;
+}
+
+int bzh_pk_info(const bzh_pk* pk, size_t* rng_bytes_per_proof, size_t* max_proof_bytes, uint32_t* num_advice, uint32_t* n_rows,
+                uint32_t* usable_rows) {
+    if (!pk) return BZH_E_ARG;
+    if (rng_bytes_per_proof) *rng_bytes_per_proof = pk->rng_bytes;
+    if (max_proof_bytes) {
+        const size_t points = (size_t)pk->na + 2 * pk->nl + pk->nsets + pk->nl + 1 + pk->npieces + 1 + 1 + 2 * (size_t)pk->k;
+        const size_t scalars = pk->instance_queries.size() + pk->advice_queries.size() + pk->fixed_queries.size() + 1 +
+                               pk->perm_columns.size() + 3 * (size_t)pk->nsets + 5 * (size_t)pk->nl + pk->rot_sets.size() + 2;
+        *max_proof_bytes = 32 * (points + scalars);
+    }
+    if (num_advice) *num_advice = (uint32_t)pk->na;
+    if (n_rows) *n_rows = (uint32_t)pk->n;
+    if (usable_rows) *usable_rows = (uint32_t)pk->usable;
+    return BZH_OK;
+}
+
+int bzh_prove_batch(bzh_ctx* ctx, bzh_pk* pk, size_t batch, const uint64_t* advice, int form, int mem, const uint64_t* instances,
+                    size_t instance_rows, const uint8_t* rng, size_t rng_stride, uint8_t* proofs, size_t proof_stride,
+                    size_t* proof_lens) {
+    if (!ctx || !pk || !batch || batch > 4096 || !advice || !rng || !proofs || !proof_lens) return BZH_E_ARG;
+    if ((form != BZH_FORM_CANONICAL && form != BZH_FORM_MONTGOMERY) || (mem != BZH_MEM_HOST && mem != BZH_MEM_DEVICE)) return BZH_E_ARG;
+    if (pk->device != ctx->device || rng_stride < pk->rng_bytes || (pk->ni && instance_rows && !instances) || instance_rows > pk->usable)
+        return BZH_E_ARG;
+    if (mem == BZH_MEM_DEVICE && form != BZH_FORM_MONTGOMERY) return BZH_E_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    BZH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint32_t* d_adv = (const uint32_t*)advice;
+    void* staged = nullptr;
+    const size_t elems = batch * (size_t)pk->na * pk->n;
+    if (mem == BZH_MEM_HOST) {
+        int rc = bzh::ws_ensure(ctx, 3, elems * 32 + 256, &staged);
+        if (rc) return rc;
+        BZH_HIP_TRY(ctx, hipMemcpyAsync(staged, advice, elems * 32, hipMemcpyHostToDevice, ctx->stream));
+        if (form == BZH_FORM_CANONICAL && (rc = bzh::field_convert(ctx, pk->field, (uint32_t*)staged, elems, 1))) return rc;
+        d_adv = (const uint32_t*)staged;
+    }
+    switch (pk->curve) {
+        case BZH_CURVE_VESTA:
+            return bzh::prove_batch_t<bzh::VestaCurve>(ctx, pk, batch, d_adv, instances, instance_rows, rng, rng_stride, proofs, proof_stride,
+                                                       proof_lens);
+        case BZH_CURVE_PALLAS:
+            return bzh::prove_batch_t<bzh::PallasCurve>(ctx, pk, batch, d_adv, instances, instance_rows, rng, rng_stride, proofs, proof_stride,
+                                                        proof_lens);
+    }
+    return BZH_E_ARG;
+}
+
+}  // extern "C"

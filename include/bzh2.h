@@ -247,6 +247,30 @@ int bzh_ipa_open_batch(bzh_ctx* ctx, const bzh_bases* bases, const uint64_t* pol
 int bzh_ipa_verify(bzh_ctx* ctx, const bzh_bases* bases, const uint64_t* commitment_xy, const uint64_t* x3, const uint64_t* v,
                    const uint8_t* proof, size_t proof_len, bzh_transcript* transcript, const uint64_t* g0_u_w);
 
+/* ---- whole proofs (halo2_proofs plonk::{keygen_pk, create_proof}; reference call sites benches/shot.rs:58-71,
+ * benches/board.rs:51-71, src/circuits/shot.rs:915-930, src/circuits/board.rs:907-922) ----------------------
+ * bzh_pk_create    keygen_pk for a circuit given as data (serialised constraint system + fixed assignment; the
+ *                  format is documented at the top of csrc/prove.hip and produced by bzh2.prover.Circuit.serialize()):
+ *                  fixed / permutation polynomials in Lagrange, coefficient and extended-coset form, l_0 / l_last /
+ *                  l_blind, resident on the device.  `srs`: n + 2 points G_0..G_(n-1), U, W with a window table
+ *                  (bzh_bases_precompute); it must outlive the key.
+ * bzh_prove_batch  create_proof for `batch` independent witnesses of that circuit in lockstep (one launch per kernel
+ *                  class per protocol phase for all of them); every proof is byte-identical to proving its witness
+ *                  alone.  advice: batch x num_advice x n field elements (`form`, `mem`; rows past the usable ones are
+ *                  overwritten with blinding values); instances: batch x num_instance x instance_rows canonical
+ *                  elements (host); rng: per proof, at offset b * rng_stride, 64 bytes per Field::random draw in
+ *                  upstream's draw order (bzh_pk_info reports the byte count); proofs: batch records of
+ *                  proof_stride bytes, lengths in proof_lens.  BZH_E_RANGE: a witness does not satisfy the circuit
+ *                  (surplus quotient coefficients) or a lookup input is not in its table. */
+typedef struct bzh_pk bzh_pk;
+int bzh_pk_create(bzh_ctx* ctx, const bzh_bases* srs, const uint8_t* circuit, size_t circuit_len, bzh_pk** out);
+int bzh_pk_free(bzh_ctx* ctx, bzh_pk* pk);
+int bzh_pk_info(const bzh_pk* pk, size_t* rng_bytes_per_proof, size_t* max_proof_bytes, uint32_t* num_advice, uint32_t* n_rows,
+                uint32_t* usable_rows);
+int bzh_prove_batch(bzh_ctx* ctx, bzh_pk* pk, size_t batch, const uint64_t* advice, int form, int mem, const uint64_t* instances,
+                    size_t instance_rows, const uint8_t* rng, size_t rng_stride, uint8_t* proofs, size_t proof_stride,
+                    size_t* proof_lens);
+
 /* ---- host helpers (CPU, no device needed): what `.to_affine()` / `to_bytes()`
  * do on the Rust side; used by tests and benches to compare canonical bytes. */
 int bzh_jacobian_to_affine(int curve, const uint64_t* xyz, size_t n, int form, uint64_t* out_xy);
