@@ -53,9 +53,9 @@ struct Stager {
             int rc = field_convert(ctx, field, dev, elems, 0);
             if (rc) return rc;
         }
-        BZH_HIP_TRY(ctx, hipMemcpyAsync(host, dev, elems * 32, hipMemcpyDeviceToHost, ctx->stream));
-        BZH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        return BZH_OK;
+        int rc = d2h_async(ctx, host, dev, elems * 32);
+        if (rc) return rc;
+        return d2h_finish(ctx);
     }
 };
 
@@ -253,6 +253,7 @@ int bzh_ctx_destroy(bzh_ctx* ctx) {
     for (int i = 0; i < bzh_ctx::kWsSlots; i++)
         if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
+    if (ctx->pin_big) (void)hipHostFree(ctx->pin_big);
     for (auto& s : ctx->spans) {
         (void)hipEventDestroy(s.a);
         (void)hipEventDestroy(s.b);

@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdint>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -43,6 +45,14 @@ struct bzh_ctx {
     // pinned upload ring: small host->device copies stay asynchronous (a pageable hipMemcpyAsync waits for the copy)
     char* pin = nullptr;
     size_t pin_bytes = 0, pin_off = 0;
+    char* pin_big = nullptr;  // grow-only pinned buffer for transfers above 1 MiB
+    size_t pin_big_bytes = 0, pin_big_off = 0;
+    struct PendingD2H {
+        void* dst;
+        const char* slot;
+        size_t bytes;
+    };
+    std::vector<PendingD2H> pending_d2h;
 };
 
 #define BZH_HIP_TRY(ctx, expr)                                                                    \
@@ -73,27 +83,131 @@ inline int ws_ensure(bzh_ctx* ctx, int slot, size_t bytes, void** out) {
     return BZH_OK;
 }
 
-// host -> device copy of a small, short-lived host buffer through the pinned ring: returns at once, stream-ordered
-inline int h2d_small(bzh_ctx* ctx, void* dst, const void* src, size_t bytes) {
-    constexpr size_t kRing = (size_t)8 << 20;
+// ---------------------------------------------------------------------------
+// Host <-> device staging through pinned memory and copy KERNELS.  The runtime's own copy paths (SDMA / blit
+// through hipMemcpyAsync) showed 3x slower transfers and multi-millisecond stalls on small copies in every
+// process after the first one on a box ("transfers"); a kernel that reads or writes mapped pinned
+// host memory has launch-like latency and is stream-ordered like everything else.
+//   h2d_small  short-lived host buffer -> device, asynchronous (ring of pinned slots, or the big buffer)
+//   d2h_async  device -> host destination, completed by d2h_finish (one stream sync for any number of them)
+// ---------------------------------------------------------------------------
+static __global__ void __launch_bounds__(256) k_xfer16(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t n16) {
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+static __global__ void __launch_bounds__(256) k_xfer4(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, size_t n4) {
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+// stream-ordered copy between two device-visible addresses (device memory or mapped pinned host memory)
+inline int xfer_launch(bzh_ctx* ctx, void* dst, const void* src, size_t bytes, hipMemcpyKind fallback) {
     if (!bytes) return BZH_OK;
-    if (bytes > kRing / 8) {
-        BZH_HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    const uintptr_t al = (uintptr_t)dst | (uintptr_t)src | (uintptr_t)bytes;
+    if ((al & 15) == 0) {
+        const size_t n16 = bytes / 16;
+        const unsigned blocks = (unsigned)std::min<size_t>((n16 + 255) / 256, 2048);
+        hipLaunchKernelGGL(k_xfer16, dim3(blocks), dim3(256), 0, ctx->stream, (uint4*)dst, (const uint4*)src, n16);
+    } else if ((al & 3) == 0) {
+        const size_t n4 = bytes / 4;
+        const unsigned blocks = (unsigned)std::min<size_t>((n4 + 255) / 256, 2048);
+        hipLaunchKernelGGL(k_xfer4, dim3(blocks), dim3(256), 0, ctx->stream, (uint32_t*)dst, (const uint32_t*)src, n4);
+    } else {
+        BZH_HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, fallback, ctx->stream));
         return BZH_OK;
     }
+    BZH_HIP_TRY(ctx, hipGetLastError());
+    return BZH_OK;
+}
+inline int pin_big_ensure(bzh_ctx* ctx, size_t bytes) {
+    if (ctx->pin_big_bytes >= bytes) return BZH_OK;
+    BZH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto& p : ctx->pending_d2h) memcpy(p.dst, p.slot, p.bytes);
+    ctx->pending_d2h.clear();
+    if (ctx->pin_big) BZH_HIP_TRY(ctx, hipHostFree(ctx->pin_big));
+    ctx->pin_big = nullptr;
+    ctx->pin_big_bytes = 0;
+    const size_t want = bytes + (bytes >> 2) + 4096;
+    BZH_HIP_TRY(ctx, hipHostMalloc((void**)&ctx->pin_big, want, hipHostMallocDefault));
+    ctx->pin_big_bytes = want;
+    ctx->pin_big_off = 0;
+    return BZH_OK;
+}
+// slot of `bytes` in the big pinned buffer; waits for the stream when the buffer has to be recycled
+inline int pin_big_take(bzh_ctx* ctx, size_t bytes, char** out) {
+    const size_t need = (bytes + 255) & ~(size_t)255;
+    if (ctx->pin_big_bytes < need) {
+        int rc = pin_big_ensure(ctx, need);
+        if (rc) return rc;
+    }
+    if (ctx->pin_big_off + need > ctx->pin_big_bytes) {
+        BZH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        for (auto& p : ctx->pending_d2h) memcpy(p.dst, p.slot, p.bytes);  // staged results leave before their slots are reused
+        ctx->pending_d2h.clear();
+        ctx->pin_big_off = 0;
+    }
+    *out = ctx->pin_big + ctx->pin_big_off;
+    ctx->pin_big_off += need;
+    return BZH_OK;
+}
+// make room for a group of big slots that have to stay valid together (no recycling in between)
+inline int pin_big_reserve(bzh_ctx* ctx, size_t total) {
+    total += 4096;
+    int rc = pin_big_ensure(ctx, total);
+    if (rc) return rc;
+    if (ctx->pin_big_off + total > ctx->pin_big_bytes) {
+        BZH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        for (auto& p : ctx->pending_d2h) memcpy(p.dst, p.slot, p.bytes);
+        ctx->pending_d2h.clear();
+        ctx->pin_big_off = 0;
+    }
+    return BZH_OK;
+}
+inline int pin_ring_take(bzh_ctx* ctx, size_t bytes, char** out) {
+    constexpr size_t kRing = (size_t)8 << 20;
     if (!ctx->pin) {
         BZH_HIP_TRY(ctx, hipHostMalloc((void**)&ctx->pin, kRing, hipHostMallocDefault));
         ctx->pin_bytes = kRing;
         ctx->pin_off = 0;
     }
-    const size_t need = (bytes + 63) & ~(size_t)63;
+    const size_t need = (bytes + 255) & ~(size_t)255;
     if (ctx->pin_off + need > ctx->pin_bytes) {  // wrap: everything queued from the ring has to have landed
         BZH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        for (auto& p : ctx->pending_d2h) memcpy(p.dst, p.slot, p.bytes);
+        ctx->pending_d2h.clear();
         ctx->pin_off = 0;
     }
-    memcpy(ctx->pin + ctx->pin_off, src, bytes);
-    BZH_HIP_TRY(ctx, hipMemcpyAsync(dst, ctx->pin + ctx->pin_off, bytes, hipMemcpyHostToDevice, ctx->stream));
+    *out = ctx->pin + ctx->pin_off;
     ctx->pin_off += need;
+    return BZH_OK;
+}
+inline int h2d_small(bzh_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    if (!bytes) return BZH_OK;
+    char* slot = nullptr;
+    int rc = bytes > ((size_t)1 << 20) ? pin_big_take(ctx, bytes, &slot) : pin_ring_take(ctx, bytes, &slot);
+    if (rc) return rc;
+    memcpy(slot, src, bytes);
+    return xfer_launch(ctx, dst, slot, bytes, hipMemcpyHostToDevice);
+}
+// pinned staging slot the caller fills itself (saves one host copy for large uploads), then h2d_commit
+inline int h2d_stage(bzh_ctx* ctx, size_t bytes, char** slot) {
+    return bytes > ((size_t)1 << 20) ? pin_big_take(ctx, bytes, slot) : pin_ring_take(ctx, bytes, slot);
+}
+inline int h2d_commit(bzh_ctx* ctx, void* dst, const char* slot, size_t bytes) {
+    return xfer_launch(ctx, dst, slot, bytes, hipMemcpyHostToDevice);
+}
+inline int d2h_async(bzh_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes) {
+    if (!bytes) return BZH_OK;
+    char* slot = nullptr;
+    int rc = bytes > ((size_t)1 << 20) ? pin_big_take(ctx, bytes, &slot) : pin_ring_take(ctx, bytes, &slot);
+    if (rc) return rc;
+    rc = xfer_launch(ctx, slot, dev_src, bytes, hipMemcpyDeviceToHost);
+    if (rc) return rc;
+    ctx->pending_d2h.push_back({host_dst, slot, bytes});
+    return BZH_OK;
+}
+// one stream synchronisation, then the staged results are handed to their destinations
+inline int d2h_finish(bzh_ctx* ctx) {
+    BZH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto& p : ctx->pending_d2h) memcpy(p.dst, p.slot, p.bytes);
+    ctx->pending_d2h.clear();
     return BZH_OK;
 }
 

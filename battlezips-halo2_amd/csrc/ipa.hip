@@ -425,13 +425,13 @@ static int ipa_open_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_po
 
     // randomness: upstream draw order = n coefficients of s(X), s_blind, then (l_j, r_j) per round
     for (size_t b = 0; b < B; b++)
-        BZH_HIP_TRY(ctx, hipMemcpyAsync(d_raw + b * nrand * 16, rng_bytes + b * rng_stride, nrand * 64, hipMemcpyHostToDevice, st));
+        IPA_TRY(h2d_small(ctx, d_raw + b * nrand * 16, rng_bytes + b * rng_stride, nrand * 64));
     hipLaunchKernelGGL((k_reduce_wide<SF>), dim3((unsigned)((B * nrand + g256 - 1) / g256)), dim3(g256), 0, st, d_raw, B * nrand,
                        d_rand);
     BZH_HIP_TRY(ctx, hipMemcpy2DAsync(d_spoly, n * 32, d_rand, nrand * 32, n * 32, B, hipMemcpyDeviceToDevice, st));
     // the scalars the host needs (s_blind and the round blinds) come back in one strided copy
     std::vector<Fe<SF>> tail(B * ntail);
-    BZH_HIP_TRY(ctx, hipMemcpy2DAsync(tail.data(), ntail * 32, d_rand + n * 8, nrand * 32, ntail * 32, B, hipMemcpyDeviceToHost, st));
+    for (size_t b = 0; b < B; b++) IPA_TRY(d2h_async(ctx, &tail[b * ntail], d_rand + (b * nrand + n) * 8, ntail * 32));
 
     std::vector<Fe<SF>> hc(B * kHc, fe_zero<SF>());
     for (size_t b = 0; b < B; b++) hc[b * kHc] = fe_to_mont(h_load<SF>(x3s + 4 * b));
@@ -447,8 +447,8 @@ static int ipa_open_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_po
     BZH_HIP_TRY(ctx, hipGetLastError());
     IPA_TRY(msm_run(ctx, bases, d_commit, n + 2, B, BZH_FORM_MONTGOMERY, (uint32_t*)d_out));
     std::vector<uint64_t> jac(2 * B * 12), xy(2 * B * 8);
-    BZH_HIP_TRY(ctx, hipMemcpyAsync(jac.data(), d_out, B * 96, hipMemcpyDeviceToHost, st));
-    BZH_HIP_TRY(ctx, hipStreamSynchronize(st));
+    IPA_TRY(d2h_async(ctx, jac.data(), d_out, B * 96));
+    IPA_TRY(d2h_finish(ctx));
     h_jac_batch_to_affine_canonical<PB>(jac.data(), B, xy.data());
     uint64_t ch[4];
     std::vector<Fe<SF>> f(B);
@@ -467,7 +467,7 @@ static int ipa_open_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_po
     IPA_TRY(poly_eval(ctx, field, p_cur, n, B, d_hc, kHc, d_dv));
     hipLaunchKernelGGL((k_sub_at0_batch<SF>), dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st, p_cur, n, d_dv, B);
     std::vector<Fe<SF>> vm(B);
-    BZH_HIP_TRY(ctx, hipMemcpyAsync(vm.data(), d_dv, B * 32, hipMemcpyDeviceToHost, st));  // read after the next sync
+    IPA_TRY(d2h_async(ctx, vm.data(), d_dv, B * 32));  // lands at the next d2h_finish
     hipLaunchKernelGGL((k_ipa_init_b_s<SF>), grid2(n), dim3(g256), 0, st, d_hc, n, b_cur, s_cur);
     BZH_HIP_TRY(ctx, hipGetLastError());
 
@@ -486,8 +486,8 @@ static int ipa_open_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_po
             BZH_HIP_TRY(ctx, hipGetLastError());
             IPA_TRY(msm_run(ctx, bases, d_lr, n + 2, 2 * B, BZH_FORM_MONTGOMERY, (uint32_t*)d_out));
         }
-        BZH_HIP_TRY(ctx, hipMemcpyAsync(jac.data(), d_out, 2 * B * 96, hipMemcpyDeviceToHost, st));
-        BZH_HIP_TRY(ctx, hipStreamSynchronize(st));
+        IPA_TRY(d2h_async(ctx, jac.data(), d_out, 2 * B * 96));
+        IPA_TRY(d2h_finish(ctx));
         h_jac_batch_to_affine_canonical<PB>(jac.data(), 2 * B, xy.data());
         pre[0] = fe_one<SF>();
         for (size_t b = 0; b < B; b++) {
@@ -516,8 +516,8 @@ static int ipa_open_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_po
         std::swap(s_cur, s_nxt);
     }
     std::vector<Fe<SF>> c(B);
-    BZH_HIP_TRY(ctx, hipMemcpyAsync(c.data(), p_cur, B * 32, hipMemcpyDeviceToHost, st));
-    BZH_HIP_TRY(ctx, hipStreamSynchronize(st));
+    IPA_TRY(d2h_async(ctx, c.data(), p_cur, B * 32));
+    IPA_TRY(d2h_finish(ctx));
     for (size_t b = 0; b < B; b++) {
         h_store<SF>(out_v + 4 * b, fe_from_mont(vm[b]));
         uint64_t sc[4];

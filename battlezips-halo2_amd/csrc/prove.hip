@@ -24,6 +24,9 @@
 //   expr := u8 tag, then  0 const: u8[32] | 1 advice / 2 fixed / 3 instance: u32 column, i32 rotation
 //                       | 4 neg: expr | 5 add: expr expr | 6 mul: expr expr | 7 scale: expr, u8[32]
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -335,8 +338,20 @@ struct Arena {
     };
     std::vector<Block> blocks;
     int device = 0;
+    size_t requested = 0;  // bytes handed out since the last reset
+    // A call's allocation sequence is deterministic, so after the first call of a given shape the arena is ONE block
+    // that every later call bumps through without touching hipMalloc (overflow blocks are merged at the next reset).
     void reset() {
+        if (blocks.size() > 1) {
+            const size_t want = requested + (requested >> 4) + ((size_t)1 << 20);
+            release();
+            Block nb;
+            nb.size = want;
+            nb.used = 0;
+            if (hipMalloc((void**)&nb.p, nb.size) == hipSuccess) blocks.push_back(nb);
+        }
         for (auto& b : blocks) b.used = 0;
+        requested = 0;
     }
     void release() {
         for (auto& b : blocks) (void)hipFree(b.p);
@@ -344,6 +359,7 @@ struct Arena {
     }
     void* alloc(size_t bytes) {
         bytes = (bytes + 255) & ~(size_t)255;
+        requested += bytes;
         for (auto& b : blocks)
             if (b.size - b.used >= bytes) {
                 void* r = b.p + b.used;
@@ -907,6 +923,17 @@ struct Prover {
             if (t) bzh_transcript_free(t);
     }
 
+    // BZH_PROVE_TRACE=1: phase wall times on stderr, with a device sync at every phase boundary
+    const bool trace = getenv("BZH_PROVE_TRACE") != nullptr;
+    std::chrono::steady_clock::time_point t_last = std::chrono::steady_clock::now();
+    void mark(const char* name) {
+        if (!trace) return;
+        (void)hipStreamSynchronize(st);
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[bzh_prove_batch] %-22s %8.2f ms\n", name, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    }
+
     uint32_t* dalloc(size_t elems) { return (uint32_t*)pk.arena.alloc(elems * 32); }
     int zero(uint32_t* p, size_t elems) {
         BZH_HIP_TRY(ctx, hipMemsetAsync(p, 0, elems * 32, st));
@@ -931,13 +958,13 @@ struct Prover {
         if (!count) return BZH_OK;
         uint32_t* raw = (uint32_t*)pk.arena.alloc(B * count * 64);
         if (!raw) return BZH_E_OOM;
-        std::vector<uint8_t> stage(B * count * 64);  // one upload for the whole batch
+        char* stage = nullptr;  // one upload for the whole batch, assembled in pinned memory
+        PV_TRY(h2d_stage(ctx, B * count * 64, &stage));
         for (size_t b = 0; b < B; b++) {
-            memcpy(&stage[b * count * 64], rng[b], count * 64);
+            memcpy(stage + b * count * 64, rng[b], count * 64);
             rng[b] += count * 64;
         }
-        PV_TRY(h2d_small(ctx, raw, stage.data(), stage.size()));
-        if (stage.size() > ((size_t)1 << 20)) BZH_HIP_TRY(ctx, hipStreamSynchronize(st));  // direct copy from `stage`
+        PV_TRY(h2d_commit(ctx, raw, stage, B * count * 64));
         return random_field(ctx, field, raw, B * count, dst);
     }
     Fe<SF> squeeze(size_t b) {
@@ -977,8 +1004,8 @@ struct Prover {
         PV_TRY(copy2d(sc + (n + 1) * 8, n + 2, bl, 1, 1, count));
         PV_TRY(msm_run(ctx, pk.srs, sc, n + 2, count, BZH_FORM_MONTGOMERY, d_out));
         std::vector<uint64_t> jac(count * 12);
-        BZH_HIP_TRY(ctx, hipMemcpyAsync(jac.data(), d_out, count * 96, hipMemcpyDeviceToHost, st));
-        BZH_HIP_TRY(ctx, hipStreamSynchronize(st));
+        PV_TRY(d2h_async(ctx, jac.data(), d_out, count * 96));
+        PV_TRY(d2h_finish(ctx));
         // Jacobian (Montgomery) -> affine canonical, one inversion
         std::vector<Fe<PB>> pre(count + 1);
         pre[0] = fe_one<PB>();
@@ -1007,8 +1034,8 @@ struct Prover {
         if (!xs || !res) return BZH_E_OOM;
         PV_TRY(upload(xs, points.data(), count));
         PV_TRY(poly_eval(ctx, field, stacked, n, count, xs, 1, res));
-        BZH_HIP_TRY(ctx, hipMemcpyAsync(out.data(), res, count * 32, hipMemcpyDeviceToHost, st));
-        BZH_HIP_TRY(ctx, hipStreamSynchronize(st));
+        PV_TRY(d2h_async(ctx, out.data(), res, count * 32));
+        PV_TRY(d2h_finish(ctx));
         return BZH_OK;
     }
 
@@ -1072,6 +1099,7 @@ int Prover<C>::prove(const uint32_t* d_advice_in, const uint64_t* instances, siz
         bzh_transcript_common_scalar(T[b], pk.vk_repr);
     }
 
+    mark("setup");
     // ---- instance columns ----------------------------------------------------------------------
     uint32_t* inst = dalloc(B * std::max(ni, 1) * n);
     uint32_t* inst_polys = dalloc(B * std::max(ni, 1) * n);
@@ -1093,6 +1121,7 @@ int Prover<C>::prove(const uint32_t* d_advice_in, const uint64_t* instances, siz
             for (int i = 0; i < ni; i++) bzh_transcript_common_point(T[b], &xy[(b * ni + i) * 8]);
     }
 
+    mark("instance");
     // ---- advice columns ------------------------------------------------------------------------
     uint32_t* adv = dalloc(B * na * n);
     uint32_t* adv_polys = dalloc(B * na * n);
@@ -1128,6 +1157,7 @@ int Prover<C>::prove(const uint32_t* d_advice_in, const uint64_t* instances, siz
         for (int i = 0; i < ni; i++) reg.add(key(K_INST, i), inst + (size_t)i * n * 8, (size_t)ni * n);
     };
 
+    mark("advice");
     // ---- lookups: compress, permute (host sort), commit -------------------------------------------
     struct Lk {
         uint32_t *a_c, *s_c, *as, *polys, *cosets;
@@ -1151,11 +1181,23 @@ int Prover<C>::prove(const uint32_t* d_advice_in, const uint64_t* instances, siz
                 return ep.horner(terms, ep.sym(SY_THETA));
             }, reg, n, side ? d.s_c : d.a_c));
         }
-        std::vector<uint64_t> ah(B * n * 4), sh(B * n * 4), pa(B * usable * 4), ps(B * usable * 4);
-        BZH_HIP_TRY(ctx, hipMemcpyAsync(ah.data(), d.a_c, B * n * 32, hipMemcpyDeviceToHost, st));
-        BZH_HIP_TRY(ctx, hipMemcpyAsync(sh.data(), d.s_c, B * n * 32, hipMemcpyDeviceToHost, st));
+        // compressed columns come back through pinned memory; the permuted pair is assembled in a pinned slot in the
+        // device layout (B, 2, n) (rows past `usable` zero until the blinding rows land) and goes up in one piece
+        char *ah_c = nullptr, *sh_c = nullptr, *as_c = nullptr;
+        PV_TRY(pin_big_reserve(ctx, 4 * B * n * 32 + ((size_t)3 << 20)));
+        PV_TRY(pin_big_take(ctx, B * n * 32, &ah_c));
+        PV_TRY(pin_big_take(ctx, B * n * 32, &sh_c));
+        PV_TRY(pin_big_take(ctx, B * 2 * n * 32, &as_c));
+        PV_TRY(xfer_launch(ctx, ah_c, d.a_c, B * n * 32, hipMemcpyDeviceToHost));
+        PV_TRY(xfer_launch(ctx, sh_c, d.s_c, B * n * 32, hipMemcpyDeviceToHost));
         BZH_HIP_TRY(ctx, hipStreamSynchronize(st));
+        const uint64_t* ah = (const uint64_t*)ah_c;
+        const uint64_t* sh = (const uint64_t*)sh_c;
+        mark(" lk:compress+d2h");
         PV_TRY(extend_witness());
+        mark(" lk:extend_witness");
+        uint64_t* as = (uint64_t*)as_c;
+        for (size_t v = 0; v < 2 * B; v++) memset(as + (v * n + usable) * 4, 0, (n - usable) * 32);
         {  // one sort per proof on host threads
             const size_t nthreads = std::min<size_t>(B, std::max(1u, std::thread::hardware_concurrency()));
             std::vector<int> rcs(B, BZH_OK);
@@ -1164,16 +1206,15 @@ int Prover<C>::prove(const uint32_t* d_advice_in, const uint64_t* instances, siz
                 th.emplace_back([&, t]() {
                     for (size_t b = t; b < B; b += nthreads)
                         rcs[b] = bzh_permute_expression_pair(field, &ah[b * n * 4], &sh[b * n * 4], usable, BZH_FORM_MONTGOMERY,
-                                                             &pa[b * usable * 4], &ps[b * usable * 4]);
+                                                             as + (b * 2) * n * 4, as + (b * 2 + 1) * n * 4);
                 });
             for (auto& t : th) t.join();
             for (int rc : rcs)
                 if (rc) return rc;
         }
-        PV_TRY(zero(d.as, B * 2 * n));
-        BZH_HIP_TRY(ctx, hipMemcpy2DAsync(d.as, 2 * n * 32, pa.data(), usable * 32, usable * 32, B, hipMemcpyHostToDevice, st));
-        BZH_HIP_TRY(ctx, hipMemcpy2DAsync(d.as + n * 8, 2 * n * 32, ps.data(), usable * 32, usable * 32, B, hipMemcpyHostToDevice, st));
-        BZH_HIP_TRY(ctx, hipStreamSynchronize(st));  // pa / ps are locals
+        mark(" lk:sort");
+        PV_TRY(h2d_commit(ctx, d.as, as_c, B * 2 * n * 32));
+        mark(" lk:h2d");
         {
             uint32_t* rows = dalloc(B * 2 * bf1);
             if (!rows) return BZH_E_OOM;
@@ -1198,6 +1239,7 @@ int Prover<C>::prove(const uint32_t* d_advice_in, const uint64_t* instances, siz
         env[b][SY_GAMMA] = squeeze(b);
     }
 
+    mark("lookup");
     // ---- permutation and lookup grand products -----------------------------------------------------
     uint32_t* zs = dalloc(B * std::max(nz, 1) * n);
     uint32_t* z_polys = dalloc(B * std::max(nz, 1) * n);
@@ -1207,9 +1249,12 @@ int Prover<C>::prove(const uint32_t* d_advice_in, const uint64_t* instances, siz
     if (!zs || !z_polys || !z_cosets || !den || !zt) return BZH_E_OOM;
     std::vector<Fe<SF>> z_blinds(B * std::max(nz, 1));
     auto finish_product = [&](int slot, int prev_slot) -> int {
+        mark("  fp:exprs");
         PV_TRY(poly_batch_invert(ctx, field, den, B * n));
+        mark("  fp:invert");
         PV_TRY(poly_vec_mul(ctx, field, zt, den, B * n));
         PV_TRY(poly_prefix_product(ctx, field, zt, n, B));
+        mark("  fp:mul+scan");
         if (prev_slot >= 0)
             hipLaunchKernelGGL((k_scale_rows<SF>), dim3((unsigned)((n + 255) / 256), (unsigned)B), dim3(256), 0, st, zt, n,
                                zs + ((size_t)prev_slot * n + usable) * 8, (size_t)nz * n);
@@ -1246,6 +1291,7 @@ int Prover<C>::prove(const uint32_t* d_advice_in, const uint64_t* instances, siz
             }, reg, n, which == 0 ? den : zt));
         }
         PV_TRY(finish_product(i, i ? i - 1 : -1));
+        mark(" gp:perm_set");
     }
     for (int li = 0; li < nl; li++) {
         Cols reg;
@@ -1260,13 +1306,16 @@ int Prover<C>::prove(const uint32_t* d_advice_in, const uint64_t* instances, siz
             return ep.mul(ep.add(ep.query(2), ep.sym(SY_BETA)), ep.add(ep.query(3), ep.sym(SY_GAMMA)));
         }, reg, n, den));
         PV_TRY(finish_product(nsets + li, -1));
+        mark(" gp:lookup_product");
     }
     if (nz) {
         PV_TRY(to_coeff(z_polys, zs, B * nz));
         PV_TRY(commit(z_polys, n, B * nz, z_blinds, xy));
         for (size_t b = 0; b < B; b++)
             for (int i = 0; i < nz; i++) bzh_transcript_write_point(T[b], C::id, &xy[(b * nz + i) * 8]);
+        mark(" gp:commit");
         PV_TRY(to_extended(z_cosets, z_polys, B * nz));
+        mark(" gp:extend_z");
     }
     for (auto& d : lk) {
         d.cosets = dalloc(B * 2 * en);
@@ -1274,6 +1323,7 @@ int Prover<C>::prove(const uint32_t* d_advice_in, const uint64_t* instances, siz
         PV_TRY(to_extended(d.cosets, d.polys, B * 2));
     }
 
+    mark("grand_products");
     // ---- vanishing argument ----------------------------------------------------------------------
     uint32_t* random_poly = dalloc(B * n);
     if (!random_poly) return BZH_E_OOM;
@@ -1295,6 +1345,7 @@ int Prover<C>::prove(const uint32_t* d_advice_in, const uint64_t* instances, siz
             bd = fe_mul(bd, delta);
         }
     }
+    mark("vanishing_setup");
     const int last_rot = -(bf + 1);
     uint32_t* h = dalloc(B * en);
     if (!h) return BZH_E_OOM;
@@ -1374,7 +1425,7 @@ int Prover<C>::prove(const uint32_t* d_advice_in, const uint64_t* instances, siz
         const size_t words = (en - (size_t)npieces * n) * 8;
         hipLaunchKernelGGL(k_any_nonzero, dim3((unsigned)((words + 255) / 256), (unsigned)B), dim3(256), 0, st,
                            h + (size_t)npieces * n * 8, words, en * 8, d_flag);
-        BZH_HIP_TRY(ctx, hipMemcpyAsync(&h_flag, d_flag, 4, hipMemcpyDeviceToHost, st));  // read after the commit's sync
+        PV_TRY(d2h_async(ctx, &h_flag, d_flag, 4));  // lands at the commit's d2h_finish
     }
     std::vector<Fe<SF>> h_blinds(B * npieces);
     for (size_t b = 0; b < B; b++)
@@ -1410,6 +1461,7 @@ int Prover<C>::prove(const uint32_t* d_advice_in, const uint64_t* instances, siz
         return fe_mul(xs[b], it->second);
     };
 
+    mark("quotient+h_commit");
     // ---- evaluations: one gather of (polynomial, rotation) jobs ----------------------------------------
     // where each committed polynomial lives: (pointer of proof 0, elements between proofs)
     std::map<uint64_t, std::pair<const uint32_t*, size_t>> where;
@@ -1475,6 +1527,7 @@ int Prover<C>::prove(const uint32_t* d_advice_in, const uint64_t* instances, siz
             for (size_t j = 0; j < J; j++) write_scalar(b, vals[b * J + j]);
     }
 
+    mark("evaluations");
     // ---- h(X) = sum_i x^(n i) h_i(X): Horner from the top piece ---------------------------------------
     uint32_t* h_poly = dalloc(B * n);
     if (!h_poly) return BZH_E_OOM;
@@ -1495,6 +1548,7 @@ int Prover<C>::prove(const uint32_t* d_advice_in, const uint64_t* instances, siz
     }
     where[key(K_MISC, M_H0)] = {h_poly, n};
 
+    mark("h_poly");
     // ---- multiopen ------------------------------------------------------------------------------
     auto blind_of = [&](size_t b, uint64_t cid) -> Fe<SF> {
         const int kind = (int)(cid >> 32);
@@ -1633,6 +1687,7 @@ int Prover<C>::prove(const uint32_t* d_advice_in, const uint64_t* instances, siz
             }
             PV_TRY(copy2d(f_parts + si * n * 8, nq * n, cur, len, len, B));
         }
+        mark("multiopen_q_kate");
         // f = sum_si x2^(..) f_si (Horner), commit, x3, q evaluations, x4, the opened polynomial
         uint32_t* f_poly = dalloc(B * n);
         uint32_t* p_poly = dalloc(B * n);
@@ -1680,6 +1735,7 @@ int Prover<C>::prove(const uint32_t* d_advice_in, const uint64_t* instances, siz
             h_store<SF>(&p_blinds[4 * b], fe_from_mont(acc));
             h_store<SF>(&x3c[4 * b], fe_from_mont(x3s[b]));
         }
+        mark("multiopen_f_p");
         // the opening draws from each proof's own cursor: a zero stride is not possible, so pass proof 0's cursor and the
         // common distance between the per-proof streams
         const size_t need = 64 * (n + 1 + 2 * (size_t)pk.k);
@@ -1687,6 +1743,7 @@ int Prover<C>::prove(const uint32_t* d_advice_in, const uint64_t* instances, siz
         for (size_t b = 0; b < B; b++) memcpy(&ipa_rng[b * need], rng[b], need);
         PV_TRY(ipa_open(ctx, pk.srs, p_poly, B, p_blinds.data(), x3c.data(), ipa_rng.data(), need, T.data(), out_v.data()));
     }
+    mark("ipa");
     for (size_t b = 0; b < B; b++) {
         const uint8_t* data = nullptr;
         size_t plen = 0;

@@ -39,6 +39,29 @@ import bzh2  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
+def pin_to_gpu_numa(local_rank):
+    """Run this rank's host threads on the CPU socket its GPU hangs off (two-socket hosts: a prover thread on the far
+    socket pays for every launch, challenge upload and commitment read-back across the socket link).  Threads created
+    afterwards inherit the mask.  Returns the NUMA node, or None when the topology cannot be read."""
+    try:
+        pr = torch.cuda.get_device_properties(local_rank)
+        bus = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % bus).read())
+        if node < 0:
+            return None
+        cpus = set()
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if cpus:
+            os.sched_setaffinity(0, cpus)
+            return node
+    except Exception:
+        pass
+    return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -52,6 +75,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=1,
                     help="proof_k* workloads: proofs advanced in lockstep per step (bzh2/prover_batch.py: one launch per kernel "
                          "class per phase for the whole batch); 1 = the single-proof latency path (bzh2/prover_dev.py)")
+    ap.add_argument("--driver", default="native", choices=["native", "python"],
+                    help="proof_k* workloads: native = bzh_prove_batch (csrc/prove.hip, the C-ABI whole-proof entry point); "
+                         "python = the ctypes-level drivers bzh2/prover_dev.py (--batch 1) / bzh2/prover_batch.py")
     ap.add_argument("--window-bits", type=int, default=0, help="SRS window-table width (0: 8 for --batch 1, else the planner's)")
     ap.add_argument("--concurrency", type=int, default=1,
                     help="proof_k* workloads: independent proofs in flight per GPU (host threads, one ctx + stream each)")
@@ -89,7 +115,7 @@ def make_bases(ctx, curve, n, seed):
 class Workload:
     """Device-resident inputs + the list of library calls that make one step."""
 
-    def __init__(self, name, ctx, device, seed, precompute=True, concurrency=1, batch=1, window_bits=0):
+    def __init__(self, name, ctx, device, seed, precompute=True, concurrency=1, batch=1, window_bits=0, driver="native"):
         self.name, self.ctx = name, ctx
         gen = torch.Generator(device=device)
         gen.manual_seed(seed)
@@ -142,8 +168,12 @@ class Workload:
             as_pt = lambda a: (bzh2.limbs_to_int(a[:4]), bzh2.limbs_to_int(a[4:]))
             g = [as_pt(a) for a in pts]
             wb = window_bits or (8 if batch == 1 else 0)
-            self.pk = D.DeviceProvingKey(ctx, circ, self.curve, g[:n], g[n + 1], g[n], device, window_bits=wb)
             self.window_bits = wb
+            self.driver = driver
+            if driver == "native":
+                self._setup_native(ctx, device, circ, adv, inst, g, n, seed, batch, concurrency, wb)
+                return
+            self.pk = D.DeviceProvingKey(ctx, circ, self.curve, g[:n], g[n + 1], g[n], device, window_bits=wb)
             self.adv_dev = [self.pk.ops.upload(col) for col in adv]
             self.inst = inst
             self.circ = circ
@@ -258,6 +288,58 @@ class Workload:
         else:
             raise ValueError(name)
 
+    def _setup_native(self, ctx, device, circ, adv, inst, g, n, seed, batch, concurrency, wb):
+        """proof_k* through bzh_pk_create / bzh_prove_batch: `concurrency` host threads, each with its own ctx + stream +
+        proving key, each proving `batch` witnesses per step in lockstep; witness tensor resident in HBM."""
+        import threading
+        from bzh2 import native as N
+        from bzh2.device import DeviceOps
+        self.workers = []
+        self.npks = []
+        for wi in range(concurrency):
+            if wi == 0:
+                st, wctx = None, ctx
+            else:
+                st = torch.cuda.Stream(device=device)
+                wctx = bzh2.Context(device.index or 0, stream=st.cuda_stream)
+            self.npks.append(N.NativeProvingKey(wctx, circ, self.curve, g[:n], g[n + 1], g[n], window_bits=wb))
+            self.workers.append((st, self.npks[-1]))
+        ops = DeviceOps(ctx, self.field, self.curve, self.npks[0].p, device)
+        adv_b = torch.stack([ops.upload(list(col) + [0] * (n - len(col))) for col in adv]).unsqueeze(0).repeat(batch, 1, 1, 1).contiguous()
+        torch.cuda.synchronize(device)
+        self.adv_b = adv_b
+        nbytes = self.npks[0].rng_bytes
+        self.rng_pool = [np.random.default_rng(seed + 100 + i).bytes(nbytes) for i in range(batch * concurrency + 3)]
+        self.step_no = 0
+        self.last_proof = b""
+        self.distinct = 0
+        self.units_per_step = batch * concurrency
+        self.inst = inst
+
+        def prove_one(wi, sn):
+            rbs = [self.rng_pool[(sn + wi * batch + b) % len(self.rng_pool)] for b in range(batch)]
+            proofs = self.workers[wi][1].prove_batch(None, [self.inst] * batch, rbs, device_ptr=adv_b.data_ptr())
+            if wi == 0:
+                self.last_proof = proofs[0]
+                self.distinct = len(set(proofs))
+
+        def prove():
+            sn = self.step_no
+            self.step_no += 1
+            ths = [threading.Thread(target=prove_one, args=(wi, sn)) for wi in range(1, concurrency)]
+            for t in ths:
+                t.start()
+            prove_one(0, sn)
+            for t in ths:
+                t.join()
+        self.calls = [("bzh_prove_batch", prove)]
+        self.alg_bytes_msm_launch = 0
+        self.alg_bytes_step = 0
+        self.desc = {"k": self.k, "circuit": "synthetic, BattleZips-shaped: 11 advice / 8 fixed / 1 instance, 24 gates, degree 9, "
+                                            "13 permutation columns, one 10-bit lookup (bzh2/synth.py)",
+                     "proof_bytes": None, "driver": "native (bzh_prove_batch)"}
+        self.result = torch.zeros((1, 12), dtype=torch.int64, device=device)
+
     def step(self):
         for _, fn in self.calls:
             fn()
@@ -315,6 +397,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
+    numa_node = pin_to_gpu_numa(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
@@ -325,7 +408,7 @@ def main():
     stream = torch.cuda.current_stream(device)
     ctx = bzh2.Context(local_rank, stream=stream.cuda_stream)
     wl = Workload(args.workload, ctx, device, seed=1234 + rank, precompute=not args.no_precompute, concurrency=args.concurrency, batch=args.batch,
-                  window_bits=args.window_bits)
+                  window_bits=args.window_bits, driver=args.driver)
 
     def barrier():
         torch.cuda.synchronize(device)
@@ -337,6 +420,7 @@ def main():
         wl.step()
     barrier()
     all_ctx = [ctx] + [w[1].ctx for w in getattr(wl, "workers", []) if w[0] is not None]
+    all_ctx = list({id(c): c for c in all_ctx}.values())
     for c in all_ctx:
         c.profile(True)
     t0 = time.perf_counter()
@@ -414,6 +498,7 @@ def main():
                          "algorithmic_bytes_per_launch": alg, "avg_launch_ms": dom_ms},
             "kernel_ms": {kname: v for kname, v in timings.items() if v["launches"]},
         }
+        line["config"]["host_threads_pinned_to_numa_node"] = numa_node
         if is_full:
             line["config"]["stages"] = ("complete create_proof: commitments, lookup, permutation, vanishing, quotient, evaluations, "
                                         "multiopen, IPA, transcript; witness synthesis excluded (columns resident in HBM)")
@@ -422,7 +507,7 @@ def main():
             line["config"]["concurrent_batches"] = args.concurrency
             line["config"]["batch"] = args.batch
             line["config"]["srs_window_bits"] = wl.window_bits or "planner"
-            if args.batch > 1:
+            if args.batch > 1 or args.driver == "native":
                 line["config"]["distinct_proofs_in_last_batch"] = wl.distinct
         if world == 1 and (is_proof or is_full) and not args.no_cpu_baseline and args.workload != "shot_k11_batch":
             line["cpu_baseline"] = cpu_baseline(args.workload, wl.k)

@@ -81,7 +81,7 @@ def test_native_prover_battlezips_shaped_and_unsatisfied_witness(gpu_ctx, oracle
         adv = np.stack([_adv_array(built[b][1], cs.n) for b in range(2)])
         assert pk.prove_batch(adv, [built[b][2] for b in range(2)], rbs) == want
         bad = adv.copy()
-        bad[1, 6, 3, 0] ^= 1                   # flip one bit cell of the second witness: breaks its running sum
+        bad[1, 2, 0, 0] ^= 1                   # a2 of a multiplication row of the second witness: a0 * a1 != a2
         try:
             proofs = pk.prove_batch(bad, [built[b][2] for b in range(2)], rbs)
         except bzh2.BzhError as e:
