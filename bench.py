@@ -1,14 +1,17 @@
 #!/usr/bin/env python3
 """bench.py -- halo2 create_proof on MI355X through libbzh2.so.
 
-Default workload `proof_k14` (BASELINE.json configs[1]: single BoardCircuit-sized proof, k=14, IPA/Pasta):
-one "step" = ONE COMPLETE create_proof (bzh2/prover_dev.py) of a circuit with the reference's Board/Shot
-shape (bzh2/synth.py: 11 advice / 8 fixed / 1 instance columns, 24 gates, degree 9, 13 permutation columns,
-one 10-bit lookup): column commitments, lookup permute + grand product, permutation grand products, vanishing
-argument (quotient over the 8n coset), evaluations, multiopen and the IPA opening, transcript included.
-Witness columns are synthetic and resident in HBM before the timed region starts; the proof bytes come back
-to the host inside it.  `--concurrency C` keeps C independent proofs in flight per GPU (host threads, one
-ctx + HIP stream each; proofs are independent, no data is shared but the read-only proving key).
+Default workload `proof_k14` (BASELINE.json configs[1..2]: BoardCircuit-sized proofs, k=14, IPA/Pasta, batched):
+one "step" = `--concurrency` host threads each proving `--batch` independent witnesses with ONE bzh_prove_batch call
+(csrc/prove.hip: the whole create_proof behind the C ABI, proofs advanced in lockstep so that every MSM, NTT, gate
+evaluation, scan and IPA round is one launch for the batch).  The circuit has the reference's Board/Shot shape
+(bzh2/synth.py: 11 advice / 8 fixed / 1 instance columns, 24 gates, degree 9, 13 permutation columns, one 10-bit
+lookup); a proof covers column commitments, lookup permute + grand product, permutation grand products, the
+vanishing argument (quotient over the 8n coset), evaluations, multiopen and the IPA opening, transcript included.
+Witness columns are synthetic and resident in HBM before the timed region starts; every proof draws its own blinding
+randomness and its bytes come back to the host inside the timed region.  Defaults: --batch 16 --concurrency 3
+(48 proofs per step).  `--batch 1 --concurrency 1` is the single-proof latency configuration.
+`--driver python` runs the ctypes-level drivers (bzh2/prover_dev.py, bzh2/prover_batch.py) instead.
 
 `board_k14` / `board_k12` / `shot_k11` / `board_k17` / `shot_k11_batch` time only the MSM + NTT schedule of
 such a proof (28 MSMs of n, 17 iNTT(n), 18 coset NTT(8n), 1 extended iNTT(8n));
@@ -16,7 +19,7 @@ such a proof (28 MSMs of n, 17 iNTT(n), 18 coset NTT(8n),
 
 roofline: the dominant kernel is k_msm_accumulate; `achieved` = the library's own count of algorithmic bytes
 (32 B per scalar + 64 B per base point per launch, bzh_ctx_work) / its HIP-event time on the launch stream
-(bzh_ctx_timings), both taken live over the timed region.
+(bzh_ctx_timings), both taken live over the timed region and summed over the host threads' contexts.
 
 Multi-GPU: one process per GPU (torchrun); proofs are independent, so every rank runs the same per-GPU
 workload (weak scaling) and the only collective is one RCCL all_gather of the ranks' outputs at the end of
@@ -72,14 +75,14 @@ def parse():
                              "proof_k11", "proof_k12", "proof_k14", "proof_k8"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-precompute", action="store_true", help="plain bases: no fixed-base window table for the SRS")
-    ap.add_argument("--batch", type=int, default=1,
+    ap.add_argument("--batch", type=int, default=16,
                     help="proof_k* workloads: proofs advanced in lockstep per step (bzh2/prover_batch.py: one launch per kernel "
                          "class per phase for the whole batch); 1 = the single-proof latency path (bzh2/prover_dev.py)")
     ap.add_argument("--driver", default="native", choices=["native", "python"],
                     help="proof_k* workloads: native = bzh_prove_batch (csrc/prove.hip, the C-ABI whole-proof entry point); "
                          "python = the ctypes-level drivers bzh2/prover_dev.py (--batch 1) / bzh2/prover_batch.py")
     ap.add_argument("--window-bits", type=int, default=0, help="SRS window-table width (0: 8 for --batch 1, else the planner's)")
-    ap.add_argument("--concurrency", type=int, default=1,
+    ap.add_argument("--concurrency", type=int, default=3,
                     help="proof_k* workloads: independent proofs in flight per GPU (host threads, one ctx + stream each)")
     return ap.parse_args()
 
@@ -319,9 +322,23 @@ class Workload:
         def prove_one(wi, sn):
             rbs = [self.rng_pool[(sn + wi * batch + b) % len(self.rng_pool)] for b in range(batch)]
             proofs = self.workers[wi][1].prove_batch(None, [self.inst] * batch, rbs, device_ptr=adv_b.data_ptr())
+            self.last_batch[wi] = proofs
             if wi == 0:
                 self.last_proof = proofs[0]
                 self.distinct = len(set(proofs))
+
+        self.last_batch = [[] for _ in range(concurrency)]
+        self.proof_stride = self.npks[0].max_proof_bytes
+
+        def proof_records():
+            """the last step's proofs of this rank as fixed-stride records {u32 length, bytes}: what the final gather carries"""
+            recs = bytearray()
+            for proofs in self.last_batch:
+                for pr in proofs:
+                    recs += len(pr).to_bytes(4, "little") + pr + bytes(self.proof_stride - len(pr))
+            a = np.frombuffer(bytes(recs), dtype=np.uint8).reshape(-1, 4 + self.proof_stride)
+            return torch.from_numpy(a.copy()).to(device)
+        self.records = proof_records
 
         def prove():
             sn = self.step_no
@@ -428,7 +445,9 @@ def main():
         wl.step()
     if dist is not None:  # the one collective: gather every rank's commitments (fixed-stride records)
         from bzh2.shard import gather_records
-        gathered = gather_records(wl.result, [wl.result.shape[0]] * world, dist)
+        local = wl.records() if hasattr(wl, "records") else wl.result  # complete proofs: the proof records themselves
+        gathered = gather_records(local, [local.shape[0]] * world, dist)
+        assert gathered.shape[0] == local.shape[0] * world
     barrier()
     elapsed = time.perf_counter() - t0
     timings = ctx.timings()
