@@ -433,16 +433,17 @@ __device__ __forceinline__ Xyzz<P> block_tree_sum(Xyzz<P> v, uint4* buf, int T) 
 
 template <class C>
 __global__ void __launch_bounds__(256) k_msm_reduce(const uint4* __restrict__ buckets, int M, int nclass, size_t spv,
-                                                      uint4* __restrict__ winsums) {
+                                                      size_t aseg_mult, uint4* __restrict__ winsums) {
     using P = typename C::Base;
     extern __shared__ __align__(16) uint32_t lds[];
     uint4* bufA = reinterpret_cast<uint4*>(lds);
     const int T = blockDim.x, tid = threadIdx.x;
     uint4* bufB = bufA + (size_t)T * 8;
     // accumulate segment blockIdx.x / nclass holds nclass bucket sets side by side in each plane
+    // (aseg_mult > 1: the chunks of a vector were pre-summed into its first segment, only that one is reduced)
     const size_t aseg = blockIdx.x / nclass, cls = blockIdx.x - aseg * nclass, MS = (size_t)M * nclass;
     const size_t segi = ((aseg / spv) * nclass + cls) * spv + aseg % spv;  // result vectors are class-major
-    const uint4* seg = buckets + aseg * MS * 8 + cls * M;
+    const uint4* seg = buckets + aseg * aseg_mult * MS * 8 + cls * M;
     const int L = M / T;  // host guarantees T <= M, both powers of two
 
     Xyzz<P> S = xyzz_identity<P>(), W = xyzz_identity<P>();
@@ -496,12 +497,12 @@ __device__ __forceinline__ Xyzz<P> xyzz_shfl_down(const Xyzz<P>& v, int d) {
 
 template <class C>
 __global__ void __launch_bounds__(64) k_msm_reduce_wave(const uint4* __restrict__ buckets, int M, int nclass, size_t spv,
-                                                         uint4* __restrict__ winsums) {
+                                                         size_t aseg_mult, uint4* __restrict__ winsums) {
     using P = typename C::Base;
     const int lane = threadIdx.x;
     const size_t aseg = blockIdx.x / nclass, cls = blockIdx.x - aseg * nclass, MS = (size_t)M * nclass;
     const size_t segi = ((aseg / spv) * nclass + cls) * spv + aseg % spv;
-    const uint4* seg = buckets + aseg * MS * 8 + cls * M;
+    const uint4* seg = buckets + aseg * aseg_mult * MS * 8 + cls * M;
     const int L = M >> 6;  // host guarantees M >= 64, a power of two
 
     Xyzz<P> S = xyzz_identity<P>(), W = xyzz_identity<P>();
@@ -528,6 +529,26 @@ __global__ void __launch_bounds__(64) k_msm_reduce_wave(const uint4* __restrict_
         if (lane < d) xyzz_add(W, o);
     }
     if (lane == 0) planes_put(winsums, (size_t)gridDim.x, segi, W);
+}
+
+// ---------------------------------------------------------------------------
+// k_msm_chunksum: bucket-wise sum of a vector's chunk segments into its first segment (grid: buckets x vectors,
+// one thread per bucket).  All lanes do useful additions, unlike the running-sum reduction, whose per-segment
+// cost this removes for every chunk but one: (nchunks - 1) additions per bucket here against 2 per bucket AND
+// per chunk there, plus its scan overhead.
+// ---------------------------------------------------------------------------
+template <class C>
+__global__ void __launch_bounds__(256) k_msm_chunksum(uint4* __restrict__ buckets, int MS, size_t nchunks) {
+    using P = typename C::Base;
+    const size_t m = blockIdx.x * (size_t)blockDim.x + threadIdx.x, v = blockIdx.y;
+    if (m >= (size_t)MS) return;
+    uint4* seg0 = buckets + v * nchunks * (size_t)MS * 8;
+    Xyzz<P> acc = planes_get<P>(seg0, (size_t)MS, m);
+    for (size_t ck = 1; ck < nchunks; ck++) {
+        const Xyzz<P> o = planes_get<P>(seg0 + ck * (size_t)MS * 8, (size_t)MS, m);
+        xyzz_add(acc, o);
+    }
+    planes_put(seg0, (size_t)MS, m, acc);
 }
 
 // ---------------------------------------------------------------------------
@@ -724,20 +745,33 @@ static int msm_run_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_sca
 #undef BZH_LAUNCH_ACC
         }
         const size_t nseg = nb * segs_per_vec;
+        bool presum = false;
         {
             ScopedTimer t(ctx, BZH_T_MSM_REDUCE);
-            if (p.M >= 64 && nseg * nclass >= 256) {
-                hipLaunchKernelGGL((k_msm_reduce_wave<C>), dim3((unsigned)(nseg * nclass)), dim3(64), 0, ctx->stream,
-                                   (const uint4*)d_buckets, p.M, nclass, segs_per_vec, (uint4*)d_winsums);
+            // many segments (throughput regime): sum the chunks of every vector bucket-wise first, then run the
+            // running-sum reduction once per vector instead of once per chunk
+            presum = acc_nwin == 1 && p.nchunks >= 2 && p.nchunks <= 32 && nseg * nclass >= 256;
+            size_t rseg = nseg, rspv = segs_per_vec, mult = 1;
+            if (presum) {
+                hipLaunchKernelGGL((k_msm_chunksum<C>), dim3((unsigned)((M_acc + 255) / 256), (unsigned)nb), dim3(256), 0, ctx->stream,
+                                   (uint4*)d_buckets, M_acc, p.nchunks);
+                rseg = nb;
+                rspv = 1;
+                mult = p.nchunks;
+            }
+            if (p.M >= 64 && rseg * nclass >= 256) {
+                hipLaunchKernelGGL((k_msm_reduce_wave<C>), dim3((unsigned)(rseg * nclass)), dim3(64), 0, ctx->stream,
+                                   (const uint4*)d_buckets, p.M, nclass, rspv, mult, (uint4*)d_winsums);
             } else {
-                hipLaunchKernelGGL((k_msm_reduce<C>), dim3((unsigned)(nseg * nclass)), dim3(red_threads), red_lds, ctx->stream,
-                                   (const uint4*)d_buckets, p.M, nclass, segs_per_vec, (uint4*)d_winsums);
+                hipLaunchKernelGGL((k_msm_reduce<C>), dim3((unsigned)(rseg * nclass)), dim3(red_threads), red_lds, ctx->stream,
+                                   (const uint4*)d_buckets, p.M, nclass, rspv, mult, (uint4*)d_winsums);
             }
         }
         {
             ScopedTimer t(ctx, BZH_T_MSM_FINALIZE);
+            const size_t fchunks = presum ? 1 : p.nchunks, fseg = presum ? nb : nseg;
             hipLaunchKernelGGL((k_msm_finalize<C>), dim3((unsigned)(nb * nclass)), dim3(64), 0, ctx->stream,
-                               (const uint4*)d_winsums, nseg * nclass, acc_nwin, p.nchunks, pre ? 0 : p.c, form,
+                               (const uint4*)d_winsums, fseg * nclass, acc_nwin, fchunks, pre ? 0 : p.c, form,
                                d_out + b0 * nclass * 24);
         }
         BZH_HIP_TRY(ctx, hipGetLastError());

@@ -196,3 +196,26 @@ def test_msm_precomputed_2_16_matches_oracle(gpu_ctx, oracle_c):
     bases = walk_bases(0, n, seed=16)
     sc = rand_scalars(rng, n, None)
     assert gpu_msm_compressed(bzh2, gpu_ctx, 0, bases, sc, precompute=0) == oracle_compressed(0, bases, sc)
+
+
+def test_msm_precomputed_many_vectors_chunk_presum(gpu_ctx, oracle_c):
+    """Throughput regime of the window-table MSM: 24 vectors of 2^14 + 2 scalars (an advice-commitment launch of a
+    lockstep proof batch) cut into >= 256 chunk segments, whose bucket sets are summed per vector before the
+    running-sum reduction (k_msm_chunksum).  Skewed vectors included; every result against the C oracle."""
+    import bzh2
+    rng = np.random.default_rng(141)
+    n, nvec = (1 << 14) + 2, 24
+    bases = walk_bases(0, n, seed=5)
+    hb = gpu_ctx.upload_bases(0, bases).precompute(11)
+    try:
+        r = O.VESTA.scalar.p
+        batch = np.stack([rand_scalars(rng, n, None) for _ in range(nvec)])
+        batch[3] = 0
+        batch[5] = C.ints_to_array([r - 1] * n)          # every digit identical
+        batch[7, : n // 2] = 0                           # half-empty vector: empty chunks
+        batch[9] = C.ints_to_array([(i % 2) for i in range(n)])
+        jac = gpu_ctx.msm(hb, batch)
+        got = bzh2.affine_compress(0, bzh2.jacobian_to_affine(0, jac))
+        assert got == oracle_compressed(0, bases, batch)
+    finally:
+        hb.free()
