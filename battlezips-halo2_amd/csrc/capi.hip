@@ -635,13 +635,16 @@ int bzh_expr_eval_batch(bzh_ctx* ctx, int field, const bzh_expr_op* prog, size_t
                       result_slot < 0 || result_slot >= BZH_EXPR_MAX_SLOTS || !batch || batch > 65535 ||
                       (const_stride && const_stride < nconsts));
     const size_t size = (size_t)1 << log_size;
+    int nslots = result_slot + 1;
     for (size_t i = 0; i < nops; i++) {  // validate the program: it indexes device memory
         const bzh_expr_op& o = prog[i];
         if (o.op > BZH_EXPR_COPY || o.dst >= BZH_EXPR_MAX_SLOTS) return BZH_E_ARG;
+        nslots = std::max(nslots, (int)o.dst + 1);
         const int kinds[2] = {o.a_kind, (o.op == BZH_EXPR_NEG || o.op == BZH_EXPR_COPY) ? BZH_EXPR_SLOT : o.b_kind};
         const int idxs[2] = {o.a_idx, (o.op == BZH_EXPR_NEG || o.op == BZH_EXPR_COPY) ? 0 : o.b_idx};
         for (int q = 0; q < 2; q++) {
             if (kinds[q] == BZH_EXPR_SLOT && (idxs[q] < 0 || idxs[q] >= BZH_EXPR_MAX_SLOTS)) return BZH_E_ARG;
+            if (kinds[q] == BZH_EXPR_SLOT) nslots = std::max(nslots, idxs[q] + 1);
             if (kinds[q] == BZH_EXPR_COLUMN && (idxs[q] < 0 || (size_t)idxs[q] >= ncols)) return BZH_E_ARG;
             if (kinds[q] == BZH_EXPR_CONST && (idxs[q] < 0 || (size_t)idxs[q] >= nconsts)) return BZH_E_ARG;
             if (kinds[q] > BZH_EXPR_CONST || kinds[q] < 0) return BZH_E_ARG;
@@ -686,7 +689,7 @@ int bzh_expr_eval_batch(bzh_ctx* ctx, int field, const bzh_expr_op* prog, size_t
     if (ncols && (rc = h2d_small(ctx, d_strides, strides.data(), ncols * sizeof(size_t)))) return rc;
     uint32_t* d_out = mem == BZH_MEM_HOST ? s.carve(batch * size * 32) : (uint32_t*)out;
     rc = expr_eval(ctx, field, d_prog, (int)nops, (const uint32_t* const*)d_ptrs, (const size_t*)d_strides, d_consts, const_stride, size,
-                   result_slot, batch, d_out);
+                   result_slot, batch, nslots, d_out);
     if (rc) return rc;
     if (mem == BZH_MEM_HOST) return s.out(out, d_out, batch * size);
     return BZH_OK;  // staging reuse by the next call is stream-ordered

@@ -260,7 +260,7 @@ int poly_vec_mul(bzh_ctx* ctx, int field, uint32_t* a, const uint32_t* b, size_t
 int poly_kate_division(bzh_ctx* ctx, int field, const uint32_t* d_c, size_t n, size_t batch, const uint32_t* d_xs, uint32_t* d_q);
 // exprvm.hip
 int expr_eval(bzh_ctx* ctx, int field, const void* d_prog, int nops, const uint32_t* const* d_cols, const size_t* d_strides,
-              const uint32_t* d_consts, size_t const_stride, size_t size, int result_slot, size_t batch, uint32_t* d_out);
+              const uint32_t* d_consts, size_t const_stride, size_t size, int result_slot, size_t batch, int nslots, uint32_t* d_out);
 // ipa.hip
 int random_field(bzh_ctx* ctx, int field, const uint32_t* d_raw, size_t count, uint32_t* d_out);
 int ipa_open(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_polys, size_t batch, const uint64_t* blinds,

@@ -1078,8 +1078,10 @@ struct Prover {
         PV_TRY(h2d_small(ctx, d_prog, pg.ops.data(), pg.ops.size() * sizeof(bzh_expr_op)));
         PV_TRY(h2d_small(ctx, d_ptrs, reg.ptr.data(), ncols * 8));
         PV_TRY(h2d_small(ctx, d_strides, reg.stride.data(), ncols * 8));
+        int nslots = pg.result_slot + 1;
+        for (auto& o : pg.ops) nslots = std::max(nslots, (int)o.dst + 1);  // operands only read slots written before
         return expr_eval(ctx, field, d_prog, (int)pg.ops.size(), (const uint32_t* const*)d_ptrs, (const size_t*)d_strides, d_consts,
-                         per_proof ? nc : 0, size, pg.result_slot, B, d_out);
+                         per_proof ? nc : 0, size, pg.result_slot, B, nslots, d_out);
     }
 
     int prove(const uint32_t* d_advice_in, const uint64_t* instances, size_t inst_rows, uint8_t* proofs, size_t proof_stride,

@@ -9,8 +9,8 @@ evaluation, scan and IPA round is one launch for the batch).  The circuit has th
 lookup); a proof covers column commitments, lookup permute + grand product, permutation grand products, the
 vanishing argument (quotient over the 8n coset), evaluations, multiopen and the IPA opening, transcript included.
 Witness columns are synthetic and resident in HBM before the timed region starts; every proof draws its own blinding
-randomness and its bytes come back to the host inside the timed region.  Defaults: --batch 16 --concurrency 3
-(48 proofs per step).  `--batch 1 --concurrency 1` is the single-proof latency configuration.
+randomness and its bytes come back to the host inside the timed region.  Defaults: --batch 16 --concurrency 4
+(64 proofs per step).  `--batch 1 --concurrency 1` is the single-proof latency configuration.
 `--driver python` runs the ctypes-level drivers (bzh2/prover_dev.py, bzh2/prover_batch.py) instead.
 
 `board_k14` / `board_k12` / `shot_k11` / `board_k17` / `shot_k11_batch` time only the MSM + NTT schedule of
@@ -82,7 +82,7 @@ def parse():
                     help="proof_k* workloads: native = bzh_prove_batch (csrc/prove.hip, the C-ABI whole-proof entry point); "
                          "python = the ctypes-level drivers bzh2/prover_dev.py (--batch 1) / bzh2/prover_batch.py")
     ap.add_argument("--window-bits", type=int, default=0, help="SRS window-table width (0: 8 for --batch 1, else the planner's)")
-    ap.add_argument("--concurrency", type=int, default=3,
+    ap.add_argument("--concurrency", type=int, default=4,
                     help="proof_k* workloads: independent proofs in flight per GPU (host threads, one ctx + stream each)")
     return ap.parse_args()
 
