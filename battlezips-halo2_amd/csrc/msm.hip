@@ -625,6 +625,286 @@ __global__ void __launch_bounds__(256) k_expand_bases(uint32_t* __restrict__ tab
 }
 
 // ---------------------------------------------------------------------------
+// Global-sort path for window-table MSMs in the many-vector regime (msm_run_t: use_gs).
+// The LDS-chunk kernel above keeps one bucket set PER CHUNK and pays for it in the reduction (chunk pre-sum +
+// running sums: as expensive as the accumulation once c > 11).  Here a vector's items are sorted by bucket ONCE,
+// across chunks (histogram per chunk -> offsets per (bucket, chunk) -> scatter), so that there is one bucket set per
+// vector, the reduction shrinks by the chunk count and wider windows (fewer table rows = fewer additions) pay off.
+//   k_gs_hist     per (chunk, vector): LDS histogram of the chunk's digits                 -> hist[b][ck][m]
+//   k_gs_scan     per vector: bucket ends E[m], offsets hist[b][ck][m] := start of (m, ck), identity for empty buckets
+//   k_gs_scatter  per (chunk, vector): item index | sign << 31 to sorted[b][position]
+//   k_gs_accumulate per (region, vector): the equal-slice accumulation of k_msm_accumulate over its region of the
+//                 sorted list; buckets cut by REGION boundaries leave a head / tail partial per workgroup
+//   k_gs_stitch   per vector: joins those workgroup partials (a handful per vector)
+// ---------------------------------------------------------------------------
+template <int T>
+__global__ void __launch_bounds__(T) k_gs_hist(const uint16_t* __restrict__ digits, size_t n_eff, size_t chunk, int M,
+                                                uint32_t* __restrict__ hist) {
+    extern __shared__ __align__(16) uint32_t lds[];
+    uint32_t* cnt = lds;  // [0, M]
+    const int tid = threadIdx.x;
+    const size_t ck = blockIdx.x, b = blockIdx.y, nchunks = gridDim.x;
+    const size_t c0 = ck * chunk;
+    const int len = (int)min(chunk, n_eff - c0);
+    const uint16_t* dg = digits + b * n_eff + c0;
+    for (int i = tid; i <= M; i += T) cnt[i] = 0;
+    __syncthreads();
+    const bool vec_ok = (reinterpret_cast<uintptr_t>(dg) & 15u) == 0;
+    const int nvec = vec_ok ? (len >> 3) : 0;
+    for (int v = tid; v < nvec; v += T) {
+        const uint4 d4 = reinterpret_cast<const uint4*>(dg)[v];
+        const uint32_t w4[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t m0 = w4[k] & 0x7fffu, m1 = (w4[k] >> 16) & 0x7fffu;
+            if (m0) atomicAdd(&cnt[m0], 1u);
+            if (m1) atomicAdd(&cnt[m1], 1u);
+        }
+    }
+    for (int i = nvec * 8 + tid; i < len; i += T) {
+        const uint32_t m = dg[i] & 0x7fffu;
+        if (m) atomicAdd(&cnt[m], 1u);
+    }
+    __syncthreads();
+    uint32_t* out = hist + (b * nchunks + ck) * (size_t)(M + 1);
+    for (int i = tid; i <= M; i += T) out[i] = cnt[i];
+}
+
+// one workgroup per vector.  ends[b][m] = end of bucket m in the sorted list (ends[b][0] = 0, ends[b][M] = item count);
+// hist[b][ck][m] becomes the first position of chunk ck's share of bucket m; maxpop[b] = largest bucket; empty buckets
+// are set to the identity here (k_gs_accumulate only writes buckets that hold items).
+template <class C>
+__global__ void __launch_bounds__(1024) k_gs_scan(uint32_t* __restrict__ hist, size_t nchunks, int M, uint32_t* __restrict__ ends,
+                                                   uint32_t* __restrict__ maxpop, uint4* __restrict__ buckets) {
+    using P = typename C::Base;
+    extern __shared__ __align__(16) uint32_t lds[];
+    uint32_t* tot = lds;  // [0, M]: bucket populations, then (exclusive scan) bucket starts
+    uint32_t* scratch = lds + (M + 2);
+    const int tid = threadIdx.x, T = blockDim.x;
+    const size_t b = blockIdx.x, hs = (size_t)(M + 1);
+    uint32_t* h = hist + b * nchunks * hs;
+    if (tid == 0) scratch[31] = 0;
+    __syncthreads();
+    uint32_t mx = 0;
+    for (int m = tid; m <= M; m += T) {
+        uint32_t run = 0;
+        for (size_t ck = 0; ck < nchunks; ck++) {
+            const uint32_t v = h[ck * hs + m];
+            h[ck * hs + m] = run;  // exclusive prefix over the chunks
+            run += v;
+        }
+        tot[m] = run;
+        if (m == M) scratch[30] = run;
+        if (m) mx = max(mx, run);
+    }
+    for (int d = 32; d >= 1; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
+    if ((tid & 63) == 0) atomicMax(&scratch[31], mx);
+    __syncthreads();
+    uint4* bk = buckets + b * (size_t)M * 8;
+    for (int m = 1 + tid; m <= M; m += T)
+        if (tot[m] == 0) planes_put(bk, (size_t)M, (size_t)(m - 1), xyzz_identity<P>());
+    const uint32_t maxp = scratch[31], last_pop = scratch[30];
+    __syncthreads();
+    block_exclusive_scan(tot, M + 1, scratch);  // tot[m] = first position of bucket m (bucket 0 holds nothing)
+    uint32_t* e = ends + b * hs;
+    for (int m = tid; m <= M; m += T) {
+        const uint32_t base = tot[m];
+        for (size_t ck = 0; ck < nchunks; ck++) h[ck * hs + m] += base;
+        e[m] = m < M ? tot[m + 1] : base + last_pop;
+    }
+    if (tid == 0) maxpop[b] = maxp;
+}
+
+template <int T>
+__global__ void __launch_bounds__(T) k_gs_scatter(const uint16_t* __restrict__ digits, size_t n_eff, size_t chunk, int M,
+                                                   const uint32_t* __restrict__ hist, uint32_t* __restrict__ sorted) {
+    extern __shared__ __align__(16) uint32_t lds[];
+    uint32_t* cnt = lds;  // next free position of every bucket for this chunk
+    const int tid = threadIdx.x;
+    const size_t ck = blockIdx.x, b = blockIdx.y, nchunks = gridDim.x;
+    const size_t c0 = ck * chunk;
+    const int len = (int)min(chunk, n_eff - c0);
+    const uint16_t* dg = digits + b * n_eff + c0;
+    const uint32_t* off = hist + (b * nchunks + ck) * (size_t)(M + 1);
+    for (int i = tid; i <= M; i += T) cnt[i] = off[i];
+    __syncthreads();
+    uint32_t* srt = sorted + b * n_eff;
+    const bool vec_ok = (reinterpret_cast<uintptr_t>(dg) & 15u) == 0;
+    const int nvec = vec_ok ? (len >> 3) : 0;
+    for (int v = tid; v < nvec; v += T) {
+        const uint4 d4 = reinterpret_cast<const uint4*>(dg)[v];
+        const uint32_t w4[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t d = (w4[k >> 1] >> ((k & 1) * 16)) & 0xffffu, m = d & 0x7fffu;
+            if (m) {
+                const uint32_t pos = atomicAdd(&cnt[m], 1u);
+                srt[pos] = (uint32_t)(c0 + (size_t)(v * 8 + k)) | ((d & 0x8000u) << 16);
+            }
+        }
+    }
+    for (int i = nvec * 8 + tid; i < len; i += T) {
+        const uint32_t d = dg[i], m = d & 0x7fffu;
+        if (m) {
+            const uint32_t pos = atomicAdd(&cnt[m], 1u);
+            srt[pos] = (uint32_t)(c0 + (size_t)i) | ((d & 0x8000u) << 16);
+        }
+    }
+}
+
+// grid (regions, vectors).  Region w of a vector covers sorted positions [w * Lw, (w+1) * Lw); inside it the T threads
+// take equal slices exactly as in k_msm_accumulate.  wg_head / wg_tail: one XYZZ value per (vector, region) each
+// (planes of stride regions * vectors), ids in wg_ids[(b * regions + w) * 2 + {0: head, 1: tail}] (0 = none).
+template <class C, int T>
+__global__ void __launch_bounds__(T) k_gs_accumulate(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
+                                                      const uint32_t* __restrict__ ends, const uint32_t* __restrict__ maxpops,
+                                                      size_t n_eff, int M, uint4* __restrict__ buckets, uint4* __restrict__ partials,
+                                                      uint4* __restrict__ wg_head, uint4* __restrict__ wg_tail,
+                                                      uint32_t* __restrict__ wg_ids, size_t row_len, size_t row_stride,
+                                                      size_t dup_from) {
+    using P = typename C::Base;
+    __shared__ uint32_t idB[T];
+    extern __shared__ __align__(16) uint32_t sl[];  // the region's slice of the sorted list (coalesced load, strided use)
+    const int tid = threadIdx.x;
+    const size_t w = blockIdx.x, b = blockIdx.y, nreg = gridDim.x, nwg_total = (size_t)gridDim.x * gridDim.y;
+    const size_t wgi = b * nreg + w;
+    const uint32_t* cnt = ends + b * (size_t)(M + 1);  // cnt[m] = end of bucket m, cnt[0] = 0
+    const uint32_t* srt = sorted + b * n_eff;
+    uint4* seg = buckets + b * (size_t)M * 8;
+    uint4* pbuf0 = partials + wgi * (size_t)(2 * T) * 8;
+    uint4* pbuf1 = pbuf0 + (size_t)T * 8;
+    const uint32_t total = cnt[M], maxpop = maxpops[b];
+    const uint32_t Lw = (uint32_t)((total + nreg - 1) / nreg);
+    const uint32_t W0 = min((uint32_t)(w * Lw), total), W1 = min(W0 + Lw, total);
+    const uint32_t L = (W1 - W0 + T - 1) / T;
+    const uint32_t start = min(W0 + (uint32_t)tid * L, W1), end = min(start + L, W1);
+    for (uint32_t i = tid; i < W1 - W0; i += T) sl[i] = srt[W0 + i];
+    __syncthreads();
+
+    Xyzz<P> acc = xyzz_identity<P>();
+    uint32_t head_id = 0, tail_id = 0;
+    bool tail_through = false;
+    if (start < end) {
+        uint32_t lo = 1, hi = (uint32_t)M;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (cnt[mid] > start) hi = mid; else lo = mid + 1;
+        }
+        uint32_t m = lo, bbeg = cnt[m - 1], bend = cnt[m];
+        auto point_addr = [&](uint32_t e) -> const uint32_t* {
+            const size_t g = (size_t)(e & 0x7fffffffu), row = g / row_len;
+            size_t col = g - row * row_len;
+            if (dup_from && col >= dup_from) col -= 2;
+            return bases + (row * row_stride + col) * 16;
+        };
+        uint32_t e_next = sl[start - W0];
+        Affine<P> q_next = affine_load<P>(point_addr(e_next));
+        for (uint32_t j = start; j < end; j++) {
+            if (j == bend) {  // bucket m ended inside this slice
+                if (bbeg < start) {
+                    planes_put(pbuf0, (size_t)T, (size_t)tid, acc);
+                    head_id = m;
+                } else {
+                    planes_put(seg, (size_t)M, (size_t)(m - 1), acc);
+                }
+                acc = xyzz_identity<P>();
+                do { m++; } while (cnt[m] <= j);
+                bbeg = cnt[m - 1];
+                bend = cnt[m];
+            }
+            const uint32_t e = e_next;
+            Affine<P> q = q_next;
+            if (j + 1 < end) {
+                e_next = sl[j + 1 - W0];
+                q_next = affine_load<P>(point_addr(e_next));
+            }
+            if (!aff_is_id(q)) {
+                if (e & 0x80000000u) q.y = fe_neg(q.y);
+                xyzz_madd(acc, q);
+            }
+        }
+        if (bend > end) {
+            tail_id = m;
+            if (bbeg < start) {  // neither begins nor ends here
+                planes_put(pbuf0, (size_t)T, (size_t)tid, acc);
+                head_id = m;
+                acc = xyzz_identity<P>();
+                tail_through = true;
+            }
+        } else if (bbeg < start) {
+            planes_put(pbuf0, (size_t)T, (size_t)tid, acc);
+            head_id = m;
+        } else {
+            planes_put(seg, (size_t)M, (size_t)(m - 1), acc);
+        }
+    }
+    // ---- stitch buckets cut by slice boundaries inside the region (uniform control flow from here) ----
+    idB[tid] = head_id;
+    __syncthreads();
+    uint32_t span = L ? (maxpop + L - 1) / L + 1 : 1;
+    if (span > (uint32_t)T) span = (uint32_t)T;
+    uint4* cur = pbuf0;
+    uint4* nxt = pbuf1;
+    Xyzz<P> headv = xyzz_identity<P>();
+    if (head_id) headv = planes_get<P>(cur, (size_t)T, (size_t)tid);
+    for (uint32_t d = 1; d < span; d <<= 1) {
+        __syncthreads();
+        if (head_id && tid + d < (uint32_t)T && idB[tid + d] == head_id) {
+            const Xyzz<P> o = planes_get<P>(cur, (size_t)T, (size_t)(tid + d));
+            xyzz_add(headv, o);
+        }
+        planes_put(nxt, (size_t)T, (size_t)tid, headv);
+        uint4* tmp = cur;
+        cur = nxt;
+        nxt = tmp;
+    }
+    __syncthreads();
+    // thread 0's run of head partials belongs to a bucket that began in an earlier region: hand it to k_gs_stitch
+    if (tid == 0) {
+        uint32_t hid = 0;
+        if (head_id && cnt[head_id - 1] < W0) {
+            hid = head_id;
+            planes_put(wg_head, nwg_total, wgi, headv);
+        }
+        wg_ids[wgi * 2] = hid;
+        wg_ids[wgi * 2 + 1] = 0;
+    }
+    __syncthreads();
+    if (tail_id && !tail_through) {  // this thread holds the start of a cut bucket: finish it
+        if (tid + 1 < T && idB[tid + 1] == tail_id) {
+            const Xyzz<P> o = planes_get<P>(cur, (size_t)T, (size_t)(tid + 1));
+            xyzz_add(acc, o);
+        }
+        if (cnt[tail_id] > W1) {  // ... unless it continues in the next region
+            planes_put(wg_tail, nwg_total, wgi, acc);
+            wg_ids[wgi * 2 + 1] = tail_id;
+        } else {
+            planes_put(seg, (size_t)M, (size_t)(tail_id - 1), acc);
+        }
+    }
+}
+
+// per vector: a bucket that starts in region w (its tail partial) and runs on through later regions (their head partials)
+template <class C>
+__global__ void __launch_bounds__(64) k_gs_stitch(const uint4* __restrict__ wg_head, const uint4* __restrict__ wg_tail,
+                                                   const uint32_t* __restrict__ wg_ids, size_t nreg, size_t nwg_total, int M,
+                                                   uint4* __restrict__ buckets) {
+    using P = typename C::Base;
+    const size_t b = blockIdx.x;
+    uint4* seg = buckets + b * (size_t)M * 8;
+    for (size_t w = threadIdx.x; w < nreg; w += blockDim.x) {
+        const uint32_t m = wg_ids[(b * nreg + w) * 2 + 1];
+        if (!m) continue;
+        Xyzz<P> acc = planes_get<P>(wg_tail, nwg_total, b * nreg + w);
+        for (size_t w2 = w + 1; w2 < nreg && wg_ids[(b * nreg + w2) * 2] == m; w2++) {
+            const Xyzz<P> o = planes_get<P>(wg_head, nwg_total, b * nreg + w2);
+            xyzz_add(acc, o);
+        }
+        planes_put(seg, (size_t)M, (size_t)(m - 1), acc);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // host driver
 // ---------------------------------------------------------------------------
 template <class C, class SF>
@@ -678,11 +958,40 @@ static int msm_run_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_sca
         pair.M = (uint32_t)p.M;
     }
     const int M_acc = p.M * nclass;  // buckets per accumulate segment
+    // global-sort path (one bucket set per vector), opt-in with BZH_MSM_GS=1.  Measured on the k = 14 proof batches
+    // (16 proofs, window bits in brackets): accumulate 22.1 ms [13] against 24.5 ms [11] for the LDS-chunk kernel, sort
+    // 3.9 ms against 0.4 ms, reduction 10.9 ms against 9.4 ms -> 405 against 397 proofs/s with four batches in flight:
+    // the additions scale with the table rows either way and big buckets (c <= 12) cost more stitching here, so the
+    // default stays on the chunk kernel.
+    static const int gs_env = [] {
+        const char* e = getenv("BZH_MSM_GS");
+        return e ? atoi(e) : 0;
+    }();
+    const bool use_gs = pre && gs_env != 0 && n_eff < ((size_t)1 << 31) && n_eff >= 4096;
+    constexpr int GT = 512;  // threads per region workgroup
+    size_t gs_nreg = 1;
+    if (use_gs) {
+        p.chunk = kMaxChunk;
+        p.nchunks = (n_eff + p.chunk - 1) / p.chunk;
+        static const int gs_items = [] {
+            const char* e = getenv("BZH_GS_ITEMS");
+            return e ? atoi(e) : 32;
+        }();  // sorted items per thread and region (region slice staged in LDS: 4 B per item)
+        gs_nreg = (n_eff + (size_t)GT * gs_items - 1) / ((size_t)GT * gs_items);
+        const size_t want = (256 + batch - 1) / batch;  // fill the CUs when there are few vectors
+        if (gs_nreg < want) gs_nreg = want;
+        const size_t cap = n_eff / ((size_t)GT * 8) ? n_eff / ((size_t)GT * 8) : 1;
+        if (gs_nreg > cap) gs_nreg = cap;
+        const size_t floor_reg = (n_eff + 28671) / 28672;  // region slice in LDS: at most 112 KB
+        if (gs_nreg < floor_reg) gs_nreg = floor_reg;
+    }
     // slice the batch so the bucket workspace stays bounded
     const size_t seg_bytes = (size_t)M_acc * 128;
     const size_t segs_per_vec = (size_t)acc_nwin * p.nchunks;
     const size_t budget = (size_t)2 << 30;
-    size_t slice = budget / (segs_per_vec * (seg_bytes + (size_t)2 * 1024 * 128));
+    const size_t gs_vec_bytes = n_eff * 4 + p.nchunks * (size_t)(M_acc + 1) * 4 + (size_t)(M_acc + 1) * 4 + 64 + seg_bytes +
+                                gs_nreg * ((size_t)2 * GT * 128 + 2 * 128 + 8) + 1024;
+    size_t slice = use_gs ? budget / gs_vec_bytes : budget / (segs_per_vec * (seg_bytes + (size_t)2 * 1024 * 128));
     if (slice < 1) slice = 1;
     if (slice > batch) slice = batch;
     if (slice > 65535) slice = 65535;  // gridDim.z
@@ -703,9 +1012,29 @@ static int msm_run_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_sca
     const size_t part_bytes = (size_t)2 * acc_threads * 128;  // per segment: two stitch buffers
     int rc;
     if ((rc = ws_ensure(ctx, 0, slice * (size_t)p.nwin * n * sizeof(uint16_t), &d_digits))) return rc;
-    if ((rc = ws_ensure(ctx, 1, slice * segs_per_vec * (seg_bytes + part_bytes), &d_buckets))) return rc;
+    if ((rc = ws_ensure(ctx, 1, use_gs ? slice * gs_vec_bytes + 4096 : slice * segs_per_vec * (seg_bytes + part_bytes), &d_buckets)))
+        return rc;
     uint4* d_partials = (uint4*)((char*)d_buckets + slice * segs_per_vec * seg_bytes);
     if ((rc = ws_ensure(ctx, 2, slice * segs_per_vec * nclass * 128, &d_winsums))) return rc;
+    // global-sort workspace, carved from slot 1: buckets | region partials | region heads | region tails | sorted | hist | ends | ids
+    uint4 *gs_partials = nullptr, *gs_head = nullptr, *gs_tail = nullptr;
+    uint32_t *gs_sorted = nullptr, *gs_hist = nullptr, *gs_ends = nullptr, *gs_maxpop = nullptr, *gs_ids = nullptr;
+    if (use_gs) {
+        char* cur = (char*)d_buckets + slice * seg_bytes;
+        auto carve = [&](size_t bytes) {
+            char* r = cur;
+            cur += (bytes + 255) & ~(size_t)255;
+            return r;
+        };
+        gs_partials = (uint4*)carve(slice * gs_nreg * 2 * GT * 128);
+        gs_head = (uint4*)carve(slice * gs_nreg * 128);
+        gs_tail = (uint4*)carve(slice * gs_nreg * 128);
+        gs_sorted = (uint32_t*)carve(slice * n_eff * 4);
+        gs_hist = (uint32_t*)carve(slice * p.nchunks * (size_t)(M_acc + 1) * 4);
+        gs_ends = (uint32_t*)carve(slice * (size_t)(M_acc + 1) * 4);
+        gs_maxpop = (uint32_t*)carve(slice * 4);
+        gs_ids = (uint32_t*)carve(slice * gs_nreg * 8);
+    }
 
     const size_t acc_lds = ((size_t)M_acc + 2 + 32 + acc_threads) * 4 + p.chunk * 2 + 16;
     int red_threads = p.M < 256 ? p.M : 256;
@@ -720,6 +1049,14 @@ static int msm_run_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_sca
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         BZH_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msm_reduce<C>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        BZH_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gs_hist<512>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        BZH_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gs_scatter<512>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        BZH_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gs_scan<C>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        BZH_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gs_accumulate<C, 512>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         attr_set[C::id] = true;
     }
 
@@ -731,6 +1068,29 @@ static int msm_run_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_sca
             hipLaunchKernelGGL((k_msm_digits<SF>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
                                d_scalars + b0 * n * 8, n, total, form, p.c, p.nwin, off, (uint16_t*)d_digits, pair);
         }
+        if (use_gs) {
+            const size_t hist_lds = ((size_t)M_acc + 1) * 4;
+            {
+                ScopedTimer t(ctx, BZH_T_MSM_DIGITS);  // the sort belongs with the digit stage
+                hipLaunchKernelGGL((k_gs_hist<512>), dim3((unsigned)p.nchunks, (unsigned)nb), dim3(512), hist_lds, ctx->stream,
+                                   (const uint16_t*)d_digits, n_eff, p.chunk, M_acc, gs_hist);
+                hipLaunchKernelGGL((k_gs_scan<C>), dim3((unsigned)nb), dim3(1024), ((size_t)M_acc + 2 + 32) * 4, ctx->stream, gs_hist,
+                                   p.nchunks, M_acc, gs_ends, gs_maxpop, (uint4*)d_buckets);
+                hipLaunchKernelGGL((k_gs_scatter<512>), dim3((unsigned)p.nchunks, (unsigned)nb), dim3(512), hist_lds, ctx->stream,
+                                   (const uint16_t*)d_digits, n_eff, p.chunk, M_acc, (const uint32_t*)gs_hist, gs_sorted);
+            }
+            {
+                ScopedTimer t(ctx, BZH_T_MSM_ACCUMULATE);
+                if (ctx->profiling) ctx->alg_bytes[BZH_T_MSM_ACCUMULATE] += (double)nb * (double)n * 32.0 + (double)n * 64.0;
+                const size_t region_lds = ((n_eff + gs_nreg - 1) / gs_nreg + 8) * 4;
+                hipLaunchKernelGGL((k_gs_accumulate<C, GT>), dim3((unsigned)gs_nreg, (unsigned)nb), dim3(GT), region_lds, ctx->stream, bases->d_xy,
+                                   (const uint32_t*)gs_sorted, (const uint32_t*)gs_ends, (const uint32_t*)gs_maxpop, n_eff, M_acc,
+                                   (uint4*)d_buckets, gs_partials, gs_head, gs_tail, gs_ids, row_len, row_stride,
+                                   pair_in ? n - 2 : (size_t)0);
+                hipLaunchKernelGGL((k_gs_stitch<C>), dim3((unsigned)nb), dim3(64), 0, ctx->stream, (const uint4*)gs_head,
+                                   (const uint4*)gs_tail, (const uint32_t*)gs_ids, gs_nreg, gs_nreg * nb, M_acc, (uint4*)d_buckets);
+            }
+        } else
         {
             ScopedTimer t(ctx, BZH_T_MSM_ACCUMULATE);
             if (ctx->profiling) ctx->alg_bytes[BZH_T_MSM_ACCUMULATE] += (double)nb * (double)n * 32.0 + (double)n * 64.0;
@@ -750,8 +1110,12 @@ static int msm_run_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_sca
             ScopedTimer t(ctx, BZH_T_MSM_REDUCE);
             // many segments (throughput regime): sum the chunks of every vector bucket-wise first, then run the
             // running-sum reduction once per vector instead of once per chunk
-            presum = acc_nwin == 1 && p.nchunks >= 2 && p.nchunks <= 32 && nseg * nclass >= 256;
+            presum = !use_gs && acc_nwin == 1 && p.nchunks >= 2 && p.nchunks <= 32 && nseg * nclass >= 256;
             size_t rseg = nseg, rspv = segs_per_vec, mult = 1;
+            if (use_gs) {
+                rseg = nb;
+                rspv = 1;
+            }
             if (presum) {
                 hipLaunchKernelGGL((k_msm_chunksum<C>), dim3((unsigned)((M_acc + 255) / 256), (unsigned)nb), dim3(256), 0, ctx->stream,
                                    (uint4*)d_buckets, M_acc, p.nchunks);
@@ -769,7 +1133,7 @@ static int msm_run_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_sca
         }
         {
             ScopedTimer t(ctx, BZH_T_MSM_FINALIZE);
-            const size_t fchunks = presum ? 1 : p.nchunks, fseg = presum ? nb : nseg;
+            const size_t fchunks = (presum || use_gs) ? 1 : p.nchunks, fseg = (presum || use_gs) ? nb : nseg;
             hipLaunchKernelGGL((k_msm_finalize<C>), dim3((unsigned)(nb * nclass)), dim3(64), 0, ctx->stream,
                                (const uint4*)d_winsums, fseg * nclass, acc_nwin, fchunks, pre ? 0 : p.c, form,
                                d_out + b0 * nclass * 24);
