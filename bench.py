@@ -72,7 +72,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="proof_k14",
                     choices=["board_k14", "board_k12", "shot_k11", "board_k17", "shot_k11_batch", "msm24", "msm20", "ntt22",
-                             "proof_k11", "proof_k12", "proof_k14", "proof_k8"])
+                             "proof_k11", "proof_k12", "proof_k14", "proof_k8", "proof_k17"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-precompute", action="store_true", help="plain bases: no fixed-base window table for the SRS")
     ap.add_argument("--batch", type=int, default=16,
@@ -487,13 +487,15 @@ def main():
         # HBM-side traffic of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
         # WRITE_SIZE in separate runs of this same command; tools/pmc_traffic.py), if one exists for this workload
         traffic, traffic_src = None, None
-        tj = os.path.join(ROOT, "profiles", "r01_e_%s_pmc_traffic.json" % args.workload)
-        if os.path.exists(tj) and args.workload != "ntt22":
+        for tag in ("r01_h", "r01_e"):
+            tj = os.path.join(ROOT, "profiles", "%s_%s_pmc_traffic.json" % (tag, args.workload))
+            if traffic is not None or not os.path.exists(tj) or args.workload == "ntt22":
+                continue
             try:
                 for e in json.load(open(tj))["kernels"]:
-                    if "k_msm_accumulate" in e["kernel"] and e["workgroup"] >= 512:
+                    if "k_msm_accumulate" in e["kernel"] and ("512" in e["kernel"] or e.get("workgroup", 0) >= 512):
                         traffic = e["read_bytes_raw"] + e["write_bytes"]
-                        traffic_src = os.path.relpath(tj, ROOT) + " (raw FETCH_SIZE: 64-B gathers, see its calibration note)"
+                        traffic_src = os.path.relpath(tj, ROOT) + " (raw FETCH_SIZE: 64-B gathers, see its correction note)"
             except Exception:
                 traffic = None
         line = {
