@@ -74,6 +74,9 @@ def parse():
                     choices=["board_k14", "board_k12", "shot_k11", "board_k17", "shot_k11_batch", "msm24", "msm20", "ntt22",
                              "proof_k11", "proof_k12", "proof_k14", "proof_k8", "proof_k17"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo + several ranks on one GPU rehearses the multi-rank path on a single-GPU box (ranks share device "
+                         "local_rank %% device_count); the driver's multi-GPU runs use nccl (RCCL)")
     ap.add_argument("--no-precompute", action="store_true", help="plain bases: no fixed-base window table for the SRS")
     ap.add_argument("--batch", type=int, default=16,
                     help="proof_k* workloads: proofs advanced in lockstep per step (bzh2/prover_batch.py: one launch per kernel "
@@ -413,6 +416,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if args.dist_backend == "gloo":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     numa_node = pin_to_gpu_numa(local_rank)
     device = torch.device("cuda", local_rank)
@@ -420,7 +425,10 @@ def main():
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     stream = torch.cuda.current_stream(device)
     ctx = bzh2.Context(local_rank, stream=stream.cuda_stream)
