@@ -434,7 +434,7 @@ class Transcript:
 
 # ---- IPA opening --------------------------------------------------------------------------------
 EXPORTS += ["bzh_ipa_open", "bzh_ipa_open_batch", "bzh_ipa_verify"]
-EXPORTS += ["bzh_pk_create", "bzh_pk_free", "bzh_pk_info", "bzh_prove_batch"]
+EXPORTS += ["bzh_pk_create", "bzh_pk_free", "bzh_pk_info", "bzh_prove_batch", "bzh_verify_batch"]
 E_VERIFY = -6
 
 

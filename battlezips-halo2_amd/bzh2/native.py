@@ -22,6 +22,8 @@ def _bind():
     L.bzh_pk_free.argtypes = [_VP, _VP]
     L.bzh_pk_info.argtypes = [_VP, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_uint32),
                               ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]
+    L.bzh_verify_batch.argtypes = [_VP, _VP, ctypes.c_size_t, _VP, ctypes.c_size_t, _VP, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t), _VP,
+                                   ctypes.POINTER(ctypes.c_int)]
     L.bzh_prove_batch.argtypes = [_VP, _VP, ctypes.c_size_t, _VP, ctypes.c_int, ctypes.c_int, _VP, ctypes.c_size_t, ctypes.c_char_p,
                                   ctypes.c_size_t, _VP, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
     L._bzh_native_bound = True
@@ -37,6 +39,7 @@ class NativeProvingKey:
         self.p = MODULI[self.field]
         tbl = np.stack([np.concatenate([int_to_limbs(pt[0]), int_to_limbs(pt[1])]) for pt in list(g) + [u, w]])
         self.bases: Bases = ctx.upload_bases(curve, tbl).precompute(window_bits)
+        self._g0_u_w = np.ascontiguousarray(np.stack([tbl[0], tbl[-2], tbl[-1]]))
         blob = serialize_circuit(circuit, self.p, vk_repr)
         L = _bind()
         h = _VP()
@@ -53,6 +56,32 @@ class NativeProvingKey:
             self.handle = None
             self.bases.free()
 
+    def _instances(self, instances):
+        B = len(instances)
+        rows = max([len(col) for cols in instances for col in cols] + [0])
+        inst = np.zeros((B, max(len(instances[0]), 1), max(rows, 1), 4), dtype=np.uint64)
+        for b, cols in enumerate(instances):
+            for i, col in enumerate(cols):
+                for r, v in enumerate(col):
+                    inst[b, i, r] = int_to_limbs(int(v) % self.p)
+        return inst, rows
+
+    def verify_batch(self, instances, proofs) -> list:
+        """plonk::verify_proof for each (instances[b], proofs[b]); returns a list of bools."""
+        L = _bind()
+        B = len(proofs)
+        inst, rows = self._instances(instances)
+        stride = max(max(len(pr) for pr in proofs), 1)
+        buf = np.zeros((B, stride), dtype=np.uint8)
+        lens = (ctypes.c_size_t * B)(*[len(pr) for pr in proofs])
+        for b, pr in enumerate(proofs):
+            buf[b, :len(pr)] = np.frombuffer(pr, dtype=np.uint8)
+        res = (ctypes.c_int * B)()
+        rc = L.bzh_verify_batch(self.ctx.handle, self.handle, B, _VP(inst.ctypes.data), rows, _VP(buf.ctypes.data), stride, lens,
+                                _VP(self._g0_u_w.ctypes.data), res)
+        self.ctx._check(rc, "bzh_verify_batch")
+        return [bool(v) for v in res]
+
     def prove_batch(self, advice, instances, rng_list, device_ptr: int | None = None) -> list:
         """advice: (B, num_advice, n, 4) uint64 canonical host array (or, with device_ptr, a device pointer to Montgomery
         limbs of that shape); instances: B lists of instance columns (equal lengths); rng_list: B byte strings."""
@@ -60,12 +89,7 @@ class NativeProvingKey:
         B = len(rng_list)
         stride = len(rng_list[0])
         assert all(len(r) == stride for r in rng_list) and stride >= self.rng_bytes, (stride, self.rng_bytes)
-        rows = max([len(col) for cols in instances for col in cols] + [0])
-        inst = np.zeros((B, max(len(instances[0]), 1), max(rows, 1), 4), dtype=np.uint64)
-        for b, cols in enumerate(instances):
-            for i, col in enumerate(cols):
-                for r, v in enumerate(col):
-                    inst[b, i, r] = int_to_limbs(int(v) % self.p)
+        inst, rows = self._instances(instances)
         proofs = np.zeros((B, self.max_proof_bytes), dtype=np.uint8)
         lens = (ctypes.c_size_t * B)()
         if device_ptr is not None:

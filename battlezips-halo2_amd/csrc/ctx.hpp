@@ -267,5 +267,8 @@ int ipa_open(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_polys, size
              const uint64_t* x3s, const uint8_t* rng_bytes, size_t rng_stride, bzh_transcript* const* trs, uint64_t* out_v);
 int ipa_verify(bzh_ctx* ctx, const bzh_bases* bases, const uint64_t* commitment_xy, const uint64_t* x3, const uint64_t* v,
                const uint8_t* proof, size_t proof_len, bzh_transcript* tr, const uint64_t* g0_u_w_xy);
+int ipa_check_batch(bzh_ctx* ctx, const bzh_bases* bases, size_t batch, size_t nl, const uint64_t* lc_pts, const uint64_t* lc_scal,
+                    const uint64_t* cu, int* ok);
+bool point_decompress(int curve, const uint8_t* in, uint64_t* xy_canonical);
 
 }  // namespace bzh

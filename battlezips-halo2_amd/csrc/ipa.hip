@@ -656,6 +656,93 @@ static int ipa_verify_t(bzh_ctx* ctx, const bzh_bases* bases, const uint64_t* co
     return memcmp(lhs, rhs, 64) == 0 ? BZH_OK : BZH_E_VERIFY;
 }
 
+// s[b][i] = c_b * prod_{j : bit (k-1-j) of i} u_(b,j)  for i < n;  s[b][n], s[b][n+1] = 0   (the verifier's G'_0 scalars)
+template <class P>
+__global__ void __launch_bounds__(256) k_ipa_verify_s(const uint32_t* __restrict__ cu, size_t n, unsigned k, uint32_t* __restrict__ s) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (i >= n + 2) return;
+    Fe<P> acc = fe_zero<P>();
+    if (i < n) {
+        const uint32_t* row = cu + b * (size_t)(k + 1) * 8;  // [c, u_0 .. u_(k-1)]
+        acc = fe_load<P>(row);
+        for (unsigned j = 0; j < k; j++)
+            if ((i >> (k - 1 - j)) & 1) acc = fe_mul(acc, fe_load<P>(row + (size_t)(j + 1) * 8));
+    }
+    fe_store(s + (b * (n + 2) + i) * 8, acc);
+}
+
+// For every opening b:  sum_i lc_scal[b][i] * lc_pts[b][i]  ==  <c_b * s(u_b), G>  ?   (the IPA verification equation with
+// everything but the n-term G'_0 moved to the left: L_j, R_j, S, the opened commitment expanded into the proof's own
+// commitments, G_0, U, W).  lc_pts: batch x nl affine canonical points ((0,0) = identity padding), lc_scal: canonical.
+template <class C>
+static int ipa_check_batch_t(bzh_ctx* ctx, const bzh_bases* bases, size_t batch, size_t nl, const uint64_t* lc_pts,
+                             const uint64_t* lc_scal, const uint64_t* cu /* batch x (k+1) canonical: c, u_j */, int* ok) {
+    using SF = typename CurveMeta<C>::SF;
+    using PB = typename C::Base;
+    const size_t n = bases->n - 2, B = batch;
+    unsigned k = 0;
+    while (((size_t)1 << k) < n) k++;
+    if (((size_t)1 << k) != n || !B || !nl) return BZH_E_ARG;
+    hipStream_t st = ctx->stream;
+    const size_t na = B * nl;  // ad-hoc table: every opening's points side by side, vector b is non-zero on its own segment
+    const size_t words = B * (n + 2) * 8 + B * (k + 1) * 8 + na * 16 + B * na * 8 + 2 * B * 24 + 256;
+    void* arena = nullptr;
+    IPA_TRY(ws_ensure(ctx, 4, words * 4, &arena));
+    uint32_t* d_s = (uint32_t*)arena;
+    uint32_t* d_cu = d_s + B * (n + 2) * 8;
+    uint32_t* d_pts = d_cu + B * (k + 1) * 8;
+    uint32_t* d_scal = d_pts + na * 16;
+    uint32_t* d_out = d_scal + B * na * 8;
+    // right side
+    std::vector<Fe<SF>> cum(B * (k + 1));
+    for (size_t i = 0; i < cum.size(); i++) cum[i] = fe_to_mont(h_load<SF>(cu + 4 * i));
+    IPA_TRY(h2d_small(ctx, d_cu, cum.data(), cum.size() * 32));
+    hipLaunchKernelGGL((k_ipa_verify_s<SF>), dim3((unsigned)((n + 2 + 255) / 256), (unsigned)B), dim3(256), 0, st, d_cu, n, k, d_s);
+    BZH_HIP_TRY(ctx, hipGetLastError());
+    IPA_TRY(msm_run(ctx, bases, d_s, n + 2, B, BZH_FORM_MONTGOMERY, d_out));
+    // left side
+    IPA_TRY(h2d_small(ctx, d_pts, lc_pts, na * 64));
+    IPA_TRY(bases_to_montgomery(ctx, C::id, d_pts, na));
+    BZH_HIP_TRY(ctx, hipMemsetAsync(d_scal, 0, B * na * 32, st));
+    for (size_t b = 0; b < B; b++) IPA_TRY(h2d_small(ctx, d_scal + (b * na + b * nl) * 8, lc_scal + b * nl * 4, nl * 32));
+    bzh_bases tmp;
+    tmp.curve = C::id;
+    tmp.n = na;
+    tmp.d_xy = d_pts;
+    tmp.device = ctx->device;
+    IPA_TRY(msm_run(ctx, &tmp, d_scal, na, B, BZH_FORM_CANONICAL, d_out + B * 24));
+    std::vector<uint64_t> jac(2 * B * 12), lhs(B * 8), rhs(B * 8);
+    IPA_TRY(d2h_async(ctx, jac.data(), d_out, 2 * B * 96));
+    IPA_TRY(d2h_finish(ctx));
+    h_jac_batch_to_affine_canonical<PB>(jac.data(), B, rhs.data());
+    // the ad-hoc MSM ran in canonical form: its output limbs are canonical, convert for the helper
+    std::vector<uint64_t> jm(B * 12);
+    for (size_t i = 0; i < B * 3; i++) h_store<PB>(&jm[4 * i], fe_to_mont(h_load<PB>(&jac[B * 12 + 4 * i])));
+    h_jac_batch_to_affine_canonical<PB>(jm.data(), B, lhs.data());
+    for (size_t b = 0; b < B; b++) ok[b] = memcmp(&lhs[b * 8], &rhs[b * 8], 64) == 0;
+    return BZH_OK;
+}
+
+int ipa_check_batch(bzh_ctx* ctx, const bzh_bases* bases, size_t batch, size_t nl, const uint64_t* lc_pts, const uint64_t* lc_scal,
+                    const uint64_t* cu, int* ok) {
+    switch (bases->curve) {
+        case BZH_CURVE_VESTA: return ipa_check_batch_t<VestaCurve>(ctx, bases, batch, nl, lc_pts, lc_scal, cu, ok);
+        case BZH_CURVE_PALLAS: return ipa_check_batch_t<PallasCurve>(ctx, bases, batch, nl, lc_pts, lc_scal, cu, ok);
+        case BZH_CURVE_BN254: return ipa_check_batch_t<Bn254Curve>(ctx, bases, batch, nl, lc_pts, lc_scal, cu, ok);
+    }
+    return BZH_E_ARG;
+}
+
+// pasta_curves from_bytes for one compressed point (host): false = not on the curve / non-canonical
+bool point_decompress(int curve, const uint8_t* in, uint64_t* xy_canonical) {
+    switch (curve) {
+        case BZH_CURVE_VESTA: return h_decompress<VestaCurve>(in, xy_canonical);
+        case BZH_CURVE_PALLAS: return h_decompress<PallasCurve>(in, xy_canonical);
+        case BZH_CURVE_BN254: return h_decompress<Bn254Curve>(in, xy_canonical);
+    }
+    return false;
+}
+
 int random_field(bzh_ctx* ctx, int field, const uint32_t* d_raw, size_t count, uint32_t* d_out) {
     if (!count) return BZH_OK;
     const dim3 grid((unsigned)((count + 255) / 256)), block(256);

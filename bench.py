@@ -72,7 +72,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="proof_k14",
                     choices=["board_k14", "board_k12", "shot_k11", "board_k17", "shot_k11_batch", "msm24", "msm20", "ntt22",
-                             "proof_k11", "proof_k12", "proof_k14", "proof_k8", "proof_k17"])
+                             "proof_k11", "proof_k12", "proof_k14", "proof_k8", "proof_k17", "verify_k11", "verify_k14"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + several ranks on one GPU rehearses the multi-rank path on a single-GPU box (ranks share device "
@@ -162,6 +162,36 @@ class Workload:
             self.desc = {"k": k, "proofs_per_step": proofs, "msm": "%dx2^%d vesta" % (28 * proofs, k),
                          "ntt": "%dx iNTT 2^%d + %dx coset NTT 2^%d + %dx coset iNTT 2^%d (Fp)" % (17 * proofs, k, 18 * proofs, k + 3, proofs, k + 3)}
             self.result = self.msm_out
+        elif name.startswith("verify_k"):
+            # the reference's second benchmark (benches/board.rs:80-86): verify_proof over a batch of proofs of the
+            # BattleZips-shaped circuit, made once (untimed) by bzh_prove_batch; one step = one bzh_verify_batch call
+            from bzh2 import native as N, synth
+            from bzh2.device import DeviceOps
+            k = int(name[len("verify_k"):])
+            n = 1 << k
+            self.k = k
+            circ, adv, inst = synth.battlezips_shaped(k, seed)
+            pts = make_bases(ctx, self.curve, n + 2, seed + 1)
+            as_pt = lambda a: (bzh2.limbs_to_int(a[:4]), bzh2.limbs_to_int(a[4:]))
+            g = [as_pt(a) for a in pts]
+            self.npk = N.NativeProvingKey(ctx, circ, self.curve, g[:n], g[n + 1], g[n])
+            ops = DeviceOps(ctx, self.field, self.curve, self.npk.p, device)
+            adv_b = torch.stack([ops.upload(list(col) + [0] * (n - len(col))) for col in adv]).unsqueeze(0).repeat(batch, 1, 1, 1).contiguous()
+            torch.cuda.synchronize(device)
+            rbs = [np.random.default_rng(seed + 100 + i).bytes(self.npk.rng_bytes) for i in range(batch)]
+            self.insts = [inst] * batch
+            self.proofs = self.npk.prove_batch(None, self.insts, rbs, device_ptr=adv_b.data_ptr())
+            self.accepted = 0
+
+            def verify():
+                res = self.npk.verify_batch(self.insts, self.proofs)
+                self.accepted = sum(res)
+            self.calls = [("bzh_verify_batch", verify)]
+            self.units_per_step = batch
+            self.alg_bytes_msm_launch = 0
+            self.alg_bytes_step = 0
+            self.desc = {"k": k, "batch": batch, "proof_bytes": len(self.proofs[0])}
+            self.result = torch.zeros((1, 12), dtype=torch.int64, device=device)
         elif name.startswith("proof_k"):
             # a COMPLETE proof per step: bzh2/prover_dev.create_proof on a circuit with the shape of the reference's
             # Shot / Board circuits (bzh2/synth.py); witness columns are resident in HBM before the timed region
@@ -474,13 +504,14 @@ def main():
         units = wl.units_per_step * args.steps * world
         is_proof = args.workload.startswith(("board", "shot"))
         is_full = args.workload.startswith("proof_k")
+        is_verify = args.workload.startswith("verify_k")
         acc = timings["msm_accumulate"]
         nt = timings["ntt"]
         if args.workload == "ntt22":
             dom_ms = nt["ms"] / max(nt["launches"], 1) * (nt["launches"] / max(args.steps, 1))  # all passes of one NTT
             alg = wl.alg_bytes_step
             dom_name = "k_ntt_pass (all passes of one 2^22 NTT)"
-        elif is_full:
+        elif is_full or is_verify:
             # MSM launches of a proof differ in size (28 column commits batched by phase, then the halving IPA
             # rounds): average the bytes the library counted per launch (bzh_ctx_work) over the same launches
             dom_ms = acc["ms"] / max(acc["launches"], 1)
@@ -528,6 +559,13 @@ def main():
             "kernel_ms": {kname: v for kname, v in timings.items() if v["launches"]},
         }
         line["config"]["host_threads_pinned_to_numa_node"] = numa_node
+        if is_verify:
+            line["metric"] = "proof verifications per second, BattleZips-shaped circuit, k=%d, IPA/Pasta" % wl.k
+            line["unit"] = "verifications/s"
+            line["config"]["stages"] = ("complete verify_proof: instance commitments, transcript replay, expected h(x), multiopen "
+                                        "recombination, IPA equation (one n-term MSM per proof)")
+            line["config"]["accepted_in_last_batch"] = wl.accepted
+            assert wl.accepted == wl.units_per_step, "a valid proof was rejected"
         if is_full:
             line["config"]["stages"] = ("complete create_proof: commitments, lookup, permutation, vanishing, quotient, evaluations, "
                                         "multiopen, IPA, transcript; witness synthesis excluded (columns resident in HBM)")

@@ -267,6 +267,11 @@ int bzh_pk_create(bzh_ctx* ctx, const bzh_bases* srs, const uint8_t* circuit, si
 int bzh_pk_free(bzh_ctx* ctx, bzh_pk* pk);
 int bzh_pk_info(const bzh_pk* pk, size_t* rng_bytes_per_proof, size_t* max_proof_bytes, uint32_t* num_advice, uint32_t* n_rows,
                 uint32_t* usable_rows);
+/* bzh_verify_batch  plonk::verify_proof (SingleVerifier; benches/board.rs:80-86) for `batch` proofs of the key's circuit:
+ *                  results[b] = 1 if proof b verifies against instances b, else 0 (malformed proofs included).
+ *                  g0_u_w: G_0, U, W of the SRS as 3 affine canonical points (the table itself only lives on the device). */
+int bzh_verify_batch(bzh_ctx* ctx, bzh_pk* pk, size_t batch, const uint64_t* instances, size_t instance_rows, const uint8_t* proofs,
+                     size_t proof_stride, const size_t* proof_lens, const uint64_t* g0_u_w, int* results);
 int bzh_prove_batch(bzh_ctx* ctx, bzh_pk* pk, size_t batch, const uint64_t* advice, int form, int mem, const uint64_t* instances,
                     size_t instance_rows, const uint8_t* rng, size_t rng_stride, uint8_t* proofs, size_t proof_stride,
                     size_t* proof_lens);

@@ -91,3 +91,59 @@ def test_native_prover_battlezips_shaped_and_unsatisfied_witness(gpu_ctx, oracle
             assert not H.verify_proof(keys, built[1][2], proofs[1], O.Blake2bTranscript(F))
     finally:
         pk.close()
+
+
+@pytest.mark.parametrize("k,with_lookup,degree", [(4, False, None), (5, True, None), (6, True, 9)])
+def test_native_verify_batch_agrees_with_oracle_verifier(gpu_ctx, oracle_c, k, with_lookup, degree):
+    """bzh_verify_batch (verify_proof, benches/board.rs:80-86): accepts exactly what the big-int oracle verifier accepts --
+    valid proofs (made by the ORACLE prover, so prover and verifier here are independent), and rejects a wrong instance,
+    flipped bytes in every section of the proof, a truncated proof and a non-canonical scalar."""
+    import bzh2
+    from bzh2 import native as N, prover as P
+    cv, F = O.VESTA, O.FP
+    cs, fixed, copies, adv, inst = S.build(k=k, seed=900 + k, with_lookup=with_lookup, degree=degree)
+    rng, g, w, u = _setup(cs, 5000 + k)
+    keys = H.Keys(cs, H.Domain(cs, F), cv, g, w, u, fixed, copies)
+    circ = P.Circuit(cs.k, cs.num_advice, cs.num_fixed, cs.num_instance, cs.gates, cs.perm_columns, cs.lookups, fixed, copies,
+                     degree=degree)
+    pk = N.NativeProvingKey(gpu_ctx, circ, bzh2.CURVE_VESTA, g, w, u)
+    try:
+        ndraws = pk.rng_bytes // 64
+        rs = [rng.randrange(F.p) for _ in range(ndraws)]
+        good = H.create_proof(keys, adv, inst, rs, O.Blake2bTranscript(F))
+        assert H.verify_proof(keys, inst, good, O.Blake2bTranscript(F))
+        cases = [(inst, good)]
+        cases.append(([[(inst[0][0] + 1) % F.p]], good))                       # wrong public input
+        step = max(1, len(good) // 12)
+        for pos in range(5, len(good), step):                                   # one flipped bit per section
+            cases.append((inst, good[:pos] + bytes([good[pos] ^ 0x04]) + good[pos + 1:]))
+        cases.append((inst, good[:-32]))                                        # truncated
+        cases.append((inst, good[:-32] + (F.p + 1).to_bytes(32, "little")))     # non-canonical final scalar
+        cases.append((inst, good + b"\x00" * 32))                               # trailing bytes
+        got = pk.verify_batch([c[0] for c in cases], [c[1] for c in cases])
+        want = [H.verify_proof(keys, c[0], c[1], O.Blake2bTranscript(F)) for c in cases]
+        assert got == want
+        assert got[0] is True and not any(got[1:])
+    finally:
+        pk.close()
+
+
+def test_native_prove_then_verify_roundtrip_shaped(gpu_ctx, oracle_c):
+    """The benchmark circuit at k = 8: bzh_prove_batch -> bzh_verify_batch accepts all; swapping instances rejects."""
+    import bzh2
+    from bzh2 import native as N, synth
+    built = [synth.battlezips_shaped(8, seed=80 + b) for b in range(3)]
+    circ = built[0][0]
+    cs = H.ConstraintSystem(circ.k, 11, 8, 1, circ.gates, circ.perm_columns, circ.lookups, degree=9)
+    rng, g, w, u = _setup(cs, 81)
+    pk = N.NativeProvingKey(gpu_ctx, circ, bzh2.CURVE_VESTA, g, w, u)
+    try:
+        rbs = [bytes(rng.getrandbits(8) for _ in range(pk.rng_bytes)) for _ in range(3)]
+        adv = np.stack([_adv_array(built[b][1], cs.n) for b in range(3)])
+        insts = [built[b][2] for b in range(3)]
+        proofs = pk.prove_batch(adv, insts, rbs)
+        assert pk.verify_batch(insts, proofs) == [True, True, True]
+        if insts[0] != insts[1]:
+            assert pk.verify_batch([insts[1], insts[0], insts[2]], proofs) == [False, False, True]
+    finally:
+        pk.close()
