@@ -147,3 +147,47 @@ def test_native_prove_then_verify_roundtrip_shaped(gpu_ctx, oracle_c):
             assert pk.verify_batch([insts[1], insts[0], insts[2]], proofs) == [False, False, True]
     finally:
         pk.close()
+
+
+def test_native_prover_device_resident_witness_and_error_paths(gpu_ctx, oracle_c):
+    """bench.py's path: the witness tensor resident in HBM in Montgomery form (BZH_MEM_DEVICE) gives the same bytes as the
+    host canonical path; a short randomness stream is BZH_E_ARG; a lookup input outside its table is BZH_E_RANGE."""
+    import torch
+    import bzh2
+    from bzh2 import native as N, prover as P
+    from bzh2.device import DeviceOps
+    cv, F = O.VESTA, O.FP
+    cs, fixed, copies, adv, inst = S.build(k=5, seed=31, with_lookup=True)
+    rng, g, w, u = _setup(cs, 6001)
+    circ = P.Circuit(cs.k, cs.num_advice, cs.num_fixed, cs.num_instance, cs.gates, cs.perm_columns, cs.lookups, fixed, copies)
+    ctx = bzh2.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    pk = N.NativeProvingKey(ctx, circ, bzh2.CURVE_VESTA, g, w, u)
+    try:
+        rbs = [bytes(rng.getrandbits(8) for _ in range(pk.rng_bytes)) for _ in range(2)]
+        host = np.stack([_adv_array(adv, cs.n)] * 2)
+        want = pk.prove_batch(host, [inst, inst], rbs)
+        assert want[0] != want[1]                                       # same witness, different blinding randomness
+        ops = DeviceOps(ctx, pk.field, pk.curve, pk.p, torch.device("cuda", 0))
+        dev = torch.stack([torch.stack([ops.upload(list(col) + [0] * (cs.n - len(col))) for col in adv])] * 2).contiguous()
+        torch.cuda.synchronize()
+        assert pk.prove_batch(None, [inst, inst], rbs, device_ptr=dev.data_ptr()) == want
+        assert pk.verify_batch([inst, inst], want) == [True, True]
+        with pytest.raises(AssertionError):
+            pk.prove_batch(host, [inst, inst], [r[:-64] for r in rbs])   # the binding refuses a short stream itself
+        L = bzh2.load()
+        import ctypes
+        lens = (ctypes.c_size_t * 2)()
+        out = np.zeros((2, pk.max_proof_bytes), dtype=np.uint8)
+        short = b"".join(r[:-64] for r in rbs)
+        rc = L.bzh_prove_batch(ctx.handle, pk.handle, 2, ctypes.c_void_p(host.ctypes.data), bzh2.FORM_CANONICAL, bzh2.MEM_HOST, None, 0,
+                               short, len(rbs[0]) - 64, ctypes.c_void_p(out.ctypes.data), pk.max_proof_bytes, lens)
+        assert rc == bzh2.E_ARG
+        bad = host.copy()
+        lookup_rows = [r for r in range(cs.usable_rows) if fixed[3][r]]
+        bad[1, 0, lookup_rows[0]] = C.ints_to_array([12345])[0]         # advice 0 feeds the lookup where q_lookup = 1
+        with pytest.raises(bzh2.BzhError) as ei:
+            pk.prove_batch(bad, [inst, inst], rbs)
+        assert ei.value.status == bzh2.E_RANGE
+    finally:
+        pk.close()
+        ctx.close()
