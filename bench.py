@@ -9,8 +9,8 @@ evaluation, scan and IPA round is one launch for the batch).  The circuit has th
 lookup); a proof covers column commitments, lookup permute + grand product, permutation grand products, the
 vanishing argument (quotient over the 8n coset), evaluations, multiopen and the IPA opening, transcript included.
 Witness columns are synthetic and resident in HBM before the timed region starts; every proof draws its own blinding
-randomness and its bytes come back to the host inside the timed region.  Defaults: --batch 16 --concurrency 4
-(64 proofs per step).  `--batch 1 --concurrency 1` is the single-proof latency configuration.
+randomness and its bytes come back to the host inside the timed region.  Defaults: --batch 24 --concurrency 4
+(96 proofs per step).  `--batch 1 --concurrency 1` is the single-proof latency configuration.
 `--driver python` runs the ctypes-level drivers (bzh2/prover_dev.py, bzh2/prover_batch.py) instead.
 
 `board_k14` / `board_k12` / `shot_k11` / `board_k17` / `shot_k11_batch` time only the MSM + NTT schedule of
@@ -78,7 +78,7 @@ def parse():
                     help="gloo + several ranks on one GPU rehearses the multi-rank path on a single-GPU box (ranks share device "
                          "local_rank %% device_count); the driver's multi-GPU runs use nccl (RCCL)")
     ap.add_argument("--no-precompute", action="store_true", help="plain bases: no fixed-base window table for the SRS")
-    ap.add_argument("--batch", type=int, default=16,
+    ap.add_argument("--batch", type=int, default=24,
                     help="proof_k* workloads: proofs advanced in lockstep per step (bzh2/prover_batch.py: one launch per kernel "
                          "class per phase for the whole batch); 1 = the single-proof latency path (bzh2/prover_dev.py)")
     ap.add_argument("--driver", default="native", choices=["native", "python"],
