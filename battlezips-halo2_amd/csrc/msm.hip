@@ -1110,7 +1110,8 @@ static int msm_run_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_sca
             ScopedTimer t(ctx, BZH_T_MSM_REDUCE);
             // many segments (throughput regime): sum the chunks of every vector bucket-wise first, then run the
             // running-sum reduction once per vector instead of once per chunk
-            presum = !use_gs && acc_nwin == 1 && p.nchunks >= 2 && p.nchunks <= 32 && nseg * nclass >= 256;
+            // (long chunk lists only when there are enough vectors to hide the serial sum over the chunks)
+            presum = !use_gs && acc_nwin == 1 && p.nchunks >= 2 && (p.nchunks <= 32 || nb * nclass >= 8) && nseg * nclass >= 256;
             size_t rseg = nseg, rspv = segs_per_vec, mult = 1;
             if (use_gs) {
                 rseg = nb;
