@@ -930,7 +930,12 @@ static int msm_run_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_sca
         // Chunk count: at least ceil(n_eff / 32768) (u16 local index), more when that fills the chip's
         // CUs more evenly -- the launch's makespan is ceil(workgroups / CUs) rounds of `chunk` additions
         // plus, per extra chunk, one more bucket set to reduce (2 full additions per bucket).
-        const size_t cmin = (n_eff + kMaxChunk - 1) / kMaxChunk;
+        static const size_t max_chunk = [] {
+            const char* e = getenv("BZH_ACC_CHUNK");  // tuning knob: items per accumulate workgroup (<= 32768)
+            const size_t v = e ? (size_t)atol(e) : kMaxChunk;
+            return v >= 1024 && v <= kMaxChunk ? v : kMaxChunk;
+        }();
+        const size_t cmin = (n_eff + max_chunk - 1) / max_chunk;
         const double cus = (double)(ctx->num_cu > 0 ? ctx->num_cu : 256);
         double best = 1e300;
         size_t best_nc = cmin;
@@ -1008,7 +1013,11 @@ static int msm_run_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_sca
     const size_t est_wgs = segs_per_vec * slice;
     (void)est_wgs;
     // ~200 VGPRs per lane: 2 waves/SIMD, so 512 threads = one workgroup per CU; 1024 would spill
-    const int acc_threads = p.chunk >= 8192 ? 512 : 256;
+    static const int acc_threads_env = [] {
+        const char* e = getenv("BZH_ACC_THREADS");
+        return e ? atoi(e) : 0;
+    }();
+    const int acc_threads = acc_threads_env == 256 || acc_threads_env == 512 ? acc_threads_env : (p.chunk >= 8192 ? 512 : 256);
     const size_t part_bytes = (size_t)2 * acc_threads * 128;  // per segment: two stitch buffers
     int rc;
     if ((rc = ws_ensure(ctx, 0, slice * (size_t)p.nwin * n * sizeof(uint16_t), &d_digits))) return rc;
