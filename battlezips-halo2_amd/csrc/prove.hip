@@ -442,6 +442,7 @@ struct bzh_pk {
     // verifying key: commitments to the fixed and permutation polynomials (computed at the first verification)
     bool vk_ready = false;
     std::vector<uint64_t> fixed_commitments, sigma_commitments;  // affine canonical x || y
+    std::mutex mu;  // the arena and the program cache serve one call at a time, whichever ctx it comes through
 };
 
 namespace bzh {
@@ -2275,6 +2276,7 @@ int bzh_verify_batch(bzh_ctx* ctx, bzh_pk* pk, size_t batch, const uint64_t* ins
     if (pk->device != ctx->device || (pk->ni && instance_rows && !instances) || instance_rows > pk->usable) return BZH_E_ARG;
     for (size_t b = 0; b < batch; b++)
         if (proof_lens[b] > proof_stride) return BZH_E_ARG;
+    std::lock_guard<std::mutex> lkp(pk->mu);
     std::lock_guard<std::mutex> lk(ctx->mu);
     BZH_HIP_TRY(ctx, hipSetDevice(ctx->device));
     int rc = BZH_E_ARG;
@@ -2298,6 +2300,7 @@ int bzh_prove_batch(bzh_ctx* ctx, bzh_pk* pk, size_t batch, const uint64_t* advi
     if (pk->device != ctx->device || rng_stride < pk->rng_bytes || (pk->ni && instance_rows && !instances) || instance_rows > pk->usable)
         return BZH_E_ARG;
     if (mem == BZH_MEM_DEVICE && form != BZH_FORM_MONTGOMERY) return BZH_E_ARG;
+    std::lock_guard<std::mutex> lkp(pk->mu);
     std::lock_guard<std::mutex> lk(ctx->mu);
     BZH_HIP_TRY(ctx, hipSetDevice(ctx->device));
     const uint32_t* d_adv = (const uint32_t*)advice;

@@ -261,7 +261,9 @@ int bzh_ipa_verify(bzh_ctx* ctx, const bzh_bases* bases, const uint64_t* commitm
  *                  elements (host); rng: per proof, at offset b * rng_stride, 64 bytes per Field::random draw in
  *                  upstream's draw order (bzh_pk_info reports the byte count); proofs: batch records of
  *                  proof_stride bytes, lengths in proof_lens.  BZH_E_RANGE: a witness does not satisfy the circuit
- *                  (surplus quotient coefficients) or a lookup input is not in its table. */
+ *                  (surplus quotient coefficients) or a lookup input is not in its table.
+ *                  A key serves one call at a time (its device arena and program cache are per key): concurrent batches
+ *                  use one key per host thread, as bench.py does. */
 typedef struct bzh_pk bzh_pk;
 int bzh_pk_create(bzh_ctx* ctx, const bzh_bases* srs, const uint8_t* circuit, size_t circuit_len, bzh_pk** out);
 int bzh_pk_free(bzh_ctx* ctx, bzh_pk* pk);
