@@ -66,3 +66,23 @@ def test_binary_value_basics():
     assert v.bitfield(4) == [1, 0, 1, 0] and v.to_repr()[0] == 5 and G.BinaryValue.from_repr(v.to_repr()) == v
     with pytest.raises(ValueError):
         G.BinaryValue(G.FP_MODULUS).to_fp()
+
+
+def test_wasm_record_round_trip_and_canonical_check():
+    """src/wasm/circuit_wasm.rs:27-31,75-83: {commitment: Vec<[u8;32]>, proof: Vec<u8>} as serde writes it."""
+    import json
+    from bzh2.wire import BattleZipsRecord
+    from bzh2.game import FP_MODULUS
+    rec = BattleZipsRecord([5, FP_MODULUS - 1], bytes(range(200)))
+    text = rec.to_json()
+    d = json.loads(text)
+    assert [len(c) for c in d["commitment"]] == [32, 32] and d["commitment"][0][:2] == [5, 0] and d["proof"][:3] == [0, 1, 2]
+    back = BattleZipsRecord.from_json(text)
+    assert back.commitment == rec.commitment and back.proof == rec.proof
+    d["commitment"][1] = list(FP_MODULUS.to_bytes(32, "little"))            # p itself is not a canonical Fp
+    with pytest.raises(ValueError):
+        BattleZipsRecord.from_json(json.dumps(d))
+    fixed = rec.to_fixed(256)
+    assert len(fixed) == 260 and BattleZipsRecord.proof_from_fixed(fixed) == rec.proof
+    with pytest.raises(ValueError):
+        rec.to_fixed(100)
