@@ -191,3 +191,47 @@ def test_native_prover_device_resident_witness_and_error_paths(gpu_ctx, oracle_c
     finally:
         pk.close()
         ctx.close()
+
+
+def test_native_prover_minimal_circuit_without_instance_permutation_or_lookup(gpu_ctx, oracle_c):
+    """Degenerate shapes: no instance column, no permutation argument, no lookup -- one multiplication gate with a rotated
+    query.  Prover bytes equal the oracle's, both verifiers accept, a broken row is rejected."""
+    import bzh2
+    from bzh2 import native as N, prover as P
+    cv, F = O.VESTA, O.FP
+    p = F.p
+    k, n = 4, 16
+    A = lambda c, r=0: ('advice', c, r)
+    gates = [('mul', ('fixed', 0, 0), ('add', ('mul', A(0), A(1)), ('neg', A(0, 1))))]     # q * (a0 * a1 - a0[next]) = 0
+    cs = H.ConstraintSystem(k, 2, 1, 0, gates, [], [])
+    usable = cs.usable_rows
+    rr = random.Random(17)
+    a0, a1 = [rr.randrange(p)], []
+    for r in range(usable - 1):
+        a1.append(rr.randrange(p))
+        a0.append(a0[-1] * a1[-1] % p)
+    a1.append(0)
+    fixed = [[1] * (usable - 1) + [0] * (n - usable + 1)]
+    adv = [a0 + [0] * (n - usable), a1 + [0] * (n - usable)]
+    rng, g, w, u = _setup(cs, 7001)
+    keys = H.Keys(cs, H.Domain(cs, F), cv, g, w, u, fixed, [])
+    circ = P.Circuit(k, 2, 1, 0, gates, [], [], fixed, [])
+    pk = N.NativeProvingKey(gpu_ctx, circ, bzh2.CURVE_VESTA, g, w, u)
+    try:
+        rbytes = bytes(rng.getrandbits(8) for _ in range(pk.rng_bytes))
+        rs = [O.from_u512(rbytes[64 * i:64 * (i + 1)], F) for i in range(pk.rng_bytes // 64)]
+        want = H.create_proof(keys, adv, [], rs, O.Blake2bTranscript(F))
+        assert H.verify_proof(keys, [], want, O.Blake2bTranscript(F))
+        got = pk.prove_batch(np.stack([_adv_array(adv, n)]), [[]], [rbytes])
+        assert got == [want]
+        assert pk.verify_batch([[]], got) == [True]
+        broken = [list(adv[0]), list(adv[1])]
+        broken[0][3] = (broken[0][3] + 1) % p
+        try:
+            bad = pk.prove_batch(np.stack([_adv_array(broken, n)]), [[]], [rbytes])
+        except bzh2.BzhError as e:
+            assert e.status == bzh2.E_RANGE
+        else:
+            assert pk.verify_batch([[]], bad) == [False]
+    finally:
+        pk.close()
