@@ -235,3 +235,37 @@ def test_native_prover_minimal_circuit_without_instance_permutation_or_lookup(gp
             assert pk.verify_batch([[]], bad) == [False]
     finally:
         pk.close()
+
+
+@pytest.mark.parametrize("k", [11, 14])
+def test_reference_size_native_proofs_pass_the_oracle_verifier(gpu_ctx, oracle_c, monkeypatch, k):
+    """Reference sizes (k = 11: benches/shot.rs:22; k = 14: the Board scale-up bench.py measures): proofs of the BattleZips-shaped circuit made by bzh_prove_batch are
+    checked by the ORACLE's verify_proof (its n-term MSMs delegated to the C oracle, or the big-int sums would take hours);
+    a proof with one flipped byte is rejected by both verifiers."""
+    import bzh2
+    from bzh2 import native as N, synth
+    cv, F = O.VESTA, O.FP
+    circ, adv, inst = synth.battlezips_shaped(k, seed=123)
+    cs = H.ConstraintSystem(circ.k, 11, 8, 1, circ.gates, circ.perm_columns, circ.lookups, degree=9)
+    rng = random.Random(1111)
+    g0 = cv.random_point(rng)
+    walk = C.point_walk(0, C.points_to_array([g0])[0], cs.n + 2)                   # G_i = [i+1] G_0 via the C oracle
+    pts = [C.array_to_point(walk[i]) for i in range(cs.n + 2)]
+    g, u, w = pts[:cs.n], pts[cs.n], pts[cs.n + 1]
+    fast = lambda self, scalars, points: C.array_to_point(C.msm(0, C.ints_to_array([int(s) % F.p for s in scalars]),
+                                                                   C.points_to_array(points), 8))
+    monkeypatch.setattr(type(cv), "msm_naive", fast)
+    keys = H.Keys(cs, H.Domain(cs, F), cv, g, w, u, circ.fixed, circ.copies)
+    pk = N.NativeProvingKey(gpu_ctx, circ, bzh2.CURVE_VESTA, g, w, u)
+    try:
+        rbs = [bytes(rng.getrandbits(8) for _ in range(pk.rng_bytes)) for _ in range(2)]
+        advs = np.stack([_adv_array(adv, cs.n)] * 2)
+        proofs = pk.prove_batch(advs, [inst, inst], rbs)
+        assert proofs[0] != proofs[1]
+        assert H.verify_proof(keys, inst, proofs[0], O.Blake2bTranscript(F))
+        assert H.verify_proof(keys, inst, proofs[1], O.Blake2bTranscript(F))
+        bad = proofs[0][:700] + bytes([proofs[0][700] ^ 1]) + proofs[0][701:]
+        assert not H.verify_proof(keys, inst, bad, O.Blake2bTranscript(F))
+        assert pk.verify_batch([inst, inst, inst], [proofs[0], proofs[1], bad]) == [True, True, False]
+    finally:
+        pk.close()
