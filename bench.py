@@ -559,6 +559,17 @@ def main():
             "kernel_ms": {kname: v for kname, v in timings.items() if v["launches"]},
         }
         line["config"]["host_threads_pinned_to_numa_node"] = numa_node
+        if (is_full or is_verify) and acc["ms"] > 0:
+            # the bound that actually binds this kernel: bucket additions per second against the rate
+            # the same XYZZ mixed addition reaches in isolation (profiles/r01_ubench_field_gfx950.txt), i.e. the integer
+            # multiplier peak; kernel time is summed over the host threads' contexts, so overlapping batches understate it
+            wb = getattr(wl, "window_bits", 0) or 11
+            nwin = (256 + wb - 1) // wb
+            npts = (1 << wl.k) + 2
+            scalars = (acc["algorithmic_bytes"] - 64.0 * npts * acc["launches"]) / 32.0
+            adds = scalars * nwin
+            line["roofline"]["alu_equivalent"] = {"unit": "G mixed additions/s", "achieved": adds / (acc["ms"] * 1e-3) / 1e9, "peak": 14.2,
+                                                  "frac": adds / (acc["ms"] * 1e-3) / 1e9 / 14.2, "table_rows": nwin}
         if is_verify:
             line["metric"] = "proof verifications per second, BattleZips-shaped circuit, k=%d, IPA/Pasta" % wl.k
             line["unit"] = "verifications/s"
