@@ -26,6 +26,7 @@ workload (weak scaling) and the only collective is one RCCL all_gather of the ra
 the timed region.
 """
 import argparse
+import types
 import json
 import os
 import sys
@@ -65,6 +66,27 @@ def pin_to_gpu_numa(local_rank):
     return None
 
 
+def run_threads(fn, count):
+    """fn(0) on the calling thread, fn(1..count-1) on helper threads; an exception in any of them is re-raised here
+    (a failed batch must fail the run, not silently shorten the step)."""
+    import threading
+    errors = []
+
+    def guarded(i):
+        try:
+            fn(i)
+        except BaseException as e:  # noqa: BLE001
+            errors.append(e)
+    ths = [threading.Thread(target=guarded, args=(i,)) for i in range(1, count)]
+    for t in ths:
+        t.start()
+    guarded(0)
+    for t in ths:
+        t.join()
+    if errors:
+        raise errors[0]
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -72,7 +94,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="proof_k14",
                     choices=["board_k14", "board_k12", "shot_k11", "board_k17", "shot_k11_batch", "msm24", "msm20", "ntt22",
-                             "proof_k11", "proof_k12", "proof_k14", "proof_k8", "proof_k17", "verify_k11", "verify_k14"])
+                             "proof_k11", "proof_k12", "proof_k14", "proof_k8", "proof_k17", "verify_k11", "verify_k14", "mixed_board_shot"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + several ranks on one GPU rehearses the multi-rank path on a single-GPU box (ranks share device "
@@ -162,6 +184,51 @@ class Workload:
             self.desc = {"k": k, "proofs_per_step": proofs, "msm": "%dx2^%d vesta" % (28 * proofs, k),
                          "ntt": "%dx iNTT 2^%d + %dx coset NTT 2^%d + %dx coset iNTT 2^%d (Fp)" % (17 * proofs, k, 18 * proofs, k + 3, proofs, k + 3)}
             self.result = self.msm_out
+        elif name == "mixed_board_shot":
+            # BASELINE.json configs[3] on one GPU: Board-sized (k = 14) and Shot-sized (k = 11) proofs in the 1 : 10 ratio of
+            # "256 Board + 2560 Shot", two host threads per circuit, every thread its own ctx / stream / proving key
+            import threading
+            from bzh2 import native as N, synth
+            from bzh2.device import DeviceOps
+            self.k = 14
+            b14 = max(batch // 2, 1)
+            plan = [(14, b14), (11, 10 * b14), (14, b14), (11, 10 * b14)]
+            self.mix = []
+            as_pt = lambda a: (bzh2.limbs_to_int(a[:4]), bzh2.limbs_to_int(a[4:]))
+            for wi, (k, bsz) in enumerate(plan):
+                n = 1 << k
+                if wi == 0:
+                    wctx = ctx
+                else:
+                    st = torch.cuda.Stream(device=device)
+                    wctx = bzh2.Context(device.index or 0, stream=st.cuda_stream)
+                circ, adv, inst = synth.battlezips_shaped(k, seed + k)
+                g = [as_pt(a) for a in make_bases(wctx, self.curve, n + 2, seed + 1)]
+                npk = N.NativeProvingKey(wctx, circ, self.curve, g[:n], g[n + 1], g[n])
+                ops = DeviceOps(wctx, self.field, self.curve, npk.p, device)
+                adv_b = torch.stack([ops.upload(list(col) + [0] * (n - len(col))) for col in adv]).unsqueeze(0).repeat(bsz, 1, 1, 1).contiguous()
+                rbs = [np.random.default_rng(seed + 100 * wi + i).bytes(npk.rng_bytes) for i in range(bsz)]
+                self.mix.append((npk, adv_b, [inst] * bsz, rbs, wctx))
+            torch.cuda.synchronize(device)
+            self.workers = [(None if wi == 0 else True, types.SimpleNamespace(ctx=m[4])) for wi, m in enumerate(self.mix)]
+            self.proofs_made = [0] * len(plan)
+
+            def prove_one(wi):
+                npk, adv_b, insts, rbs, _ = self.mix[wi]
+                proofs = npk.prove_batch(None, insts, rbs, device_ptr=adv_b.data_ptr())
+                self.proofs_made[wi] = len(proofs)
+                if wi == 0:
+                    self.last_proof = proofs[0]
+
+            def prove():
+                run_threads(prove_one, len(plan))
+            self.calls = [("bzh_prove_batch x4 (2 Board k=14, 2 Shot k=11)", prove)]
+            self.units_per_step = sum(b for _, b in plan)
+            self.alg_bytes_msm_launch = 0
+            self.alg_bytes_step = 0
+            self.last_proof = b""
+            self.desc = {"mix": "per step %d Board-sized (k=14) + %d Shot-sized (k=11) proofs" % (2 * b14, 20 * b14)}
+            self.result = torch.zeros((1, 12), dtype=torch.int64, device=device)
         elif name.startswith("verify_k"):
             # the reference's second benchmark (benches/board.rs:80-86): verify_proof over a batch of proofs of the
             # BattleZips-shaped circuit, made once (untimed) by bzh_prove_batch; one step = one bzh_verify_batch call
@@ -247,15 +314,7 @@ class Workload:
             def prove():
                 rbs = [self.rng_pool[(self.step_no + wi) % len(self.rng_pool)] for wi in range(concurrency)]
                 self.step_no += 1
-                if concurrency == 1:
-                    prove_one(0, rbs[0])
-                    return
-                ths = [threading.Thread(target=prove_one, args=(wi, rbs[wi])) for wi in range(1, concurrency)]
-                for t in ths:
-                    t.start()
-                prove_one(0, rbs[0])
-                for t in ths:
-                    t.join()
+                run_threads(lambda wi: prove_one(wi, rbs[wi]), concurrency)
             self.calls = [("create_proof", prove)]
             if batch > 1:
                 # lockstep batch: the same witness columns for every proof of the batch (each proof still draws its own
@@ -285,12 +344,7 @@ class Workload:
                 def prove_batch():
                     sn = self.step_no
                     self.step_no += 1
-                    ths = [threading.Thread(target=prove_batch_one, args=(wi, sn)) for wi in range(1, concurrency)]
-                    for t in ths:
-                        t.start()
-                    prove_batch_one(0, sn)
-                    for t in ths:
-                        t.join()
+                    run_threads(lambda wi: prove_batch_one(wi, sn), concurrency)
                 self.calls = [("create_proofs", prove_batch)]
             self.alg_bytes_msm_launch = 0
             self.alg_bytes_step = 0  # filled from the library's own counters (bzh_ctx_work) after the timed region
@@ -376,12 +430,7 @@ class Workload:
         def prove():
             sn = self.step_no
             self.step_no += 1
-            ths = [threading.Thread(target=prove_one, args=(wi, sn)) for wi in range(1, concurrency)]
-            for t in ths:
-                t.start()
-            prove_one(0, sn)
-            for t in ths:
-                t.join()
+            run_threads(lambda wi: prove_one(wi, sn), concurrency)
         self.calls = [("bzh_prove_batch", prove)]
         self.alg_bytes_msm_launch = 0
         self.alg_bytes_step = 0
@@ -505,13 +554,14 @@ def main():
         is_proof = args.workload.startswith(("board", "shot"))
         is_full = args.workload.startswith("proof_k")
         is_verify = args.workload.startswith("verify_k")
+        is_mixed = args.workload == "mixed_board_shot"
         acc = timings["msm_accumulate"]
         nt = timings["ntt"]
         if args.workload == "ntt22":
             dom_ms = nt["ms"] / max(nt["launches"], 1) * (nt["launches"] / max(args.steps, 1))  # all passes of one NTT
             alg = wl.alg_bytes_step
             dom_name = "k_ntt_pass (all passes of one 2^22 NTT)"
-        elif is_full or is_verify:
+        elif is_full or is_verify or is_mixed:
             # MSM launches of a proof differ in size (28 column commits batched by phase, then the halving IPA
             # rounds): average the bytes the library counted per launch (bzh_ctx_work) over the same launches
             dom_ms = acc["ms"] / max(acc["launches"], 1)
@@ -570,6 +620,10 @@ def main():
             adds = scalars * nwin
             line["roofline"]["alu_equivalent"] = {"unit": "G mixed additions/s", "achieved": adds / (acc["ms"] * 1e-3) / 1e9, "peak": 14.2,
                                                   "frac": adds / (acc["ms"] * 1e-3) / 1e9 / 14.2, "table_rows": nwin}
+        if is_mixed:
+            line["metric"] = "complete proofs per second, Board-sized (k=14) : Shot-sized (k=11) = 1 : 10, IPA/Pasta"
+            line["unit"] = "proofs/s"
+            line["config"]["stages"] = "complete create_proof for every proof of the mix (bzh_prove_batch), witnesses resident in HBM"
         if is_verify:
             line["metric"] = "proof verifications per second, BattleZips-shaped circuit, k=%d, IPA/Pasta" % wl.k
             line["unit"] = "verifications/s"
