@@ -23,7 +23,7 @@
 namespace bzh {
 
 static constexpr int kTileElems = 2048;  // 64 KiB of LDS per workgroup
-static constexpr int kNttThreads = 256;
+static constexpr int kNttThreads = 256;  // 512 measured slower (130 VGPRs: still one 8-wave workgroup per CU)
 
 struct NttPassArgs {
     const uint32_t* src;  // pass input  (same index map as dst)
