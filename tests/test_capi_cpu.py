@@ -84,3 +84,16 @@ def test_normalize_and_compress_match_oracle(bzh2_lib, cid):
     arr_m = C.ints_to_array([x * R % p for x in jac]).reshape(-1, 12)
     aff_m = bzh2_lib.jacobian_to_affine(cid, arr_m, bzh2_lib.FORM_MONTGOMERY)
     assert bzh2_lib.affine_compress(cid, aff_m, bzh2_lib.FORM_MONTGOMERY) == [cv.compress(pt) for pt in pts]
+
+
+def test_cpp_example_client_compiles_against_the_header():
+    """examples/prove_batch.cpp is the compiled-code client of include/bzh2.h (what a Rust shim's call sequence looks like):
+    it has to keep compiling with a plain C++ compiler against the header alone (no HIP, no torch)."""
+    import shutil
+    import subprocess
+    cxx = shutil.which("g++")
+    if cxx is None:
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call([cxx, "-std=c++17", "-fsyntax-only", "-Wall", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "examples", "prove_batch.cpp")])
