@@ -432,6 +432,7 @@ class Workload:
             self.step_no += 1
             run_threads(lambda wi: prove_one(wi, sn), concurrency)
         self.calls = [("bzh_prove_batch", prove)]
+        self.solo_step = lambda: prove_one(0, self.step_no)
         self.alg_bytes_msm_launch = 0
         self.alg_bytes_step = 0
         self.desc = {"k": self.k, "circuit": "synthetic, BattleZips-shaped: 11 advice / 8 fixed / 1 instance, 24 gates, degree 9, "
@@ -544,6 +545,19 @@ def main():
                 timings[kname][f] += v[f]
     for c in all_ctx:
         c.profile(False)
+    # The same kernels with ONE batch in flight (two extra, untimed steps on the first context): with several batches
+    # overlapping, every kernel shares the GPU with the others' and its own duration stretches, which says nothing about
+    # the kernel.  Reported beside the timed region's figures as roofline.single_batch_in_flight.
+    solo = None
+    if rank == 0 and hasattr(wl, "solo_step") and len(all_ctx) > 1:
+        wl.solo_step()
+        torch.cuda.synchronize(device)
+        ctx.profile(True)
+        for _ in range(2):
+            wl.solo_step()
+        torch.cuda.synchronize(device)
+        solo = ctx.timings()["msm_accumulate"]
+        ctx.profile(False)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -620,6 +634,15 @@ def main():
             adds = scalars * nwin
             line["roofline"]["alu_equivalent"] = {"unit": "G mixed additions/s", "achieved": adds / (acc["ms"] * 1e-3) / 1e9, "peak": 14.2,
                                                   "frac": adds / (acc["ms"] * 1e-3) / 1e9 / 14.2, "table_rows": nwin}
+            if solo is not None and solo["ms"] > 0:
+                s_ms = solo["ms"] / max(solo["launches"], 1)
+                s_alg = solo["algorithmic_bytes"] / max(solo["launches"], 1)
+                s_adds = (solo["algorithmic_bytes"] - 64.0 * npts * solo["launches"]) / 32.0 * nwin
+                line["roofline"]["single_batch_in_flight"] = {
+                    "avg_launch_ms": s_ms, "achieved": s_alg / (s_ms * 1e-3) / 1e9, "frac": s_alg / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "alu_equivalent": {"achieved": s_adds / (solo["ms"] * 1e-3) / 1e9, "peak": 14.2, "frac": s_adds / (solo["ms"] * 1e-3) / 1e9 / 14.2},
+                    "note": "same kernel, one batch in flight (2 untimed steps after the timed region); in the timed region "
+                            "%d batches share the GPU and every launch stretches accordingly" % len(all_ctx)}
         if is_mixed:
             line["metric"] = "complete proofs per second, Board-sized (k=14) : Shot-sized (k=11) = 1 : 10, IPA/Pasta"
             line["unit"] = "proofs/s"
