@@ -242,7 +242,9 @@ __global__ void __launch_bounds__(T) k_msm_accumulate(const uint32_t* __restrict
     uint16_t* sorted = reinterpret_cast<uint16_t*>(idB + T);
 
     const int tid = threadIdx.x;
-    const size_t ck = blockIdx.x, w = blockIdx.y, b = blockIdx.z, nchunks = gridDim.x;
+    // vector index fastest: workgroups dispatched together (and dealt round-robin to the XCDs) work on the SAME chunk of
+    // different vectors, i.e. gather from the same 2 MB window of the base table, which then lives in every XCD's L2
+    const size_t b = blockIdx.x, w = blockIdx.y, ck = blockIdx.z, nchunks = gridDim.z;
     const size_t c0 = ck * chunk;
     const int len = (int)min(chunk, n - c0);
     const uint16_t* dg = digits + (b * (size_t)nwin + w) * n + c0;
@@ -1103,7 +1105,7 @@ static int msm_run_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_sca
         {
             ScopedTimer t(ctx, BZH_T_MSM_ACCUMULATE);
             if (ctx->profiling) ctx->alg_bytes[BZH_T_MSM_ACCUMULATE] += (double)nb * (double)n * 32.0 + (double)n * 64.0;
-            const dim3 grid((unsigned)p.nchunks, (unsigned)acc_nwin, (unsigned)nb);
+            const dim3 grid((unsigned)nb, (unsigned)acc_nwin, (unsigned)p.nchunks);
 #define BZH_LAUNCH_ACC(TT)                                                                                              \
     hipLaunchKernelGGL((k_msm_accumulate<C, TT>), grid, dim3(TT), acc_lds, ctx->stream, bases->d_xy,                      \
                        (const uint16_t*)d_digits, n_eff, acc_nwin, M_acc, p.chunk, (uint4*)d_buckets, d_partials, row_len, \
