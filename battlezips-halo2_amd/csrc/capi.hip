@@ -2,6 +2,7 @@
 // staging around the MSM / NTT drivers, and the host-side helpers.
 #include <cstring>
 #include <algorithm>
+#include <thread>
 #include <new>
 #include <vector>
 
@@ -153,12 +154,23 @@ static int permute_pair_host(const uint64_t* input, const uint64_t* table, size_
         bool operator==(const Key& o) const { return !memcmp(l, o.l, 32); }
     };
     std::vector<Key> a(usable), t(usable);
-    for (size_t i = 0; i < usable; i++) {
-        store_host<PP>(a[i].l, load_host<PP>(input + 4 * i, form), BZH_FORM_CANONICAL);
-        store_host<PP>(t[i].l, load_host<PP>(table + 4 * i, form), BZH_FORM_CANONICAL);
+    if (form == BZH_FORM_CANONICAL) {  // canonical limbs ARE the sort keys: no field arithmetic on the host
+        memcpy(a.data(), input, usable * 32);
+        memcpy(t.data(), table, usable * 32);
+    } else {
+        for (size_t i = 0; i < usable; i++) {
+            store_host<PP>(a[i].l, load_host<PP>(input + 4 * i, form), BZH_FORM_CANONICAL);
+            store_host<PP>(t[i].l, load_host<PP>(table + 4 * i, form), BZH_FORM_CANONICAL);
+        }
     }
-    std::sort(a.begin(), a.end());
-    std::sort(t.begin(), t.end());
+    if (usable >= 4096) {  // the two sorts are independent: a second thread takes the table
+        std::thread other([&]() { std::sort(t.begin(), t.end()); });
+        std::sort(a.begin(), a.end());
+        other.join();
+    } else {
+        std::sort(a.begin(), a.end());
+        std::sort(t.begin(), t.end());
+    }
     // leftover multiset = table minus one copy of every distinct input value
     std::vector<Key> s(usable);
     std::vector<size_t> repeated;
@@ -179,6 +191,11 @@ static int permute_pair_host(const uint64_t* input, const uint64_t* table, size_
         if (repeated.empty()) return BZH_E_RANGE;
         s[repeated.back()] = t[j];
         repeated.pop_back();
+    }
+    if (form == BZH_FORM_CANONICAL) {
+        memcpy(out_input, a.data(), usable * 32);
+        memcpy(out_table, s.data(), usable * 32);
+        return BZH_OK;
     }
     for (size_t i = 0; i < usable; i++) {
         store_host<PP>(out_input + 4 * i, load_host<PP>(a[i].l, BZH_FORM_CANONICAL), form);

@@ -1194,8 +1194,14 @@ int Prover<C>::prove(const uint32_t* d_advice_in, const uint64_t* instances, siz
         PV_TRY(pin_big_take(ctx, B * n * 32, &ah_c));
         PV_TRY(pin_big_take(ctx, B * n * 32, &sh_c));
         PV_TRY(pin_big_take(ctx, B * 2 * n * 32, &as_c));
-        PV_TRY(xfer_launch(ctx, ah_c, d.a_c, B * n * 32, hipMemcpyDeviceToHost));
-        PV_TRY(xfer_launch(ctx, sh_c, d.s_c, B * n * 32, hipMemcpyDeviceToHost));
+        // the host sorts canonical integers: convert on the device (copies; the Montgomery originals feed the grand product)
+        uint32_t* canon = dalloc(2 * B * n);
+        if (!canon) return BZH_E_OOM;
+        BZH_HIP_TRY(ctx, hipMemcpyAsync(canon, d.a_c, B * n * 32, hipMemcpyDeviceToDevice, st));
+        BZH_HIP_TRY(ctx, hipMemcpyAsync(canon + B * n * 8, d.s_c, B * n * 32, hipMemcpyDeviceToDevice, st));
+        PV_TRY(field_convert(ctx, field, canon, 2 * B * n, 0));
+        PV_TRY(xfer_launch(ctx, ah_c, canon, B * n * 32, hipMemcpyDeviceToHost));
+        PV_TRY(xfer_launch(ctx, sh_c, canon + B * n * 8, B * n * 32, hipMemcpyDeviceToHost));
         BZH_HIP_TRY(ctx, hipStreamSynchronize(st));
         const uint64_t* ah = (const uint64_t*)ah_c;
         const uint64_t* sh = (const uint64_t*)sh_c;
@@ -1211,7 +1217,7 @@ int Prover<C>::prove(const uint32_t* d_advice_in, const uint64_t* instances, siz
             for (size_t t = 0; t < nthreads; t++)
                 th.emplace_back([&, t]() {
                     for (size_t b = t; b < B; b += nthreads)
-                        rcs[b] = bzh_permute_expression_pair(field, &ah[b * n * 4], &sh[b * n * 4], usable, BZH_FORM_MONTGOMERY,
+                        rcs[b] = bzh_permute_expression_pair(field, &ah[b * n * 4], &sh[b * n * 4], usable, BZH_FORM_CANONICAL,
                                                              as + (b * 2) * n * 4, as + (b * 2 + 1) * n * 4);
                 });
             for (auto& t : th) t.join();
@@ -1220,6 +1226,7 @@ int Prover<C>::prove(const uint32_t* d_advice_in, const uint64_t* instances, siz
         }
         mark(" lk:sort");
         PV_TRY(h2d_commit(ctx, d.as, as_c, B * 2 * n * 32));
+        PV_TRY(field_convert(ctx, field, d.as, B * 2 * n, 1));  // back to Montgomery form (the zero rows stay zero)
         mark(" lk:h2d");
         {
             uint32_t* rows = dalloc(B * 2 * bf1);
