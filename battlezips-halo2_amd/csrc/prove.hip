@@ -1828,7 +1828,7 @@ template <class C>
 static bool verify_host(const bzh_pk& pk, const uint64_t* inst_xy, const uint8_t* proof, size_t len, size_t nl_cap,
                         ProofView<C>& out) {
     using SF = typename CurveScalar<C>::SF;
-    const int na = pk.na, nf = pk.nf, ni = pk.ni, nsets = pk.nsets, nl = pk.nl, npieces = pk.npieces, bf = pk.bf;
+    const int na = pk.na, ni = pk.ni, nsets = pk.nsets, nl = pk.nl, npieces = pk.npieces;
     const size_t n = pk.n, m = pk.perm_columns.size();
     const unsigned k = pk.k;
     bzh_transcript* T = nullptr;
@@ -1984,8 +1984,8 @@ static bool verify_host(const bzh_pk& pk, const uint64_t* inst_xy, const uint8_t
     if (bad) return false;
     const Fe<SF> expected_h = fe_mul(hacc, fe_inv(xn1));
 
-    // multiopen: evaluation of commitment `cid` at rotation r, and its place in the linear combination
-    const int last_rot = -(bf + 1);
+    // multiopen: evaluation of commitment `cid` at rotation r (a permutation product's third rotation is -(blinding + 1)),
+    // and its place in the linear combination
     auto eval_of = [&](uint64_t cid, int r) -> Fe<SF> {
         const int kind = (int)(cid >> 32);
         const size_t i = (size_t)(cid & 0xffffffffu);
