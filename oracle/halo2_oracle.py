@@ -160,25 +160,32 @@ def build_permutation(cs: ConstraintSystem, copies):
 class Keys:
     """Proving/verifying key material: fixed columns, permutation polynomials, l_0 / l_last / l_blind."""
 
-    def __init__(self, cs, dom, curve, g, w, u, fixed, copies, vk_repr=0x1234):
+    def __init__(self, cs, dom, curve, g, w, u, fixed, copies, vk_repr=0x1234, verifier_only=False):
+        """verifier_only: keep what verify_proof reads (the vk: commitments of the fixed and permutation polynomials) and
+        skip the prover's extended-coset forms -- the big-int NTTs of size 2^(k+3) that make large k impractical."""
         self.cs, self.dom, self.curve, self.g, self.w, self.u = cs, dom, curve, g, w, u
         F, p, n = dom.F, dom.F.p, cs.n
         self.vk_repr = vk_repr % p
         self.fixed = [list(col) + [0] * (n - len(col)) for col in fixed]
         self.fixed_polys = [dom.lagrange_to_coeff(c) for c in self.fixed]
-        self.fixed_cosets = [dom.coeff_to_extended(c) for c in self.fixed_polys]
         mapping = build_permutation(cs, copies)
-        self.sigma = [[pow(dom.delta, mapping[c][r][0], p) * pow(dom.omega, mapping[c][r][1], p) % p for r in range(n)]
+        dpow = [pow(dom.delta, c, p) for c in range(len(cs.perm_columns))]
+        wpow = [1] * n
+        for r in range(1, n):
+            wpow[r] = wpow[r - 1] * dom.omega % p
+        self.sigma = [[dpow[mapping[c][r][0]] * wpow[mapping[c][r][1]] % p for r in range(n)]
                       for c in range(len(cs.perm_columns))]
         self.sigma_polys = [dom.lagrange_to_coeff(s) for s in self.sigma]
-        self.sigma_cosets = [dom.coeff_to_extended(s) for s in self.sigma_polys]
-        last = cs.usable_rows                              # row n - (blinding_factors + 1)
-        self.l0 = dom.lagrange_basis_ext(0)
-        self.l_last = dom.lagrange_basis_ext(last)
-        lb = [0] * n
-        for r in range(last + 1, n):
-            lb[r] = 1
-        self.l_blind = dom.coeff_to_extended(dom.lagrange_to_coeff(lb))
+        if not verifier_only:
+            self.fixed_cosets = [dom.coeff_to_extended(c) for c in self.fixed_polys]
+            self.sigma_cosets = [dom.coeff_to_extended(s) for s in self.sigma_polys]
+            last = cs.usable_rows                              # row n - (blinding_factors + 1)
+            self.l0 = dom.lagrange_basis_ext(0)
+            self.l_last = dom.lagrange_basis_ext(last)
+            lb = [0] * n
+            for r in range(last + 1, n):
+                lb[r] = 1
+            self.l_blind = dom.coeff_to_extended(dom.lagrange_to_coeff(lb))
         self.fixed_commitments = [self.commit(c, 1) for c in self.fixed_polys]
         self.sigma_commitments = [self.commit(c, 1) for c in self.sigma_polys]
 

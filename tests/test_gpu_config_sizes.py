@@ -1,0 +1,96 @@
+"""BASELINE.json configs at their OWN sizes, through the C ABI, against the C oracle (oracle/oracle.c):
+  configs[4]  2^24-point MSM on Vesta (plain bases and fixed-base window table) == best_multiexp restatement
+  configs[4]  2^22 NTT over Fp: forward, ZETA-coset and inverse, the full vector bit for bit
+Reference seams: halo2_proofs `best_multiexp` / `best_fft` as reached from create_proof (benches/shot.rs:68,
+benches/board.rs:61-68).  Scalars / elements are uniform below the modulus (tests/randutil.py)."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+import coracle as C
+import pasta as O
+from randutil import FIELD_MODULUS, SCALAR_MODULUS, uniform_below
+
+pytestmark = pytest.mark.gpu
+
+THREADS = max(1, min(32, os.cpu_count() or 1))
+
+
+def test_msm_2_24_vesta_matches_oracle_plain_and_window_table(gpu_ctx, oracle_c):
+    import bzh2
+    cid, n = 0, 1 << 24
+    cv = O.VESTA
+    g = cv.random_point(random.Random(2024))
+    bases = C.point_walk(cid, C.points_to_array([g])[0], n)         # G_i = [i+1]G, affine, from the C oracle
+    rng = np.random.default_rng(24)
+    sc = uniform_below(rng, n, SCALAR_MODULUS[cid])
+    sc[7] = 0
+    sc[8] = C.int_to_limbs(SCALAR_MODULUS[cid] - 1)
+    want = cv.compress(C.array_to_point(C.msm(cid, sc, bases, THREADS)))
+    assert want != bytes(32)
+    hb = gpu_ctx.upload_bases(cid, bases)
+    try:
+        jac = gpu_ctx.msm(hb, sc)
+        got = bzh2.affine_compress(cid, bzh2.jacobian_to_affine(cid, jac))
+        assert got == [want]
+        hb.precompute(13)                                            # 20 table rows of 2^24 points: 20 GiB of HBM
+        jac = gpu_ctx.msm(hb, sc)
+        got = bzh2.affine_compress(cid, bzh2.jacobian_to_affine(cid, jac))
+        assert got == [want]
+    finally:
+        hb.free()
+
+
+def test_ntt_2_22_full_vector_matches_oracle(gpu_ctx, oracle_c):
+    F = O.FP
+    k = 22
+    n = 1 << k
+    rng = np.random.default_rng(2222)
+    a = uniform_below(rng, n, FIELD_MODULUS[0])
+    w = F.omega(k)
+    zeta = pow(F.g, (F.p - 1) // 3, F.p)
+    fwd = gpu_ctx.ntt(0, a, omega=w)
+    assert (fwd == C.ntt(0, a, w, threads=THREADS)).all()
+    cos = gpu_ctx.ntt(0, a, omega=w, coset_shift=zeta)
+    assert (cos == C.ntt(0, a, w, coset_shift=zeta, threads=THREADS)).all()
+    inv = gpu_ctx.ntt(0, a, omega=w, inverse=True)
+    assert (inv == C.ntt(0, a, w, inverse=True, threads=THREADS)).all()
+    cinv = gpu_ctx.ntt(0, a, omega=w, inverse=True, coset_shift=F.g)
+    assert (cinv == C.ntt(0, a, w, inverse=True, coset_shift=F.g, threads=THREADS)).all()
+
+
+def test_k17_native_proof_passes_the_oracle_verifier(gpu_ctx, oracle_c, monkeypatch):
+    """BASELINE.json's metric names k = 17: one complete proof of the BattleZips-shaped circuit at k = 17 made by
+    bzh_prove_batch must be accepted by the ORACLE's verify_proof (n-term MSMs and the size-n inverse NTTs of the vk
+    delegated to the C oracle -- same definitions, the big-int loops would take hours), a tampered copy rejected."""
+    import bzh2
+    import halo2_oracle as H
+    from bzh2 import native as N, synth
+    cv, F = O.VESTA, O.FP
+    k = 17
+    circ, adv, inst = synth.battlezips_shaped(k, seed=1717)
+    cs = H.ConstraintSystem(circ.k, 11, 8, 1, circ.gates, circ.perm_columns, circ.lookups, degree=9)
+    rng = random.Random(171717)
+    g0 = cv.random_point(rng)
+    walk = C.point_walk(0, C.points_to_array([g0])[0], cs.n + 2)
+    pts = [C.array_to_point(walk[i]) for i in range(cs.n + 2)]
+    g, u, w = pts[:cs.n], pts[cs.n], pts[cs.n + 1]
+    fast = lambda self, scalars, points: C.array_to_point(C.msm(0, C.ints_to_array([int(s) % F.p for s in scalars]),
+                                                                   C.points_to_array(points), THREADS))
+    monkeypatch.setattr(type(cv), "msm_naive", fast)
+    monkeypatch.setattr(H.Domain, "lagrange_to_coeff",
+                        lambda self, v: C.array_to_ints(C.ntt(0, C.ints_to_array(v), self.omega, inverse=True, threads=THREADS)))
+    keys = H.Keys(cs, H.Domain(cs, F), cv, g, w, u, circ.fixed, circ.copies, verifier_only=True)
+    pk = N.NativeProvingKey(gpu_ctx, circ, bzh2.CURVE_VESTA, g, w, u)
+    try:
+        rb = bytes(rng.getrandbits(8) for _ in range(pk.rng_bytes))
+        advs = np.stack([np.stack([C.ints_to_array(list(col) + [0] * (cs.n - len(col))) for col in adv])])
+        proof = pk.prove_batch(advs, [inst], [rb])[0]
+        assert H.verify_proof(keys, inst, proof, O.Blake2bTranscript(F))
+        bad = proof[:900] + bytes([proof[900] ^ 1]) + proof[901:]
+        assert not H.verify_proof(keys, inst, bad, O.Blake2bTranscript(F))
+        assert pk.verify_batch([inst, inst], [proof, bad]) == [True, False]
+    finally:
+        pk.close()

@@ -8,14 +8,14 @@ import pytest
 
 import coracle as C
 import pasta as O
+from randutil import SCALAR_MODULUS, uniform_below
 
 pytestmark = pytest.mark.gpu
 
 
-def rand_scalars(rng, n, modulus):
-    a = np.frombuffer(rng.bytes(n * 32), dtype=np.uint64).reshape(n, 4).copy()
-    a[:, 3] &= (1 << 61) - 1          # < 2^253 < every modulus used here
-    return a
+def rand_scalars(rng, n, cid=0):
+    """uniform below the scalar-field modulus of curve `cid` (tests/randutil.py)"""
+    return uniform_below(rng, n, SCALAR_MODULUS[cid])
 
 
 def walk_bases(cid, n, seed):
@@ -51,7 +51,7 @@ def test_msm_matches_oracle(gpu_ctx, oracle_c, cid, n):
     import bzh2
     rng = np.random.default_rng(1000 * cid + n)
     bases = walk_bases(cid, n, seed=cid)
-    sc = rand_scalars(rng, n, None)
+    sc = rand_scalars(rng, n, cid)
     assert gpu_msm_compressed(bzh2, gpu_ctx, cid, bases, sc) == oracle_compressed(cid, bases, sc)
 
 
@@ -88,12 +88,12 @@ def test_msm_empty_and_prefix(gpu_ctx, oracle_c):
         out = gpu_ctx.msm(b, np.zeros((0, 4), dtype=np.uint64))
         assert (out == 0).all()                     # empty sum = identity (Z = 0)
         rng = np.random.default_rng(4)
-        sc = rand_scalars(rng, 40, None)            # shorter than the table: prefix, like Params::commit
+        sc = rand_scalars(rng, 40)            # shorter than the table: prefix, like Params::commit
         jac = gpu_ctx.msm(b, sc)
         got = bzh2.affine_compress(0, bzh2.jacobian_to_affine(0, jac))
         assert got == oracle_compressed(0, bases, sc)
         with pytest.raises(bzh2.BzhError):          # longer than the table: upstream asserts
-            gpu_ctx.msm(b, rand_scalars(rng, 65, None))
+            gpu_ctx.msm(b, rand_scalars(rng, 65))
     finally:
         b.free()
 
@@ -104,7 +104,7 @@ def test_msm_batched_shared_bases_and_montgomery(gpu_ctx, oracle_c):
     n, batch = 2048, 28
     rng = np.random.default_rng(5)
     bases = walk_bases(0, n, seed=9)
-    sc = rand_scalars(rng, n * batch, None).reshape(batch, n, 4)
+    sc = rand_scalars(rng, n * batch).reshape(batch, n, 4)
     want = oracle_compressed(0, bases, sc)
     assert gpu_msm_compressed(bzh2, gpu_ctx, 0, bases, sc) == want
     R, p = O.FP.R, O.FP.p
@@ -119,7 +119,7 @@ def test_msm_medium_matches_oracle(gpu_ctx, oracle_c, log_n):
     n = 1 << log_n
     rng = np.random.default_rng(log_n)
     bases = walk_bases(0, n, seed=log_n)
-    sc = rand_scalars(rng, n, None)
+    sc = rand_scalars(rng, n)
     assert gpu_msm_compressed(bzh2, gpu_ctx, 0, bases, sc) == oracle_compressed(0, bases, sc)
 
 
@@ -131,8 +131,8 @@ def test_msm_large_linearity(gpu_ctx, oracle_c):
     cv = O.VESTA
     rng = np.random.default_rng(18)
     bases = walk_bases(0, n, seed=18)
-    a = rand_scalars(rng, n, None)
-    b = rand_scalars(rng, n, None)
+    a = rand_scalars(rng, n)
+    b = rand_scalars(rng, n)
     ai, bi = C.array_to_ints(a), C.array_to_ints(b)
     ab = C.ints_to_array([(x + y) % O.P for x, y in zip(ai, bi)])
     hb = gpu_ctx.upload_bases(0, bases)
@@ -155,7 +155,7 @@ def test_msm_precomputed_table_matches_oracle(gpu_ctx, oracle_c, cid, n, c):
     import bzh2
     rng = np.random.default_rng(7000 * cid + n + c)
     bases = walk_bases(cid, n, seed=40 + cid)
-    sc = rand_scalars(rng, n, None)
+    sc = rand_scalars(rng, n, cid)
     want = oracle_compressed(cid, bases, sc)
     assert gpu_msm_compressed(bzh2, gpu_ctx, cid, bases, sc, precompute=c) == want
 
@@ -173,11 +173,11 @@ def test_msm_precomputed_prefix_batch_and_edges(gpu_ctx, oracle_c):
     hb = gpu_ctx.upload_bases(0, bases).precompute()
     try:
         for m in (1, 2, 1000, 2999, 3000):          # prefixes (row_len != row_stride)
-            sc = rand_scalars(rng, m, None)
+            sc = rand_scalars(rng, m)
             jac = gpu_ctx.msm(hb, sc)
             got = bzh2.affine_compress(0, bzh2.jacobian_to_affine(0, jac))
             assert got == oracle_compressed(0, bases, sc), m
-        batch = np.stack([rand_scalars(rng, n, None) for _ in range(5)])
+        batch = np.stack([rand_scalars(rng, n) for _ in range(5)])
         batch[1] = C.ints_to_array([r - 1] * n)     # every digit identical: one bucket per window
         batch[2] = 0
         batch[3] = C.ints_to_array([1] * n)
@@ -194,7 +194,7 @@ def test_msm_precomputed_2_16_matches_oracle(gpu_ctx, oracle_c):
     n = 1 << 16
     rng = np.random.default_rng(16)
     bases = walk_bases(0, n, seed=16)
-    sc = rand_scalars(rng, n, None)
+    sc = rand_scalars(rng, n)
     assert gpu_msm_compressed(bzh2, gpu_ctx, 0, bases, sc, precompute=0) == oracle_compressed(0, bases, sc)
 
 
@@ -209,7 +209,7 @@ def test_msm_precomputed_many_vectors_chunk_presum(gpu_ctx, oracle_c):
     hb = gpu_ctx.upload_bases(0, bases).precompute(11)
     try:
         r = O.VESTA.scalar.p
-        batch = np.stack([rand_scalars(rng, n, None) for _ in range(nvec)])
+        batch = np.stack([rand_scalars(rng, n) for _ in range(nvec)])
         batch[3] = 0
         batch[5] = C.ints_to_array([r - 1] * n)          # every digit identical
         batch[7, : n // 2] = 0                           # half-empty vector: empty chunks

@@ -6,14 +6,14 @@ import pytest
 
 import coracle as C
 import pasta as O
+from randutil import FIELD_MODULUS, uniform_below
 
 pytestmark = pytest.mark.gpu
 
 
-def rand_elems(rng, n):
-    a = np.frombuffer(rng.bytes(n * 32), dtype=np.uint64).reshape(n, 4).copy()
-    a[:, 3] &= (1 << 61) - 1
-    return a
+def rand_elems(rng, n, fid=0):
+    """uniform below the modulus of field `fid` (tests/randutil.py)"""
+    return uniform_below(rng, n, FIELD_MODULUS[fid])
 
 
 @pytest.mark.parametrize("fid", [0, 1, 2])
@@ -21,7 +21,7 @@ def rand_elems(rng, n):
 def test_ntt_matches_oracle(gpu_ctx, oracle_c, fid, k):
     F = O.FIELD_BY_ID[fid]
     rng = np.random.default_rng(100 * fid + k)
-    a = rand_elems(rng, 1 << k)
+    a = rand_elems(rng, 1 << k, fid)
     w = F.omega(k)
     got = gpu_ctx.ntt(fid, a, omega=w)
     assert (got == C.ntt(fid, a, w, threads=8)).all()
@@ -59,7 +59,7 @@ def test_ntt_batched_and_montgomery(gpu_ctx, oracle_c):
 def test_ntt_default_omega_is_domain_generator(gpu_ctx, oracle_c):
     F = O.FQ
     rng = np.random.default_rng(8)
-    a = rand_elems(rng, 1 << 9)
+    a = rand_elems(rng, 1 << 9, 1)
     assert (gpu_ctx.ntt(1, a) == C.ntt(1, a, F.omega(9))).all()
 
 
@@ -115,6 +115,6 @@ def test_plain_inverse_all_pass_counts(gpu_ctx, oracle_c, k):
     two (k=12) and three (k=19) passes."""
     F = O.FQ
     rng = np.random.default_rng(400 + k)
-    a = rand_elems(rng, 1 << k)
+    a = rand_elems(rng, 1 << k, 1)
     w = F.omega(k)
     assert (gpu_ctx.ntt(1, a, omega=w, inverse=True) == C.ntt(1, a, w, inverse=True, threads=8)).all()
