@@ -435,6 +435,10 @@ class Transcript:
 # ---- IPA opening --------------------------------------------------------------------------------
 EXPORTS += ["bzh_ipa_open", "bzh_ipa_open_batch", "bzh_ipa_verify"]
 EXPORTS += ["bzh_pk_create", "bzh_pk_free", "bzh_pk_info", "bzh_prove_batch", "bzh_verify_batch"]
+# circuit front end (bzh2/circuits.py)
+EXPORTS += ["bzh_circuit_create", "bzh_circuit_free", "bzh_circuit_last_error", "bzh_circuit_blob", "bzh_circuit_describe",
+            "bzh_circuit_info", "bzh_synthesize_shot", "bzh_synthesize_board", "bzh_synthesize_bitify_test", "bzh_board_witness",
+            "bzh_shot_serialize", "bzh_pedersen_commit_host", "bzh_fixed_base_tables"]
 E_VERIFY = -6
 
 

@@ -40,7 +40,8 @@ class NativeProvingKey:
         tbl = np.stack([np.concatenate([int_to_limbs(pt[0]), int_to_limbs(pt[1])]) for pt in list(g) + [u, w]])
         self.bases: Bases = ctx.upload_bases(curve, tbl).precompute(window_bits)
         self._g0_u_w = np.ascontiguousarray(np.stack([tbl[0], tbl[-2], tbl[-1]]))
-        blob = serialize_circuit(circuit, self.p, vk_repr)
+        # a circuit built by the C++ front end (bzh2.circuits.CircuitLayout.blob()) arrives already serialised
+        blob = bytes(circuit) if isinstance(circuit, (bytes, bytearray)) else serialize_circuit(circuit, self.p, vk_repr)
         L = _bind()
         h = _VP()
         ctx._check(L.bzh_pk_create(ctx.handle, self.bases.handle, blob, len(blob), ctypes.byref(h)), "bzh_pk_create")

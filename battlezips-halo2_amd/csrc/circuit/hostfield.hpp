@@ -369,6 +369,23 @@ inline Jac jac_add(const Jac& p, const Jac& q) {
     r.z = ((p.z + q.z).sqr() - z1z1 - z2z2) * h;
     return r;
 }
+// p + q for an affine, non-identity q (madd-2007-bl)
+inline Jac jac_add_mixed(const Jac& p, const Aff& q) {
+    if (p.z.is_zero()) return Jac{q.x, q.y, Fp::one()};
+    const Fp z1z1 = p.z.sqr();
+    const Fp u2 = q.x * z1z1, s2 = q.y * p.z * z1z1;
+    if (u2 == p.x) {
+        if (s2 == p.y) return jac_double(p);
+        return jac_identity();
+    }
+    const Fp h = u2 - p.x, hh = h.sqr(), i = hh.dbl().dbl(), j = h * i;
+    const Fp rr = (s2 - p.y).dbl(), v = p.x * i;
+    Jac r;
+    r.x = rr.sqr() - j - v.dbl();
+    r.y = rr * (v - r.x) - (p.y * j).dbl();
+    r.z = (p.z + h).sqr() - z1z1 - hh;
+    return r;
+}
 inline Jac jac_neg(const Jac& p) { return Jac{p.x, -p.y, p.z}; }
 inline std::vector<Aff> batch_normalize(const std::vector<Jac>& v) {
     std::vector<Fp> zs(v.size());

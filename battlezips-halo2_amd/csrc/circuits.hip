@@ -1,0 +1,642 @@
+// C ABI of the circuit front end (include/bzh2.h, "circuits"): the reference's ShotCircuit / BoardCircuit as
+// constraint-system DATA for bzh_pk_create, and their witness synthesis for bzh_prove_batch.
+//
+// Replaces, on the reference side, `Circuit::configure` + the keygen `synthesize` (keygen_vk / keygen_pk:
+// benches/shot.rs:60-61, benches/board.rs:53-54) and the `synthesize` call-back create_proof makes per proof
+// (src/circuits/shot.rs:40-52 -> src/chips/shot.rs:308-354; src/circuits/board.rs:38-50 ->
+// src/chips/board.rs:331-363).  Chips live in csrc/circuit/*.hpp (host C++); the only device code here is the kernel
+// that expands the compact staged witness into the advice tensor.
+#include <dlfcn.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cstdio>
+#include <memory>
+#include <mutex>
+#include <sstream>
+#include <thread>
+
+#include "circuit/chips.hpp"
+#include "ctx.hpp"
+
+using namespace bzc;
+
+namespace {
+
+// GENERATOR constants of the two fixed bases: hash_to_curve("battlezips:hash2curve")(b"v" / b"r") on Pallas
+// (src/utils/constants/fixed_bases/board_commit_v.rs:5-14, board_commit_r.rs:5-14; their `generator` tests :2941-2948)
+static const uint64_t GEN_V[8] = {0x0aaf6299a6692ca4ull, 0xbd7d655cae1385d7ull, 0xaa3fc3f9268467a3ull, 0x1e2542d216c42158ull,
+                                  0x37a9d7aa880f14b2ull, 0xe705a08374ba472full, 0x0a26f1bc8cffd318ull, 0x32c5c94a039386f8ull};
+static const uint64_t GEN_R[8] = {0xdf6e95bb730e5277ull, 0x1693cb90e5c65c55ull, 0xcfb7d2c81d8bc40cull, 0x1c332c6fa1a9c3d7ull,
+                                  0x04962380847950b8ull, 0xccc5ff9ca952893full, 0x75d6a964af190d95ull, 0x0f9890742e8ad0e5ull};
+
+static Aff aff_from_limbs(const uint64_t* l) {
+    Aff a;
+    if (!Fp::from_limbs(l, &a.x) || !Fp::from_limbs(l + 4, &a.y)) throw std::logic_error("generator constant");
+    return a;
+}
+
+// ---- fixed-base tables: derived once per process (Z search), cached on disk next to the library -------------------
+static std::string cache_dir() {
+    const char* env = getenv("BZH_CACHE_DIR");
+    if (env && *env) return env;
+    Dl_info info;
+    if (dladdr((void*)&cache_dir, &info) && info.dli_fname) {
+        std::string p = info.dli_fname;
+        const size_t s = p.rfind('/');
+        return (s == std::string::npos ? std::string(".") : p.substr(0, s)) + "/.bzh2_cache";
+    }
+    return ".bzh2_cache";
+}
+static bool load_zu(const std::string& path, const Aff& gen, FixedBase& fb) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    const int NW = ECC_NUM_WINDOWS;
+    std::vector<uint64_t> buf(8 + NW + (size_t)NW * ECC_H * 4);
+    const bool ok = fread(buf.data(), 8, buf.size(), f) == buf.size();
+    fclose(f);
+    if (!ok) return false;
+    uint64_t g[8];
+    gen.x.to_limbs(g);
+    gen.y.to_limbs(g + 4);
+    if (memcmp(g, buf.data(), 64) != 0) return false;
+    fb.z.assign(buf.begin() + 8, buf.begin() + 8 + NW);
+    fb.u.resize(NW);
+    for (int w = 0; w < NW; w++) {
+        for (int k = 0; k < ECC_H; k++) {
+            if (!Fp::from_limbs(&buf[8 + NW + ((size_t)w * ECC_H + k) * 4], &fb.u[w][k])) return false;
+            if (fb.u[w][k].sqr() != fb.points[w][k].y + Fp::from_u64(fb.z[w])) return false;   // u^2 = y + z
+        }
+    }
+    return true;
+}
+static void save_zu(const std::string& dir, const std::string& path, const Aff& gen, const FixedBase& fb) {
+    mkdir(dir.c_str(), 0755);
+    const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+    FILE* f = fopen(tmp.c_str(), "wb");
+    if (!f) return;
+    std::vector<uint64_t> buf(8);
+    gen.x.to_limbs(buf.data());
+    gen.y.to_limbs(buf.data() + 4);
+    buf.insert(buf.end(), fb.z.begin(), fb.z.end());
+    for (auto& row : fb.u) {
+        for (auto& v : row) {
+            uint64_t l[4];
+            v.to_limbs(l);
+            buf.insert(buf.end(), l, l + 4);
+        }
+    }
+    const bool ok = fwrite(buf.data(), 8, buf.size(), f) == buf.size();
+    fclose(f);
+    if (ok) {
+        rename(tmp.c_str(), path.c_str());
+    } else {
+        remove(tmp.c_str());
+    }
+}
+static FixedBase cached_fixed_base(const Aff& gen, const char* tag) {
+    const std::string dir = cache_dir(), path = dir + "/fixed_base_" + tag + "_v1.bin";
+    FixedBase fb;
+    fb.generator = gen;
+    fixed_base_window_points(gen, ECC_NUM_WINDOWS, fb.points);
+    if (load_zu(path, gen, fb)) {
+        std::vector<Fp> pts;
+        for (int k = 0; k < ECC_H; k++) pts.push_back(Fp::from_u64((uint64_t)k));
+        fb.lagrange.resize(ECC_NUM_WINDOWS);
+        for (int w = 0; w < ECC_NUM_WINDOWS; w++) {
+            std::vector<Fp> xs(ECC_H);
+            for (int k = 0; k < ECC_H; k++) xs[k] = fb.points[w][k].x;
+            const std::vector<Fp> co = lagrange_interpolate(pts, xs);
+            for (int k = 0; k < ECC_H; k++) fb.lagrange[w][k] = co[k];
+        }
+        return fb;
+    }
+    fb = make_fixed_base(gen);
+    save_zu(dir, path, gen, fb);
+    return fb;
+}
+static const BoardFixedBases& fixed_bases() {
+    static std::once_flag once;
+    static std::unique_ptr<BoardFixedBases> fb;
+    std::call_once(once, [] {
+        std::unique_ptr<BoardFixedBases> p(new BoardFixedBases());
+        p->v = cached_fixed_base(aff_from_limbs(GEN_V), "v");
+        p->r = cached_fixed_base(aff_from_limbs(GEN_R), "r");
+        fb = std::move(p);
+    });
+    return *fb;
+}
+
+// test circuits of the reference's bitify unit tests (src/chips/bitify.rs:255-403)
+struct BitifyTestConfig {
+    BitifyConfig bitify;
+    Column bits, lc1, e2, fixed;
+};
+static BitifyTestConfig bitify_test_configure(ConstraintSystem& meta, bool num2bits) {
+    BitifyTestConfig c;
+    c.bits = meta.advice_column();
+    c.lc1 = meta.advice_column();
+    c.e2 = meta.advice_column();
+    c.fixed = meta.fixed_column();
+    meta.enable_equality(c.bits);
+    meta.enable_equality(c.lc1);
+    meta.enable_equality(c.e2);
+    meta.enable_constant(c.fixed);
+    c.bitify = num2bits ? num2bits_configure(meta, c.bits, c.lc1, c.e2, c.fixed) : bits2num_configure(meta, c.bits, c.lc1, c.e2, c.fixed);
+    const Column trace = meta.advice_column();
+    meta.enable_equality(trace);
+    return c;
+}
+
+}  // namespace
+
+struct bzh_circuit {
+    int kind = 0;
+    unsigned k = 0;
+    unsigned bits = 0;  // bitify test circuits: B
+    ConstraintSystem cs;
+    ShotConfig shot;
+    BoardConfig board;
+    BitifyTestConfig bitify;
+    Assembly keygen;                   // fixed columns (selector columns appended), copies, regions
+    std::vector<size_t> region_starts;
+    size_t rows_used = 0;              // advice rows [0, rows_used) are the only ones synthesis writes
+    std::vector<uint8_t> blob;
+    std::string describe;
+    int num_instance_rows = 0;
+};
+
+namespace {
+
+struct AnyInput {
+    ShotInput shot;
+    BoardInput board;
+    Fp value;          // bitify tests
+    BinaryValue binary;
+};
+
+// one synthesis pass of the circuit's `synthesize` into `lay`; returns the public inputs (instance column 0)
+static std::vector<Fp> run_synthesize(const bzh_circuit& c, Layouter& lay, const AnyInput& in) {
+    std::vector<Fp> inst;
+    switch (c.kind) {
+        case BZH_CIRCUIT_SHOT: {
+            const Aff cm = shot_synthesize(c.shot, lay, fixed_bases(), in.shot);
+            inst = {cm.x, cm.y, Fp::from_u128(in.shot.shot.lower_u128()), Fp::from_u128(in.shot.hit.lower_u128())};
+            break;
+        }
+        case BZH_CIRCUIT_BOARD: {
+            const Aff cm = board_synthesize(c.board, lay, fixed_bases(), in.board);
+            inst = {cm.x, cm.y};
+            break;
+        }
+        case BZH_CIRCUIT_NUM2BITS_TEST: {
+            const AssignedCell value = lay.assign_region("trace", [&](Region& region) { return region.assign_advice(c.bitify.bits, 0, in.value); });
+            std::vector<Fp> bits(c.bits);
+            for (unsigned i = 0; i < c.bits; i++) bits[i] = in.binary.bit_fp((int)i);
+            num2bits_synthesize(c.bitify.bitify, lay, value, bits);
+            break;
+        }
+        case BZH_CIRCUIT_BITS2NUM_TEST: {
+            const std::vector<AssignedCell> assigned = lay.assign_region("trace", [&](Region& region) {
+                std::vector<AssignedCell> a;
+                for (unsigned i = 0; i < c.bits; i++) a.push_back(region.assign_advice(c.bitify.bits, i, in.binary.bit_fp((int)i)));
+                return a;
+            });
+            bits2num_synthesize(c.bitify.bitify, lay, assigned);
+            break;
+        }
+        default: throw std::logic_error("circuit kind");
+    }
+    return inst;
+}
+
+static AnyInput default_input(int kind) {
+    // pattern #1 board, shot (3, 5), hit (src/circuits/shot.rs:102-112, src/circuits/board.rs:101-107)
+    AnyInput in;
+    Board b;
+    b.deck.add(0, 3, 3, true);
+    b.deck.add(1, 5, 4, false);
+    b.deck.add(2, 0, 1, false);
+    b.deck.add(3, 0, 5, true);
+    b.deck.add(4, 6, 1, false);
+    const int opts[5] = {0, 0, 0, 0, 0};
+    in.shot.board = b.state(opts);
+    in.shot.trapdoor = Fq::from_u64(0x5eed);
+    const uint8_t sx = 3, sy = 5;
+    in.shot.shot = serialize_shot(&sx, &sy, 1);
+    in.shot.hit = BinaryValue::from_u8(1);
+    b.witness(opts, in.board.ship_commitments);
+    in.board.board = in.shot.board;
+    in.board.trapdoor = in.shot.trapdoor;
+    in.value = Fp::zero();
+    (void)kind;
+    return in;
+}
+
+static const char* kind_name(int t) { return t == ADVICE ? "advice" : (t == FIXED ? "fixed" : "instance"); }
+static std::string json_escape(const std::string& s) {
+    std::string o;
+    for (char ch : s) {
+        if (ch == '"' || ch == '\\') o.push_back('\\');
+        o.push_back(ch);
+    }
+    return o;
+}
+
+static void build_blob_and_describe(bzh_circuit& c) {
+    ConstraintSystem& cs = c.cs;
+    const size_t n = c.keygen.n;
+    BlobWriter w;
+    w.u32(0x32435A42u);  // "BZC2"
+    w.u32(c.k);
+    w.u32((uint32_t)cs.num_advice);
+    w.u32((uint32_t)cs.num_fixed);
+    w.u32((uint32_t)cs.num_instance);
+    w.u32((uint32_t)cs.degree());
+    uint8_t vk_repr[32] = {0x34, 0x12};  // opaque: upstream hashes the vk's Debug string
+    w.b.insert(w.b.end(), vk_repr, vk_repr + 32);
+    uint32_t npolys = 0;
+    for (auto& g : cs.gates) npolys += (uint32_t)g.polys.size();
+    w.u32(npolys);
+    for (auto& g : cs.gates) {
+        for (auto& p : g.polys) w.expr(p);
+    }
+    w.u32((uint32_t)cs.permutation.size());
+    for (auto& pc : cs.permutation) {
+        w.u8((uint8_t)pc.kind);
+        w.u32((uint32_t)pc.index);
+    }
+    w.u32((uint32_t)cs.lookups.size());
+    for (auto& lk : cs.lookups) {
+        w.u32((uint32_t)lk.inputs.size());
+        for (auto& e : lk.inputs) w.expr(e);
+        for (auto& e : lk.tables) w.expr(e);
+    }
+    auto perm_index = [&](const Column& col) -> uint32_t {
+        for (size_t i = 0; i < cs.permutation.size(); i++) {
+            if (cs.permutation[i] == col) return (uint32_t)i;
+        }
+        throw std::logic_error("copy constraint on a column without equality enabled");
+    };
+    w.u32((uint32_t)c.keygen.copies.size());
+    for (auto& cp : c.keygen.copies) {
+        w.u32(perm_index(cp.a));
+        w.u32((uint32_t)cp.row_a);
+        w.u32(perm_index(cp.b));
+        w.u32((uint32_t)cp.row_b);
+    }
+    for (int f = 0; f < cs.num_fixed; f++) {
+        const std::vector<Fp>& col = c.keygen.fixed[f];
+        size_t len = n;
+        while (len && col[len - 1].is_zero()) len--;
+        w.u32((uint32_t)len);
+        for (size_t r = 0; r < len; r++) w.fe(col[r]);
+    }
+    // explicit query lists, in upstream's registration order (enable_equality registers before any gate does)
+    for (const std::vector<Query>* qs : {&cs.advice_queries, &cs.fixed_queries, &cs.instance_queries}) {
+        w.u32((uint32_t)qs->size());
+        for (auto& q : *qs) {
+            w.u32((uint32_t)q.column);
+            w.u32((uint32_t)q.rotation);
+        }
+    }
+    c.blob.swap(w.b);
+
+    std::ostringstream o;
+    o << "{\"kind\":" << c.kind << ",\"k\":" << c.k << ",\"num_advice\":" << cs.num_advice << ",\"num_fixed\":" << cs.num_fixed
+      << ",\"num_instance\":" << cs.num_instance << ",\"num_selectors\":" << cs.num_selectors << ",\"degree\":" << cs.degree()
+      << ",\"blinding_factors\":" << cs.blinding_factors() << ",\"usable_rows\":" << c.keygen.usable_rows << ",\"rows_used\":" << c.rows_used
+      << ",\"num_polys\":" << npolys << ",\"num_copies\":" << c.keygen.copies.size() << ",\"gates\":[";
+    uint32_t first = 0;
+    for (size_t gi = 0; gi < cs.gates.size(); gi++) {
+        const Gate& g = cs.gates[gi];
+        o << (gi ? "," : "") << "{\"name\":\"" << json_escape(g.name) << "\",\"first_poly\":" << first << ",\"constraints\":[";
+        for (size_t i = 0; i < g.constraint_names.size(); i++) o << (i ? "," : "") << "\"" << json_escape(g.constraint_names[i]) << "\"";
+        o << "],\"queried_cells\":[";
+        for (size_t i = 0; i < g.queried_cells.size(); i++)
+            o << (i ? "," : "") << "[\"" << kind_name(g.queried_cells[i].kind) << "\"," << g.queried_cells[i].column << "," << g.queried_cells[i].rotation << "]";
+        o << "]}";
+        first += (uint32_t)g.polys.size();
+    }
+    o << "],\"regions\":[";
+    for (size_t ri = 0; ri < c.keygen.regions.size(); ri++) {
+        const RegionInfo& r = c.keygen.regions[ri];
+        o << (ri ? "," : "") << "{\"name\":\"" << json_escape(r.name) << "\",\"has_rows\":" << (r.has_rows ? "true" : "false") << ",\"row_lo\":" << r.row_lo
+          << ",\"row_hi\":" << r.row_hi << ",\"columns\":[";
+        size_t i = 0;
+        for (auto& col : r.columns) o << (i++ ? "," : "") << "[\"" << kind_name(col.kind) << "\"," << col.index << "]";
+        o << "]}";
+    }
+    o << "],\"permutation\":[";
+    for (size_t i = 0; i < cs.permutation.size(); i++) o << (i ? "," : "") << "[\"" << kind_name(cs.permutation[i].kind) << "\"," << cs.permutation[i].index << "]";
+    o << "]";
+    const char* qn[3] = {"advice_queries", "fixed_queries", "instance_queries"};
+    const std::vector<Query>* qv[3] = {&cs.advice_queries, &cs.fixed_queries, &cs.instance_queries};
+    for (int t = 0; t < 3; t++) {
+        o << ",\"" << qn[t] << "\":[";
+        for (size_t i = 0; i < qv[t]->size(); i++) o << (i ? "," : "") << "[" << (*qv[t])[i].column << "," << (*qv[t])[i].rotation << "]";
+        o << "]";
+    }
+    o << "}";
+    c.describe = o.str();
+}
+
+static int circuit_create(int kind, unsigned k, unsigned bits, bzh_circuit** out) {
+    std::unique_ptr<bzh_circuit> cp(new bzh_circuit());
+    bzh_circuit& c = *cp;
+    c.kind = kind;
+    c.k = k;
+    c.bits = bits;
+    switch (kind) {
+        case BZH_CIRCUIT_SHOT: c.shot = shot_configure(c.cs); c.num_instance_rows = 4; break;
+        case BZH_CIRCUIT_BOARD: c.board = board_configure(c.cs); c.num_instance_rows = 2; break;
+        case BZH_CIRCUIT_NUM2BITS_TEST: c.bitify = bitify_test_configure(c.cs, true); break;
+        case BZH_CIRCUIT_BITS2NUM_TEST: c.bitify = bitify_test_configure(c.cs, false); break;
+        default: return BZH_E_ARG;
+    }
+    if (((size_t)1 << k) < (size_t)c.cs.minimum_rows()) return BZH_E_RANGE;
+    c.keygen.init(c.cs, k, true, false);
+    Layouter lay(c.keygen, c.cs.constants);
+    AnyInput in = default_input(kind);
+    run_synthesize(c, lay, in);
+    c.region_starts = lay.regions;
+    for (auto& kv : lay.columns) {
+        if (kv.first.kind == ADVICE) c.rows_used = std::max(c.rows_used, kv.second);
+    }
+    const std::vector<std::vector<Fp>> sel_polys = c.cs.compress_selectors(c.keygen.selectors);
+    for (auto& p : sel_polys) c.keygen.fixed.push_back(p);
+    build_blob_and_describe(c);
+    *out = cp.release();
+    return BZH_OK;
+}
+
+// rows [0, stride) of every (proof, column) come from the compact staged block, the rest of the n rows are zero
+__global__ void __launch_bounds__(256) k_expand_advice(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t n, size_t stride) {
+    const size_t i = blockIdx.x * (size_t)256 + threadIdx.x, pc = blockIdx.y;   // i indexes 16-byte halves of the n elements
+    if (i >= 2 * n) return;
+    dst[pc * 2 * n + i] = (i < 2 * stride) ? src[pc * 2 * stride + i] : make_uint4(0, 0, 0, 0);
+}
+
+struct BatchInputs {
+    const uint64_t* a = nullptr;  // shot: boards            | board: ship commitments (10 x 4) | bitify: value (canonical)
+    const uint64_t* b = nullptr;  // shot: trapdoors         | board: boards                    | bitify: binary
+    const uint64_t* c = nullptr;  // shot: shots             | board: trapdoors
+    const uint64_t* d = nullptr;  // shot: hits
+};
+static void input_at(const bzh_circuit& c, const BatchInputs& bi, size_t i, AnyInput& in) {
+    auto fq = [](const uint64_t* l) {
+        Fq v;
+        if (!Fq::from_limbs(l, &v)) throw GameError("trapdoor is not a canonical scalar");
+        return v;
+    };
+    switch (c.kind) {
+        case BZH_CIRCUIT_SHOT:
+            in.shot.board = BinaryValue::from_limbs(bi.a + 4 * i);
+            in.shot.trapdoor = fq(bi.b + 4 * i);
+            in.shot.shot = BinaryValue::from_limbs(bi.c + 4 * i);
+            in.shot.hit = BinaryValue::from_limbs(bi.d + 4 * i);
+            break;
+        case BZH_CIRCUIT_BOARD:
+            for (int j = 0; j < 10; j++) in.board.ship_commitments[j] = BinaryValue::from_limbs(bi.a + 4 * (10 * i + j));
+            in.board.board = BinaryValue::from_limbs(bi.b + 4 * i);
+            in.board.trapdoor = fq(bi.c + 4 * i);
+            break;
+        default:
+            if (!Fp::from_limbs(bi.a + 4 * i, &in.value)) throw GameError("value is not canonical");
+            in.binary = BinaryValue::from_limbs(bi.b + 4 * i);
+    }
+}
+
+// synthesise `batch` witnesses into compact blocks [proof][num_advice][stride] of Montgomery limbs
+static int synthesize_compact(const bzh_circuit& c, size_t batch, const BatchInputs& bi, Fp* compact, size_t stride, uint64_t* instances,
+                              unsigned threads, std::string* err) {
+    const size_t na = (size_t)c.cs.num_advice;
+    std::atomic<size_t> next{0};
+    std::atomic<int> status{BZH_OK};
+    std::mutex emu;
+    auto worker = [&] {
+        Assembly as;
+        for (size_t i; (i = next.fetch_add(1)) < batch;) {
+            if (status.load() != BZH_OK) return;
+            try {
+                Fp* out = compact + i * na * stride;
+                std::fill(out, out + na * stride, Fp::zero());
+                as.init(c.cs, c.k, false, true, out, stride);
+                as.usable_rows = c.keygen.usable_rows;
+                Layouter lay(as, c.cs.constants);
+                lay.known_starts = &c.region_starts;
+                AnyInput in;
+                input_at(c, bi, i, in);
+                const std::vector<Fp> inst = run_synthesize(c, lay, in);
+                if (instances) {
+                    for (size_t r = 0; r < inst.size(); r++) inst[r].to_limbs(instances + (i * inst.size() + r) * 4);
+                }
+            } catch (const std::exception& e) {
+                std::lock_guard<std::mutex> g(emu);
+                if (err) *err = e.what();
+                status.store(BZH_E_RANGE);
+                return;
+            }
+        }
+    };
+    if (!threads) threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    threads = (unsigned)std::min<size_t>(threads, batch);
+    if (threads <= 1) {
+        worker();
+    } else {
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < threads; t++) pool.emplace_back(worker);
+        for (auto& t : pool) t.join();
+    }
+    return status.load();
+}
+
+static thread_local std::string g_circuit_error;
+
+}  // namespace
+
+extern "C" {
+
+int bzh_circuit_create(int kind, unsigned k, unsigned bits, bzh_circuit** out) {
+    if (!out || k < 4 || k > 24) return BZH_E_ARG;
+    if ((kind == BZH_CIRCUIT_NUM2BITS_TEST || kind == BZH_CIRCUIT_BITS2NUM_TEST) && (bits < 1 || bits > 256)) return BZH_E_ARG;
+    try {
+        return circuit_create(kind, k, bits, out);
+    } catch (const SynthesisError& e) {
+        g_circuit_error = e.what();
+        return BZH_E_RANGE;   // not enough rows for this k
+    } catch (const std::exception& e) {
+        g_circuit_error = e.what();
+        return BZH_E_ARG;
+    }
+}
+int bzh_circuit_free(bzh_circuit* c) {
+    delete c;
+    return BZH_OK;
+}
+const char* bzh_circuit_last_error(void) { return g_circuit_error.c_str(); }
+int bzh_circuit_blob(const bzh_circuit* c, uint8_t* out, size_t cap, size_t* len) {
+    if (!c || !len) return BZH_E_ARG;
+    *len = c->blob.size();
+    if (!out) return BZH_OK;
+    if (cap < c->blob.size()) return BZH_E_RANGE;
+    memcpy(out, c->blob.data(), c->blob.size());
+    return BZH_OK;
+}
+int bzh_circuit_describe(const bzh_circuit* c, char* out, size_t cap, size_t* len) {
+    if (!c || !len) return BZH_E_ARG;
+    *len = c->describe.size() + 1;
+    if (!out) return BZH_OK;
+    if (cap < *len) return BZH_E_RANGE;
+    memcpy(out, c->describe.c_str(), *len);
+    return BZH_OK;
+}
+int bzh_circuit_info(const bzh_circuit* c, uint32_t* num_advice, uint32_t* num_instance_rows, uint32_t* n_rows, uint32_t* rows_used,
+                     uint32_t* num_gates, uint32_t* num_regions) {
+    if (!c) return BZH_E_ARG;
+    if (num_advice) *num_advice = (uint32_t)c->cs.num_advice;
+    if (num_instance_rows) *num_instance_rows = (uint32_t)c->num_instance_rows;
+    if (n_rows) *n_rows = (uint32_t)c->keygen.n;
+    if (rows_used) *rows_used = (uint32_t)c->rows_used;
+    if (num_gates) *num_gates = (uint32_t)c->cs.gates.size();
+    if (num_regions) *num_regions = (uint32_t)c->keygen.regions.size();
+    return BZH_OK;
+}
+
+static int synthesize_any(bzh_ctx* ctx, const bzh_circuit* c, size_t batch, const BatchInputs& bi, uint64_t* advice, int form, int mem,
+                          uint64_t* instances, unsigned threads) {
+    if (!c || !batch || batch > 65536 || !advice) return BZH_E_ARG;
+    if ((form != BZH_FORM_CANONICAL && form != BZH_FORM_MONTGOMERY) || (mem != BZH_MEM_HOST && mem != BZH_MEM_DEVICE)) return BZH_E_ARG;
+    if (mem == BZH_MEM_DEVICE && (!ctx || form != BZH_FORM_MONTGOMERY)) return BZH_E_ARG;
+    const size_t na = (size_t)c->cs.num_advice, n = c->keygen.n, stride = std::max<size_t>(c->rows_used, 1);
+    std::string err;
+    if (mem == BZH_MEM_HOST) {
+        std::vector<Fp> compact(batch * na * stride);
+        const int rc = synthesize_compact(*c, batch, bi, compact.data(), stride, instances, threads, &err);
+        if (rc) {
+            g_circuit_error = err;
+            if (ctx) ctx->last_error = err;
+            return rc;
+        }
+        memset(advice, 0, batch * na * n * 32);
+        for (size_t pc = 0; pc < batch * na; pc++) {
+            for (size_t r = 0; r < stride; r++) {
+                uint64_t* dst = advice + (pc * n + r) * 4;
+                if (form == BZH_FORM_MONTGOMERY) {
+                    memcpy(dst, compact[pc * stride + r].l, 32);
+                } else {
+                    compact[pc * stride + r].to_limbs(dst);
+                }
+            }
+        }
+        return BZH_OK;
+    }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    BZH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    char* slot = nullptr;
+    const size_t bytes = batch * na * stride * 32;
+    int rc = bzh::h2d_stage(ctx, bytes, &slot);
+    if (rc) return rc;
+    rc = synthesize_compact(*c, batch, bi, (Fp*)slot, stride, instances, threads, &err);
+    if (rc) {
+        g_circuit_error = err;
+        ctx->last_error = err;
+        return rc;
+    }
+    dim3 grid((unsigned)((2 * n + 255) / 256), (unsigned)(batch * na));
+    hipLaunchKernelGGL(k_expand_advice, grid, dim3(256), 0, ctx->stream, (uint4*)advice, (const uint4*)slot, n, stride);
+    BZH_HIP_TRY(ctx, hipGetLastError());
+    return BZH_OK;
+}
+
+int bzh_synthesize_shot(bzh_ctx* ctx, const bzh_circuit* c, size_t batch, const uint64_t* boards, const uint64_t* trapdoors, const uint64_t* shots,
+                        const uint64_t* hits, uint64_t* advice, int form, int mem, uint64_t* instances, unsigned threads) {
+    if (!c || c->kind != BZH_CIRCUIT_SHOT || !boards || !trapdoors || !shots || !hits) return BZH_E_ARG;
+    BatchInputs bi;
+    bi.a = boards, bi.b = trapdoors, bi.c = shots, bi.d = hits;
+    return synthesize_any(ctx, c, batch, bi, advice, form, mem, instances, threads);
+}
+int bzh_synthesize_board(bzh_ctx* ctx, const bzh_circuit* c, size_t batch, const uint64_t* ship_commitments, const uint64_t* boards,
+                         const uint64_t* trapdoors, uint64_t* advice, int form, int mem, uint64_t* instances, unsigned threads) {
+    if (!c || c->kind != BZH_CIRCUIT_BOARD || !ship_commitments || !boards || !trapdoors) return BZH_E_ARG;
+    BatchInputs bi;
+    bi.a = ship_commitments, bi.b = boards, bi.c = trapdoors;
+    return synthesize_any(ctx, c, batch, bi, advice, form, mem, instances, threads);
+}
+int bzh_synthesize_bitify_test(const bzh_circuit* c, const uint64_t* value, const uint64_t* binary, uint64_t* advice) {
+    if (!c || (c->kind != BZH_CIRCUIT_NUM2BITS_TEST && c->kind != BZH_CIRCUIT_BITS2NUM_TEST) || !value || !binary) return BZH_E_ARG;
+    BatchInputs bi;
+    bi.a = value, bi.b = binary;
+    return synthesize_any(nullptr, c, 1, bi, advice, BZH_FORM_CANONICAL, BZH_MEM_HOST, nullptr, 1);
+}
+
+/* game / witness marshalling (src/utils/{ship,deck,board,shot}.rs) */
+int bzh_board_witness(const int8_t* ships, const int32_t* options, uint64_t* ship_commitments, uint64_t* state) {
+    if (!ships || !ship_commitments || !state) return BZH_E_ARG;
+    try {
+        Board b;
+        int opts[5] = {0, 0, 0, 0, 0};
+        for (int i = 0; i < 5; i++) {
+            const int8_t *s = ships + 3 * i;
+            if (s[0] >= 0) b.deck.add(i, s[0], s[1], s[2] != 0);
+            if (options) opts[i] = options[i];
+        }
+        BinaryValue w[10];
+        b.witness(opts, w);
+        for (int i = 0; i < 10; i++) memcpy(ship_commitments + 4 * i, w[i].w, 32);
+        const BinaryValue st = b.state(opts);
+        memcpy(state, st.w, 32);
+        return BZH_OK;
+    } catch (const std::exception& e) {
+        g_circuit_error = e.what();
+        return BZH_E_RANGE;
+    }
+}
+int bzh_shot_serialize(const uint8_t* xs, const uint8_t* ys, size_t count, uint64_t* out) {
+    if (!xs || !ys || !out) return BZH_E_ARG;
+    try {
+        const BinaryValue b = serialize_shot(xs, ys, (int)count);
+        memcpy(out, b.w, 32);
+        return BZH_OK;
+    } catch (const std::exception& e) {
+        g_circuit_error = e.what();
+        return BZH_E_RANGE;
+    }
+}
+/* native Pedersen commitment on the host from the circuit's own window tables (src/utils/pedersen.rs:17-28) */
+int bzh_pedersen_commit_host(const uint64_t* message, const uint64_t* trapdoor, uint64_t* out_xy) {
+    if (!message || !trapdoor || !out_xy) return BZH_E_ARG;
+    try {
+        Fp m;
+        Fq t;
+        if (!Fp::from_limbs(message, &m) || !Fq::from_limbs(trapdoor, &t)) return BZH_E_RANGE;
+        const Aff a = pedersen_commit_native(fixed_bases(), m, t);
+        a.x.to_limbs(out_xy);
+        a.y.to_limbs(out_xy + 4);
+        return BZH_OK;
+    } catch (const std::exception& e) {
+        g_circuit_error = e.what();
+        return BZH_E_RANGE;
+    }
+}
+/* fixed-base tables of the in-circuit Pedersen commitment: base 0 = V, 1 = R; z: 85 u64, u: 85 x 8 x 4 canonical limbs,
+ * lagrange: 85 x 8 x 4 canonical limbs (src/utils/constants/fixed_bases/board_commit_{v,r}.rs:17-2927) */
+int bzh_fixed_base_tables(int base, uint64_t* z, uint64_t* u, uint64_t* lagrange) {
+    if (base < 0 || base > 1) return BZH_E_ARG;
+    try {
+        const FixedBase& fb = base == 0 ? fixed_bases().v : fixed_bases().r;
+        for (int w = 0; w < ECC_NUM_WINDOWS; w++) {
+            if (z) z[w] = fb.z[w];
+            for (int k = 0; k < ECC_H; k++) {
+                if (u) fb.u[w][k].to_limbs(u + ((size_t)w * ECC_H + k) * 4);
+                if (lagrange) fb.lagrange[w][k].to_limbs(lagrange + ((size_t)w * ECC_H + k) * 4);
+            }
+        }
+        return BZH_OK;
+    } catch (const std::exception& e) {
+        g_circuit_error = e.what();
+        return BZH_E_HIP;
+    }
+}
+
+}  // extern "C"

@@ -15,12 +15,14 @@
 // one grow-only arena owned by the proving key.
 //
 // Circuit blob, little-endian:
-//   u32 magic "BZC1" | u32 k | u32 num_advice | u32 num_fixed | u32 num_instance | u32 min_degree | u8[32] vk_repr
-//   u32 ngates, ngates x expr
+//   u32 magic "BZC1" or "BZC2" | u32 k | u32 num_advice | u32 num_fixed | u32 num_instance | u32 min_degree | u8[32] vk_repr
+//   u32 ngates, ngates x expr                                                   (every constraint polynomial of every gate, flattened)
 //   u32 nperm, nperm x (u8 kind {0 advice, 1 fixed, 2 instance}, u32 index)
 //   u32 nlookups, per lookup: u32 m, m x expr (inputs), m x expr (table)
 //   u32 ncopies, ncopies x (u32 col_a, u32 row_a, u32 col_b, u32 row_b)        (indices into the permutation columns)
 //   num_fixed x (u32 len, len x u8[32] canonical values)                        (rows past len are zero)
+//   "BZC2" only: advice, fixed, instance query lists, each u32 count, count x (u32 column, i32 rotation), in upstream's
+//   query REGISTRATION order (= the order of the evaluations in the proof); written by csrc/circuits.hip
 //   expr := u8 tag, then  0 const: u8[32] | 1 advice / 2 fixed / 3 instance: u32 column, i32 rotation
 //                       | 4 neg: expr | 5 add: expr expr | 6 mul: expr expr | 7 scale: expr, u8[32]
 #include <algorithm>
@@ -584,7 +586,9 @@ static int pk_create_t(bzh_ctx* ctx, const bzh_bases* srs, const uint8_t* blob, 
     std::unique_ptr<bzh_pk> pkp(new bzh_pk());
     bzh_pk& pk = *pkp;
     Reader r{blob, blob + len};
-    if (r.u32() != 0x31435A42u) return BZH_E_ARG;  // "BZC1"
+    const uint32_t magic = r.u32();
+    if (magic != 0x31435A42u && magic != 0x32435A42u) return BZH_E_ARG;  // "BZC1" / "BZC2"
+    const bool explicit_queries = magic == 0x32435A42u;
     pk.curve = C::id;
     pk.field = FM::id;
     pk.device = ctx->device;
@@ -639,16 +643,39 @@ static int pk_create_t(bzh_ctx* ctx, const bzh_bases* srs, const uint8_t* blob, 
     }
     if (!r.ok) return BZH_E_ARG;
 
-    // derived shape: queries in first-use order, degree, blinding factors (upstream ConstraintSystem)
-    std::vector<Query3> qs;
-    for (int g : pk.gates) cx_queries(pk, g, qs);
+    // shape: queries, degree, blinding factors (upstream ConstraintSystem).  "BZC2" carries the query lists in
+    // upstream's registration order (a query is registered when it is made: `enable_equality` registers the column's
+    // current-row query at once, before any gate of the reference's configure functions -- src/chips/board.rs:199,217
+    // before :275); "BZC1" derives them in first-use order: gates, lookups, then the permutation columns.
+    std::vector<Query3> used, qs;
+    for (int g : pk.gates) cx_queries(pk, g, used);
     for (auto& lk : pk.lookups) {
-        for (int e : lk.first) cx_queries(pk, e, qs);
-        for (int e : lk.second) cx_queries(pk, e, qs);
+        for (int e : lk.first) cx_queries(pk, e, used);
+        for (int e : lk.second) cx_queries(pk, e, used);
     }
     for (auto& pc : pk.perm_columns) {
         const Query3 q{pc.first, pc.second, 0};
-        if (std::find(qs.begin(), qs.end(), q) == qs.end()) qs.push_back(q);
+        if (std::find(used.begin(), used.end(), q) == used.end()) used.push_back(q);
+    }
+    if (explicit_queries) {
+        const int tags[3] = {CX_ADVICE, CX_FIXED, CX_INSTANCE};
+        const int limits[3] = {pk.na, pk.nf, pk.ni};
+        for (int t = 0; t < 3; t++) {
+            const uint32_t nq = r.u32();
+            if (!r.ok || nq > 65536) return BZH_E_ARG;
+            for (uint32_t i = 0; i < nq && r.ok; i++) {
+                const Query3 q{tags[t], (int)r.u32(), (int)r.u32()};
+                if (q.col < 0 || q.col >= limits[t] || q.rot < -(int)n || q.rot > (int)n) return BZH_E_ARG;
+                if (std::find(qs.begin(), qs.end(), q) != qs.end()) return BZH_E_ARG;
+                qs.push_back(q);
+            }
+        }
+        if (!r.ok) return BZH_E_ARG;
+        for (auto& q : used) {   // every cell the constraint system reads must be in the lists
+            if (std::find(qs.begin(), qs.end(), q) == qs.end()) return BZH_E_ARG;
+        }
+    } else {
+        qs = used;
     }
     std::map<int, int> per_col;
     for (auto& q : qs) {

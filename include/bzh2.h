@@ -278,6 +278,64 @@ int bzh_prove_batch(bzh_ctx* ctx, bzh_pk* pk, size_t batch, const uint64_t* advi
                     size_t instance_rows, const uint8_t* rng, size_t rng_stride, uint8_t* proofs, size_t proof_stride,
                     size_t* proof_lens);
 
+/* ---- circuits: the reference's ShotCircuit / BoardCircuit as data + their witness synthesis -------------------------
+ * The reference-side interface this replaces is `impl Circuit<pallas::Base> for {ShotCircuit, BoardCircuit}`
+ * (src/circuits/shot.rs:22-53, src/circuits/board.rs:21-51): `configure` -> ShotChip::configure / BoardChip::configure
+ * (src/chips/shot.rs:179-297, src/chips/board.rs:194-321) and `synthesize` -> ShotChip::synthesize / BoardChip::synthesize
+ * (src/chips/shot.rs:308-354, src/chips/board.rs:331-363), with every chip under them (src/chips/{bitify,placement,
+ * transpose,pedersen}.rs and halo2_gadgets' EccChip), laid out by SimpleFloorPlanner.  Host C++, no device needed
+ * except for BZH_MEM_DEVICE output.
+ *   bzh_circuit_create   configure + the keygen synthesis at 2^k rows (Shot: k >= 11, Board: k >= 12 -- the reference's
+ *                        sizes, benches/shot.rs:22, benches/board.rs:22; BZH_E_RANGE if the circuit does not fit) +
+ *                        selector compression.  `bits`: B of the two bitify test circuits (src/chips/bitify.rs:255-403),
+ *                        ignored otherwise.
+ *   bzh_circuit_blob     the serialised constraint system + fixed assignment for bzh_pk_create ("BZC2", csrc/prove.hip);
+ *                        out = NULL only reports the length.
+ *   bzh_circuit_describe JSON: column counts, gates (names, constraint names, queried cells), regions (name, rows,
+ *                        columns), permutation columns, query lists -- what dev::MockProver reports failures against.
+ *   bzh_synthesize_shot / bzh_synthesize_board
+ *                        `batch` witnesses: fills advice = batch x num_advice x 2^k elements (`form`; BZH_MEM_HOST, or
+ *                        BZH_MEM_DEVICE + BZH_FORM_MONTGOMERY: staged compactly through pinned memory and expanded on the
+ *                        ctx's stream) -- exactly the tensor bzh_prove_batch consumes -- and instances = batch x
+ *                        {4, 2} canonical public inputs (Shot: commitment x, y, shot, hit: src/circuits/shot.rs:125-130;
+ *                        Board: commitment x, y: src/circuits/board.rs:113-118).  Inputs are the constructor arguments of
+ *                        ShotCircuit::new / BoardCircuit::new: 256-bit BinaryValues as 4 limbs, trapdoors as canonical
+ *                        Pallas scalars.  `threads` host threads (0 = auto).  BZH_E_RANGE: an input the reference would
+ *                        panic on (H and V share a bit: src/utils/binary.rs:97-108; non-canonical trapdoor).
+ *   bzh_board_witness    Board::from(&Deck::from(ships)).{witness, state}(options): ships = 5 x (x, y, z), x < 0 = None;
+ *                        options = 5 WitnessOption values (src/utils/ship.rs:315-331) or NULL;
+ *                        out: 10 ship commitments [H5, V5, H4, V4, H3a, V3a, H3b, V3b, H2, V2] and the board state.
+ *   bzh_shot_serialize   shot::serialize (src/utils/shot.rs:12-19).
+ *   bzh_pedersen_commit_host   pedersen_commit (src/utils/pedersen.rs:17-28) on the host, from the circuit's window tables.
+ *   bzh_fixed_base_tables      Z / U / Lagrange tables of BoardCommitV (0) and BoardCommitR (1), derived from the generators
+ *                        (src/utils/constants/fixed_bases/board_commit_{v,r}.rs). */
+typedef struct bzh_circuit bzh_circuit;
+typedef enum { BZH_CIRCUIT_SHOT = 0, BZH_CIRCUIT_BOARD = 1, BZH_CIRCUIT_NUM2BITS_TEST = 2, BZH_CIRCUIT_BITS2NUM_TEST = 3 } bzh_circuit_kind;
+typedef enum {
+    BZH_WITNESS_DEFAULT = 0,
+    BZH_WITNESS_DUAL_PLACEMENT = 1,
+    BZH_WITNESS_NONCONSECUTIVE = 2,
+    BZH_WITNESS_EXTRA_BIT = 3,
+    BZH_WITNESS_OVERSIZED = 4,
+    BZH_WITNESS_UNDERSIZED = 5
+} bzh_witness_option;
+int bzh_circuit_create(int kind, unsigned k, unsigned bits, bzh_circuit** out);
+int bzh_circuit_free(bzh_circuit* c);
+const char* bzh_circuit_last_error(void);
+int bzh_circuit_blob(const bzh_circuit* c, uint8_t* out, size_t cap, size_t* len);
+int bzh_circuit_describe(const bzh_circuit* c, char* out, size_t cap, size_t* len);
+int bzh_circuit_info(const bzh_circuit* c, uint32_t* num_advice, uint32_t* num_instance_rows, uint32_t* n_rows, uint32_t* rows_used,
+                     uint32_t* num_gates, uint32_t* num_regions);
+int bzh_synthesize_shot(bzh_ctx* ctx, const bzh_circuit* c, size_t batch, const uint64_t* boards, const uint64_t* trapdoors, const uint64_t* shots,
+                        const uint64_t* hits, uint64_t* advice, int form, int mem, uint64_t* instances, unsigned threads);
+int bzh_synthesize_board(bzh_ctx* ctx, const bzh_circuit* c, size_t batch, const uint64_t* ship_commitments, const uint64_t* boards,
+                         const uint64_t* trapdoors, uint64_t* advice, int form, int mem, uint64_t* instances, unsigned threads);
+int bzh_synthesize_bitify_test(const bzh_circuit* c, const uint64_t* value, const uint64_t* binary, uint64_t* advice);
+int bzh_board_witness(const int8_t* ships, const int32_t* options, uint64_t* ship_commitments, uint64_t* state);
+int bzh_shot_serialize(const uint8_t* xs, const uint8_t* ys, size_t count, uint64_t* out);
+int bzh_pedersen_commit_host(const uint64_t* message, const uint64_t* trapdoor, uint64_t* out_xy);
+int bzh_fixed_base_tables(int base, uint64_t* z, uint64_t* u, uint64_t* lagrange);
+
 /* ---- host helpers (CPU, no device needed): what `.to_affine()` / `to_bytes()`
  * do on the Rust side; used by tests and benches to compare canonical bytes. */
 int bzh_jacobian_to_affine(int curve, const uint64_t* xyz, size_t n, int form, uint64_t* out_xy);

@@ -63,7 +63,11 @@ def expr_eval(e, leaf, p):
 
 
 class ConstraintSystem:
-    def __init__(self, k, num_advice, num_fixed, num_instance, gates, perm_columns, lookups=(), degree=None):
+    def __init__(self, k, num_advice, num_fixed, num_instance, gates, perm_columns, lookups=(), degree=None, queries=None):
+        """queries: optional (advice, fixed, instance) lists of (column, rotation) in upstream's REGISTRATION order --
+        a query is registered when it is made (`enable_equality` registers the column's current-row query before any
+        gate of the reference's configure functions does: src/chips/board.rs:199,217 before :275).  Without it the
+        order is derived: gates, lookups, then the permutation columns."""
         self.k, self.n = k, 1 << k
         self.num_advice, self.num_fixed, self.num_instance = num_advice, num_fixed, num_instance
         self.gates = list(gates)
@@ -79,6 +83,11 @@ class ConstraintSystem:
             q = (c[0], c[1], 0)
             if q not in qs:
                 qs.append(q)
+        if queries is not None:
+            listed = [('advice', c, r) for c, r in queries[0]] + [('fixed', c, r) for c, r in queries[1]] + \
+                     [('instance', c, r) for c, r in queries[2]]
+            assert all(q in listed for q in qs), "a queried cell is missing from the explicit query lists"
+            qs = listed
         self.advice_queries = [(c, r) for t, c, r in qs if t == 'advice']
         self.fixed_queries = [(c, r) for t, c, r in qs if t == 'fixed']
         self.instance_queries = [(c, r) for t, c, r in qs if t == 'instance']
