@@ -41,7 +41,7 @@ EXPORTS = [
     "bzh_version", "bzh_strerror", "bzh_device_count", "bzh_ctx_create", "bzh_ctx_create_on_stream",
     "bzh_ctx_destroy", "bzh_ctx_sync", "bzh_last_error", "bzh_ctx_profile", "bzh_ctx_timings", "bzh_ctx_work",
     "bzh_bases_upload", "bzh_bases_precompute", "bzh_bases_free", "bzh_bases_len", "bzh_msm", "bzh_ntt",
-    "bzh_jacobian_to_affine", "bzh_affine_compress", "bzh_field_omega",
+    "bzh_jacobian_to_affine", "bzh_jacobian_sum", "bzh_affine_compress", "bzh_field_omega",
 ]
 
 
@@ -250,6 +250,18 @@ def jacobian_to_affine(curve: int, xyz: np.ndarray, form: int = FORM_CANONICAL) 
     rc = load().bzh_jacobian_to_affine(curve, _u64(a), a.shape[0], form, _u64(out))
     if rc != OK:
         raise BzhError(rc, "bzh_jacobian_to_affine")
+    return out
+
+
+def jacobian_sum(curve: int, xyz: np.ndarray, form: int = FORM_CANONICAL) -> np.ndarray:
+    """Sum of Jacobian points on the host (the combine step of an MSM split over several GPUs)."""
+    a = np.ascontiguousarray(xyz, dtype=np.uint64).reshape(-1, 12)
+    out = np.zeros(12, dtype=np.uint64)
+    L = load()
+    L.bzh_jacobian_sum.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_uint64), ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]
+    rc = L.bzh_jacobian_sum(curve, _u64(a), a.shape[0], form, _u64(out))
+    if rc != OK:
+        raise BzhError(rc, "bzh_jacobian_sum")
     return out
 
 

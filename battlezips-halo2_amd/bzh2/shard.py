@@ -33,3 +33,16 @@ def gather_records(local: torch.Tensor, counts, dist=None) -> torch.Tensor:
     out = [torch.empty_like(padded) for _ in range(world)]
     dist.all_gather(out, padded)
     return torch.cat([out[r][: counts[r]] for r in range(world)], dim=0)
+
+
+def combine_msm_partials(curve: int, local_jacobian, dist=None, form: int = 0):
+    """One MSM whose points are split over the ranks (BASELINE.json configs[4], "8 GPUs"): every rank
+    has computed sum_{i in shard_range(N, rank, world)} s_i G_i as one Jacobian point (12 limbs = 96 bytes).  The partials are
+    all-gathered (world x 96 B -- there is no elliptic-curve reduction op to all_reduce with) and added locally by every rank.
+    `local_jacobian`: (12,) uint64-as-int64 tensor or array in `form`.  Returns the (12,) uint64 numpy sum."""
+    import numpy as np
+    from . import jacobian_sum
+    t = local_jacobian if isinstance(local_jacobian, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(local_jacobian).view(np.int64))
+    t = t.reshape(1, 12)
+    parts = gather_records(t, [1] * (dist.get_world_size() if dist is not None and dist.is_initialized() else 1), dist)
+    return jacobian_sum(curve, parts.cpu().numpy().view(np.uint64), form)

@@ -110,6 +110,27 @@ static void compress_host(const uint64_t* xy, size_t n, int form, uint8_t* out) 
     }
 }
 
+// sum of n Jacobian points on the host: the combine step of an MSM whose points are split over several GPUs
+// (each rank's partial result is one 96-byte point; SURVEY.md section 8e "8-GPU single MSM")
+template <class P>
+static void jac_sum_host(const uint64_t* xyz, size_t n, int form, uint64_t* out) {
+    std::vector<uint64_t> aff(8 * (n ? n : 1));
+    jac_to_aff_host<P>(xyz, n, form, aff.data());
+    Xyzz<P> acc = xyzz_identity<P>();
+    for (size_t i = 0; i < n; i++) {
+        Affine<P> a;
+        a.x = load_host<P>(aff.data() + 8 * i, form);
+        a.y = load_host<P>(aff.data() + 8 * i + 4, form);
+        if (aff_is_id(a)) continue;
+        xyzz_madd(acc, a);
+    }
+    Fe<P> X, Y, Z;
+    xyzz_to_jacobian(acc, X, Y, Z);
+    store_host<P>(out, X, form);
+    store_host<P>(out + 4, Y, form);
+    store_host<P>(out + 8, Z, form);
+}
+
 template <class P>
 static void omega_host(unsigned S, uint32_t gen, unsigned log_n, int form, uint64_t* out) {
     // ROOT_OF_UNITY = gen^((p-1) >> S); omega = ROOT^(2^(S - log_n))
@@ -767,6 +788,17 @@ int bzh_jacobian_to_affine(int curve, const uint64_t* xyz, size_t n, int form, u
         case BZH_CURVE_VESTA: jac_to_aff_host<FqParams>(xyz, n, form, out_xy); break;
         case BZH_CURVE_PALLAS: jac_to_aff_host<FpParams>(xyz, n, form, out_xy); break;
         case BZH_CURVE_BN254: jac_to_aff_host<BnFqParams>(xyz, n, form, out_xy); break;
+    }
+    return BZH_OK;
+}
+
+int bzh_jacobian_sum(int curve, const uint64_t* xyz, size_t n, int form, uint64_t* out_xyz) {
+    if (!out_xyz || (!xyz && n)) return BZH_E_ARG;
+    if (!valid_curve(curve) || !valid_form(form)) return BZH_E_ARG;
+    switch (curve) {
+        case BZH_CURVE_VESTA: jac_sum_host<FqParams>(xyz, n, form, out_xyz); break;
+        case BZH_CURVE_PALLAS: jac_sum_host<FpParams>(xyz, n, form, out_xyz); break;
+        case BZH_CURVE_BN254: jac_sum_host<BnFqParams>(xyz, n, form, out_xyz); break;
     }
     return BZH_OK;
 }

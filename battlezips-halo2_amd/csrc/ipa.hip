@@ -549,7 +549,13 @@ static int ipa_verify_t(bzh_ctx* ctx, const bzh_bases* bases, const uint64_t* co
     uint64_t ch[4];
     // S
     uint64_t S[8];
-    if (!h_decompress<C>(proof, S)) return BZH_E_VERIFY;
+    // identity points cannot enter the transcript upstream (Blake2bRead::common_point errors): reject them
+    auto is_identity = [](const uint64_t* p) {
+        uint64_t any = 0;
+        for (int i = 0; i < 8; i++) any |= p[i];
+        return any == 0;
+    };
+    if (!h_decompress<C>(proof, S) || is_identity(S)) return BZH_E_VERIFY;
     IPA_TRY(bzh_transcript_common_point(tr, S));
     IPA_TRY(bzh_transcript_squeeze_challenge(tr, ch));
     const Fe<SF> xi = fe_to_mont(h_load<SF>(ch));
@@ -560,6 +566,7 @@ static int ipa_verify_t(bzh_ctx* ctx, const bzh_bases* bases, const uint64_t* co
         uint64_t* L = &pts[(2 * j) * 8];
         uint64_t* R = &pts[(2 * j + 1) * 8];
         if (!h_decompress<C>(proof + 32 + 64 * j, L) || !h_decompress<C>(proof + 64 + 64 * j, R)) return BZH_E_VERIFY;
+        if (is_identity(L) || is_identity(R)) return BZH_E_VERIFY;
         IPA_TRY(bzh_transcript_common_point(tr, L));
         IPA_TRY(bzh_transcript_common_point(tr, R));
         IPA_TRY(bzh_transcript_squeeze_challenge(tr, ch));

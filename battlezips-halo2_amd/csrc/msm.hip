@@ -1050,8 +1050,9 @@ static int msm_run_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_sca
     const size_t acc_lds = ((size_t)M_acc + 2 + 32 + acc_threads) * 4 + p.chunk * 2 + 16;
     int red_threads = p.M < 256 ? p.M : 256;
     const size_t red_lds = (size_t)red_threads * 128 * 2;
-    static bool attr_set[3] = {false, false, false};
-    if (!attr_set[C::id]) {
+    // per context (= per device; the ctx mutex is held): the dynamic-LDS limit is a per-device function attribute, so a
+    // process that opens contexts on several GPUs has to raise it on each of them
+    if (!ctx->msm_attr_set[C::id]) {
         BZH_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msm_accumulate<C, 256>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         BZH_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msm_accumulate<C, 512>),
@@ -1068,7 +1069,7 @@ static int msm_run_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_sca
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         BZH_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gs_accumulate<C, 512>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        attr_set[C::id] = true;
+        ctx->msm_attr_set[C::id] = true;
     }
 
     for (size_t b0 = 0; b0 < batch; b0 += slice) {

@@ -1875,6 +1875,16 @@ static bool verify_host(const bzh_pk& pk, const uint64_t* inst_xy, const uint8_t
             bad = true;
             return idx;
         }
+        // upstream's Blake2bRead::common_point fails on the identity ("cannot write points at infinity to the
+        // transcript"): a proof carrying an identity commitment is rejected, not absorbed as (0, 0)
+        {
+            uint64_t any = 0;
+            for (int i = 0; i < 8; i++) any |= pts[idx * 8 + i];
+            if (!any) {
+                bad = true;
+                return idx;
+            }
+        }
         off += 32;
         bzh_transcript_common_point(T, &pts[idx * 8]);
         return idx;

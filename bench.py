@@ -1,29 +1,32 @@
 #!/usr/bin/env python3
-"""bench.py -- halo2 create_proof on MI355X through libbzh2.so.
+"""bench.py -- halo2 create_proof for the BattleZips circuits on MI355X through libbzh2.so.
 
-Default workload `proof_k14` (BASELINE.json configs[1..2]: BoardCircuit-sized proofs, k=14, IPA/Pasta, batched):
-one "step" = `--concurrency` host threads each proving `--batch` independent witnesses with ONE bzh_prove_batch call
-(csrc/prove.hip: the whole create_proof behind the C ABI, proofs advanced in lockstep so that every MSM, NTT, gate
-evaluation, scan and IPA round is one launch for the batch).  The circuit has the reference's Board/Shot shape
-(bzh2/synth.py: 11 advice / 8 fixed / 1 instance columns, 24 gates, degree 9, 13 permutation columns, one 10-bit
-lookup); a proof covers column commitments, lookup permute + grand product, permutation grand products, the
-vanishing argument (quotient over the 8n coset), evaluations, multiopen and the IPA opening, transcript included.
-Witness columns are synthetic and resident in HBM before the timed region starts; every proof draws its own blinding
-randomness and its bytes come back to the host inside the timed region.  Defaults: --batch 24 --concurrency 4
-(96 proofs per step).  `--batch 1 --concurrency 1` is the single-proof latency configuration.
-`--driver python` runs the ctypes-level drivers (bzh2/prover_dev.py, bzh2/prover_batch.py) instead.
+Default workload `proof_k14` (BASELINE.json configs[1..2]): complete proofs of the reference's BoardCircuit
+(src/circuits/board.rs, 57 gates, built by the C++ front end csrc/circuit/*.hpp) in a 2^14-row table, IPA over Pasta.
+One "step" = `--concurrency` host threads, each taking `--batch` DISTINCT witnesses (fleets from a pool, a fresh
+trapdoor per proof and step) through
+    bzh_synthesize_board  (Circuit::synthesize: host C++ witness generation, compact pinned staging, expansion kernel)
+    bzh_prove_batch       (create_proof for the batch in lockstep: every MSM, NTT, gate evaluation, scan and IPA round
+                           is one launch for the batch; transcript included; proof bytes back on the host)
+both INSIDE the timed region.  `proof_k11` is the ShotCircuit at the reference's own size (benches/shot.rs:22),
+`proof_k12` the BoardCircuit at its own size (benches/board.rs:22), `proof_k17` the Board scale-up.  After the timed
+region the last batch of every thread is checked with bzh_verify_batch (untimed).
+`--batch 1 --concurrency 1` is the single-proof latency configuration.
 
-`board_k14` / `board_k12` / `shot_k11` / `board_k17` / `shot_k11_batch` time only the MSM + NTT schedule of
-such a proof (28 MSMs of n, 17 iNTT(n), 18 coset NTT(8n), 1 extended iNTT(8n));
-`msm24` / `msm20` / `ntt22` are the config-5 microbenches.
+`mixed_board_shot` is BASELINE.json configs[3]: a FIXED batch of 256 Board (k = 14) + 2560 Shot (k = 11) proofs per step
+(divided by --mix-divisor), sharded over the ranks with bzh2.shard.shard_range (strong scaling), gathered as
+fixed-stride proof records at the end.  `verify_k*` is the reference's second benchmark (benches/board.rs:80-86).
+`board_k14` / `board_k12` / `shot_k11` / `board_k17` / `shot_k11_batch` time only the MSM + NTT schedule of a proof
+(SURVEY.md section 3.1); `msm24` / `msm20` / `ntt22` are the config-5 microbenches -- with --gpus N > 1 `msm24` splits the
+2^24 points over the ranks (N/8 points each), all_gathers the partial sums (96 B each) and adds them locally.
 
 roofline: the dominant kernel is k_msm_accumulate; `achieved` = the library's own count of algorithmic bytes
 (32 B per scalar + 64 B per base point per launch, bzh_ctx_work) / its HIP-event time on the launch stream
 (bzh_ctx_timings), both taken live over the timed region and summed over the host threads' contexts.
 
 Multi-GPU: one process per GPU (torchrun); proofs are independent, so every rank runs the same per-GPU
-workload (weak scaling) and the only collective is one RCCL all_gather of the ranks' outputs at the end of
-the timed region.
+workload (weak scaling; `mixed_board_shot` and multi-rank `msm24`: strong) and the only collective is one RCCL all_gather
+of the ranks' proof records at the end of the timed region.
 """
 import argparse
 import types
@@ -101,11 +104,11 @@ def parse():
                          "local_rank %% device_count); the driver's multi-GPU runs use nccl (RCCL)")
     ap.add_argument("--no-precompute", action="store_true", help="plain bases: no fixed-base window table for the SRS")
     ap.add_argument("--batch", type=int, default=24,
-                    help="proof_k* workloads: proofs advanced in lockstep per step (bzh2/prover_batch.py: one launch per kernel "
-                         "class per phase for the whole batch); 1 = the single-proof latency path (bzh2/prover_dev.py)")
-    ap.add_argument("--driver", default="native", choices=["native", "python"],
-                    help="proof_k* workloads: native = bzh_prove_batch (csrc/prove.hip, the C-ABI whole-proof entry point); "
-                         "python = the ctypes-level drivers bzh2/prover_dev.py (--batch 1) / bzh2/prover_batch.py")
+                    help="proof_k* workloads: witnesses synthesised and proved in lockstep per bzh_prove_batch call; "
+                         "1 = the single-proof latency path")
+    ap.add_argument("--circuit", default="auto", choices=["auto", "shot", "board"],
+                    help="proof_k* workloads: which of the reference's circuits (auto: ShotCircuit at k = 11, BoardCircuit otherwise)")
+    ap.add_argument("--mix-divisor", type=int, default=1, help="mixed_board_shot: divide the fixed batch (256 Board + 2560 Shot) by this")
     ap.add_argument("--window-bits", type=int, default=0, help="SRS window-table width (0: 8 for --batch 1, else the planner's)")
     ap.add_argument("--concurrency", type=int, default=4,
                     help="proof_k* workloads: independent proofs in flight per GPU (host threads, one ctx + stream each)")
@@ -140,10 +143,138 @@ def make_bases(ctx, curve, n, seed):
     return out
 
 
+PATTERN_1 = [(3, 3, True), (5, 4, False), (0, 1, False), (0, 5, True), (6, 1, False)]      # src/circuits/board.rs:101-107
+FQ_MODULUS = 0x40000000000000000000000000000000224698fc0994a8dd8c46eb2100000001
+
+
+def random_fleet(rng):
+    """a valid random fleet (rejection sampling of in-bounds, non-overlapping placements) and its occupied cells"""
+    while True:
+        used, deck = set(), []
+        for length in (5, 4, 3, 3, 2):
+            for _ in range(200):
+                z = rng.random() < 0.5
+                x, y = rng.randrange(10 - (0 if z else length - 1)), rng.randrange(10 - (length - 1 if z else 0))
+                cells = {(x, y + i) if z else (x + i, y) for i in range(length)}
+                if not cells & used:
+                    used |= cells
+                    deck.append((x, y, z))
+                    break
+            else:
+                break
+        if len(deck) == 5:
+            return deck, used
+
+
+class ProofRunner:
+    """`workers` host threads, each with its own ctx + stream + proving key + advice tensor in HBM, proving slices of
+    `batch` witnesses of one real circuit: bzh_synthesize_{shot,board} (device output) then bzh_prove_batch."""
+
+    POOL = 64   # distinct fleets / shots the witnesses cycle through; every proof also gets its own trapdoor
+
+    def __init__(self, kind, k, ctx, device, seed, batch, workers, window_bits=0, first_ctx=None):
+        import random
+        from bzh2 import circuits as Cm, native as N
+        from bzh2.game import BinaryValue
+        self.kind, self.k, self.batch, self.device = kind, k, batch, device
+        self.Cm = Cm
+        self.layout = Cm.CircuitLayout(Cm.SHOT if kind == "shot" else Cm.BOARD, k)
+        blob = self.layout.blob()
+        d = self.layout.describe()
+        self.circuit_desc = ("%sCircuit of the reference (src/circuits/%s.rs) via the C++ front end: %d gates / %d constraint polynomials, %d advice + %d fixed "
+                             "(incl. %d selector) columns, degree %d, %d permutation columns, 1 lookup, %d regions, %d of 2^%d rows used"
+                             % (kind.capitalize(), kind, len(d["gates"]), d["num_polys"], d["num_advice"], d["num_fixed"],
+                                d["num_fixed"] - 10, d["degree"], len(d["permutation"]), len(d["regions"]), d["rows_used"], k))
+        n = 1 << k
+        as_pt = lambda a: (bzh2.limbs_to_int(a[:4]), bzh2.limbs_to_int(a[4:]))
+        g = [as_pt(a) for a in make_bases(ctx, bzh2.CURVE_VESTA, n + 2, 4242 + k)]   # same SRS on every rank
+        rng = random.Random(seed)
+        self.pool = []
+        for _ in range(self.POOL):
+            deck, used = random_fleet(rng)
+            ships, state = Cm.board_witness(deck, None)
+            x, y = rng.randrange(10), rng.randrange(10)
+            self.pool.append((ships, state, Cm.shot_serialize([x], [y]), BinaryValue.from_u8(1 if (x, y) in used else 0)))
+        self.rng_seed = seed
+        self.ctxs, self.streams, self.pks, self.adv = [], [], [], []
+        for wi in range(workers):
+            if wi == 0 and first_ctx is not None:
+                st, wctx = None, first_ctx
+            else:
+                st = torch.cuda.Stream(device=device)
+                wctx = bzh2.Context(device.index or 0, stream=st.cuda_stream)
+            self.streams.append(st)
+            self.ctxs.append(wctx)
+            self.pks.append(N.NativeProvingKey(wctx, blob, bzh2.CURVE_VESTA, g[:n], g[n + 1], g[n], window_bits=window_bits))
+            self.adv.append(torch.zeros((batch, self.layout.num_advice, n, 4), dtype=torch.int64, device=device))
+        torch.cuda.synchronize(device)
+        self.rng_bytes = self.pks[0].rng_bytes
+        self.proof_stride = self.pks[0].max_proof_bytes
+        self.last_batch = [[] for _ in range(workers)]
+        self.last_insts = [[] for _ in range(workers)]
+        self.step_batches = [[] for _ in range(workers)]      # every batch of the current plan (for the record gather)
+        self.np_rng = [np.random.default_rng(seed + 1000 + wi) for wi in range(workers)]
+
+    def worker_ctxs(self):
+        return [(st, types.SimpleNamespace(ctx=c)) for st, c in zip(self.streams, self.ctxs)]
+
+    def _circuits(self, lo, count):
+        Cm = self.Cm
+        out = []
+        for i in range(lo, lo + count):
+            ships, state, shot, hit = self.pool[i % self.POOL]
+            trapdoor = (0x9e3779b97f4a7c15 * (i + 1) * (self.rng_seed + 3) + (i << 130)) % FQ_MODULUS
+            out.append(Cm.ShotCircuit(state, trapdoor, shot, hit) if self.kind == "shot" else Cm.BoardCircuit(ships, state, trapdoor))
+        return out
+
+    def _prove_slice(self, wi, lo, count):
+        circuits = self._circuits(lo, count)
+        _, insts = self.layout.synthesize(circuits, ctx=self.ctxs[wi], device_ptr=self.adv[wi].data_ptr(), threads=4)
+        blob = self.np_rng[wi].bytes(self.rng_bytes * count)
+        rbs = [blob[i * self.rng_bytes:(i + 1) * self.rng_bytes] for i in range(count)]
+        proofs = self.pks[wi].prove_batch(None, insts, rbs, device_ptr=self.adv[wi].data_ptr())
+        self.last_batch[wi], self.last_insts[wi] = proofs, insts
+        self.step_batches[wi].append(proofs)
+
+    def plan(self, lo, count):
+        """jobs (one per worker) that together prove witnesses [lo, lo + count) in slices of `batch`"""
+        slices = [(s, min(self.batch, lo + count - s)) for s in range(lo, lo + count, self.batch)]
+        W = len(self.pks)
+
+        def job(wi):
+            def run():
+                self.step_batches[wi] = []
+                for s, c in slices[wi::W]:
+                    self._prove_slice(wi, s, c)
+            return run
+        return [job(wi) for wi in range(W)]
+
+    def has_records(self):
+        return any(self.step_batches)
+
+    def proof_records(self):
+        """the last step's proofs of this rank as fixed-stride records {u32 length, bytes}: what the final gather carries"""
+        recs = bytearray()
+        for batches in self.step_batches:
+            for proofs in batches:
+                for pr in proofs:
+                    recs += len(pr).to_bytes(4, "little") + pr + bytes(self.proof_stride - len(pr))
+        a = np.frombuffer(bytes(recs), dtype=np.uint8).reshape(-1, 4 + self.proof_stride)
+        return torch.from_numpy(a.copy()).to(self.device)
+
+    def verify_last(self):
+        ok = True
+        for wi, pk in enumerate(self.pks):
+            if self.last_batch[wi]:
+                ok = ok and all(pk.verify_batch(self.last_insts[wi], self.last_batch[wi]))
+        return ok
+
+
 class Workload:
     """Device-resident inputs + the list of library calls that make one step."""
 
-    def __init__(self, name, ctx, device, seed, precompute=True, concurrency=1, batch=1, window_bits=0, driver="native"):
+    def __init__(self, name, ctx, device, seed, precompute=True, concurrency=1, batch=1, window_bits=0, circuit="auto", rank=0, world=1,
+                 mix_divisor=1, dist=None):
         self.name, self.ctx = name, ctx
         gen = torch.Generator(device=device)
         gen.manual_seed(seed)
@@ -185,186 +316,103 @@ class Workload:
                          "ntt": "%dx iNTT 2^%d + %dx coset NTT 2^%d + %dx coset iNTT 2^%d (Fp)" % (17 * proofs, k, 18 * proofs, k + 3, proofs, k + 3)}
             self.result = self.msm_out
         elif name == "mixed_board_shot":
-            # BASELINE.json configs[3] on one GPU: Board-sized (k = 14) and Shot-sized (k = 11) proofs in the 1 : 10 ratio of
-            # "256 Board + 2560 Shot", two host threads per circuit, every thread its own ctx / stream / proving key
-            import threading
-            from bzh2 import native as N, synth
-            from bzh2.device import DeviceOps
+            # BASELINE.json configs[3]: a FIXED batch of 256 Board (k = 14) + 2560 Shot (k = 11) proofs per step, sharded over
+            # the ranks (strong scaling): rank r proves shard_range(total, r, world) of each kind
+            from bzh2.shard import shard_range
             self.k = 14
-            b14 = max(batch // 2, 1)
-            plan = [(14, b14), (11, 10 * b14), (14, b14), (11, 10 * b14)]
-            self.mix = []
-            as_pt = lambda a: (bzh2.limbs_to_int(a[:4]), bzh2.limbs_to_int(a[4:]))
-            for wi, (k, bsz) in enumerate(plan):
-                n = 1 << k
-                if wi == 0:
-                    wctx = ctx
-                else:
-                    st = torch.cuda.Stream(device=device)
-                    wctx = bzh2.Context(device.index or 0, stream=st.cuda_stream)
-                circ, adv, inst = synth.battlezips_shaped(k, seed + k)
-                g = [as_pt(a) for a in make_bases(wctx, self.curve, n + 2, seed + 1)]
-                npk = N.NativeProvingKey(wctx, circ, self.curve, g[:n], g[n + 1], g[n])
-                ops = DeviceOps(wctx, self.field, self.curve, npk.p, device)
-                adv_b = torch.stack([ops.upload(list(col) + [0] * (n - len(col))) for col in adv]).unsqueeze(0).repeat(bsz, 1, 1, 1).contiguous()
-                rbs = [np.random.default_rng(seed + 100 * wi + i).bytes(npk.rng_bytes) for i in range(bsz)]
-                self.mix.append((npk, adv_b, [inst] * bsz, rbs, wctx))
-            torch.cuda.synchronize(device)
-            self.workers = [(None if wi == 0 else True, types.SimpleNamespace(ctx=m[4])) for wi, m in enumerate(self.mix)]
-            self.proofs_made = [0] * len(plan)
-
-            def prove_one(wi):
-                npk, adv_b, insts, rbs, _ = self.mix[wi]
-                proofs = npk.prove_batch(None, insts, rbs, device_ptr=adv_b.data_ptr())
-                self.proofs_made[wi] = len(proofs)
-                if wi == 0:
-                    self.last_proof = proofs[0]
+            nb, ns = max(256 // mix_divisor, 1), max(2560 // mix_divisor, 1)
+            mine_b, mine_s = shard_range(nb, rank, world), shard_range(ns, rank, world)
+            self.provers = [ProofRunner("board", 14, ctx, device, seed, batch=max(batch // 2, 1), workers=2, window_bits=window_bits, first_ctx=ctx),
+                            ProofRunner("shot", 11, ctx, device, seed + 7, batch=max(batch // 2, 1) * 8, workers=2, window_bits=window_bits)]
+            self.shares = [(mine_b.start, len(mine_b)), (mine_s.start, len(mine_s))]
+            self.workers = [w for p in self.provers for w in p.worker_ctxs()]
 
             def prove():
-                run_threads(prove_one, len(plan))
-            self.calls = [("bzh_prove_batch x4 (2 Board k=14, 2 Shot k=11)", prove)]
-            self.units_per_step = sum(b for _, b in plan)
+                jobs = []
+                for p, (lo, cnt) in zip(self.provers, self.shares):
+                    jobs += p.plan(lo, cnt)
+                run_threads(lambda i: jobs[i](), len(jobs))
+            self.calls = [("bzh_synthesize_* + bzh_prove_batch, fixed batch shard", prove)]
+            self.units_per_step = nb + ns                 # whole-job units: the fixed batch (every rank adds its share)
+            self.local_units_per_step = len(mine_b) + len(mine_s)
+            self.fixed_total = True
+            self.records = lambda: torch.cat([p.proof_records() for p in self.provers if p.has_records()], dim=0)
+            self.record_counts = lambda: [len(shard_range(nb, r, world)) + len(shard_range(ns, r, world)) for r in range(world)]
+            self.verify_last = lambda: all(p.verify_last() for p in self.provers)
             self.alg_bytes_msm_launch = 0
             self.alg_bytes_step = 0
             self.last_proof = b""
-            self.desc = {"mix": "per step %d Board-sized (k=14) + %d Shot-sized (k=11) proofs" % (2 * b14, 20 * b14)}
+            self.desc = {"mix": "per step %d BoardCircuit (k=14) + %d ShotCircuit (k=11) proofs, fixed batch; this rank: %d + %d"
+                                % (nb, ns, len(mine_b), len(mine_s))}
             self.result = torch.zeros((1, 12), dtype=torch.int64, device=device)
         elif name.startswith("verify_k"):
-            # the reference's second benchmark (benches/board.rs:80-86): verify_proof over a batch of proofs of the
-            # BattleZips-shaped circuit, made once (untimed) by bzh_prove_batch; one step = one bzh_verify_batch call
-            from bzh2 import native as N, synth
-            from bzh2.device import DeviceOps
+            # the reference's second benchmark (benches/board.rs:80-86): verify_proof over a batch of proofs of the real
+            # circuit, made once (untimed) by bzh_prove_batch; one step = one bzh_verify_batch call
             k = int(name[len("verify_k"):])
-            n = 1 << k
             self.k = k
-            circ, adv, inst = synth.battlezips_shaped(k, seed)
-            pts = make_bases(ctx, self.curve, n + 2, seed + 1)
-            as_pt = lambda a: (bzh2.limbs_to_int(a[:4]), bzh2.limbs_to_int(a[4:]))
-            g = [as_pt(a) for a in pts]
-            self.npk = N.NativeProvingKey(ctx, circ, self.curve, g[:n], g[n + 1], g[n])
-            ops = DeviceOps(ctx, self.field, self.curve, self.npk.p, device)
-            adv_b = torch.stack([ops.upload(list(col) + [0] * (n - len(col))) for col in adv]).unsqueeze(0).repeat(batch, 1, 1, 1).contiguous()
-            torch.cuda.synchronize(device)
-            rbs = [np.random.default_rng(seed + 100 + i).bytes(self.npk.rng_bytes) for i in range(batch)]
-            self.insts = [inst] * batch
-            self.proofs = self.npk.prove_batch(None, self.insts, rbs, device_ptr=adv_b.data_ptr())
+            self.runner = ProofRunner("shot" if k == 11 else "board", k, ctx, device, seed, batch=batch, workers=1, window_bits=window_bits, first_ctx=ctx)
+            self.runner.plan(0, batch)[0]()
+            self.insts, self.proofs = self.runner.last_insts[0], self.runner.last_batch[0]
             self.accepted = 0
 
             def verify():
-                res = self.npk.verify_batch(self.insts, self.proofs)
+                res = self.runner.pks[0].verify_batch(self.insts, self.proofs)
                 self.accepted = sum(res)
             self.calls = [("bzh_verify_batch", verify)]
             self.units_per_step = batch
             self.alg_bytes_msm_launch = 0
             self.alg_bytes_step = 0
-            self.desc = {"k": k, "batch": batch, "proof_bytes": len(self.proofs[0])}
+            self.desc = {"k": k, "batch": batch, "proof_bytes": len(self.proofs[0]), "circuit": self.runner.circuit_desc}
             self.result = torch.zeros((1, 12), dtype=torch.int64, device=device)
         elif name.startswith("proof_k"):
-            # a COMPLETE proof per step: bzh2/prover_dev.create_proof on a circuit with the shape of the reference's
-            # Shot / Board circuits (bzh2/synth.py); witness columns are resident in HBM before the timed region
-            from bzh2 import prover_dev as D, synth
+            # COMPLETE proofs of the reference's circuit per step: witness synthesis + create_proof, both timed
             k = int(name[len("proof_k"):])
-            n = 1 << k
             self.k = k
-            circ, adv, inst = synth.battlezips_shaped(k, seed)
-            pts = make_bases(ctx, self.curve, n + 2, seed + 1)
-            as_pt = lambda a: (bzh2.limbs_to_int(a[:4]), bzh2.limbs_to_int(a[4:]))
-            g = [as_pt(a) for a in pts]
+            kind = circuit if circuit != "auto" else ("shot" if k == 11 else "board")
             wb = window_bits or (8 if batch == 1 else 0)
             self.window_bits = wb
-            self.driver = driver
-            if driver == "native":
-                self._setup_native(ctx, device, circ, adv, inst, g, n, seed, batch, concurrency, wb)
-                return
-            self.pk = D.DeviceProvingKey(ctx, circ, self.curve, g[:n], g[n + 1], g[n], device, window_bits=wb)
-            self.adv_dev = [self.pk.ops.upload(col) for col in adv]
-            self.inst = inst
-            self.circ = circ
-            ndraws = 3 * n + 2048
-            self.rng_pool = [np.random.default_rng(seed + 100 + i).bytes(64 * ndraws) for i in range(4)]
+            self.runner = ProofRunner(kind, k, ctx, device, seed, batch=batch, workers=concurrency, window_bits=wb, first_ctx=ctx)
+            self.workers = self.runner.worker_ctxs()
             self.step_no = 0
-            self.last_proof = b""
-
-            # `concurrency` independent proofs per step, one host thread each with its own ctx + HIP stream;
-            # the proving key (SRS window table, fixed / permutation polynomials) is shared read-only
-            import copy
-            import threading
-            self.units_per_step = concurrency
-            self.workers = []
-            for wi in range(concurrency):
-                if wi == 0:
-                    self.workers.append((None, self.pk))
-                    continue
-                st = torch.cuda.Stream(device=device)
-                wctx = bzh2.Context(device.index or 0, stream=st.cuda_stream)
-                wpk = copy.copy(self.pk)
-                wpk.ctx = wctx
-                wpk.ops = type(self.pk.ops)(wctx, self.pk.field, self.pk.curve, self.pk.p, device)
-                self.workers.append((st, wpk))
-
-            def prove_one(wi, rb):
-                st, wpk = self.workers[wi]
-                if st is None:
-                    self.last_proof = D.create_proof(wpk, self.adv_dev, self.inst, rb, bzh2.Transcript(bzh2.FIELD_FP))
-                else:
-                    with torch.cuda.stream(st):
-                        D.create_proof(wpk, self.adv_dev, self.inst, rb, bzh2.Transcript(bzh2.FIELD_FP))
-                    st.synchronize()
 
             def prove():
-                rbs = [self.rng_pool[(self.step_no + wi) % len(self.rng_pool)] for wi in range(concurrency)]
+                jobs = self.runner.plan(self.step_no * batch * concurrency, batch * concurrency)
                 self.step_no += 1
-                run_threads(lambda wi: prove_one(wi, rbs[wi]), concurrency)
-            self.calls = [("create_proof", prove)]
-            if batch > 1:
-                # lockstep batch: the same witness columns for every proof of the batch (each proof still draws its own
-                # blinding randomness, so the proofs differ), stacked once and resident in HBM
-                # `concurrency` such batches run side by side (host threads, one ctx + stream each): one batch's host
-                # phases (transcripts, lookup sort, challenge uploads) overlap the other's kernels
-                from bzh2 import prover_batch as PB
-                bps = [PB.BatchProver(wpk) for _, wpk in self.workers]
-                adv_b = torch.stack(self.adv_dev).unsqueeze(0).repeat(batch, 1, 1, 1).contiguous()
-                self.units_per_step = batch * concurrency
-                self.rng_pool = [np.random.default_rng(seed + 100 + i).bytes(64 * ndraws) for i in range(batch * concurrency + 3)]
-                self.distinct = 0
-
-                def prove_batch_one(wi, step_no):
-                    rbs = [self.rng_pool[(step_no + wi * batch + b) % len(self.rng_pool)] for b in range(batch)]
-                    st = self.workers[wi][0]
-                    trs = [bzh2.Transcript(bzh2.FIELD_FP) for _ in range(batch)]
-                    if st is None:
-                        proofs = PB.create_proofs(bps[wi], adv_b, [self.inst] * batch, rbs, trs)
-                        self.last_proof = proofs[0]
-                        self.distinct = len(set(proofs))
-                    else:
-                        with torch.cuda.stream(st):
-                            PB.create_proofs(bps[wi], adv_b, [self.inst] * batch, rbs, trs)
-                        st.synchronize()
-
-                def prove_batch():
-                    sn = self.step_no
-                    self.step_no += 1
-                    run_threads(lambda wi: prove_batch_one(wi, sn), concurrency)
-                self.calls = [("create_proofs", prove_batch)]
+                run_threads(lambda i: jobs[i](), len(jobs))
+            self.calls = [("bzh_synthesize_%s + bzh_prove_batch" % kind, prove)]
+            self.solo_step = lambda: self.runner.plan(0, batch)[0]()
+            self.units_per_step = batch * concurrency
+            self.records = self.runner.proof_records
+            self.verify_last = self.runner.verify_last
             self.alg_bytes_msm_launch = 0
-            self.alg_bytes_step = 0  # filled from the library's own counters (bzh_ctx_work) after the timed region
-            self.desc = {"k": k, "circuit": "synthetic, BattleZips-shaped: 11 advice / 8 fixed / 1 instance, 24 gates, degree 9, "
-                                            "13 permutation columns, one 10-bit lookup (bzh2/synth.py)",
-                         "proof_bytes": None}
+            self.alg_bytes_step = 0
+            self.desc = {"k": k, "circuit": self.runner.circuit_desc, "proof_bytes": None, "driver": "native (bzh_synthesize_* + bzh_prove_batch)"}
             self.result = torch.zeros((1, 12), dtype=torch.int64, device=device)
         elif name in ("msm24", "msm20"):
+            # config 5: one 2^k-point MSM.  With several ranks the POINTS are split (shard_range: N / world per GPU, no
+            # exchange of inputs); each step all-gathers the 96-byte partial sums and every rank adds them locally
+            from bzh2.shard import combine_msm_partials, shard_range
             k = 24 if name == "msm24" else 20
             n = 1 << k
             self.k = k
-            self.bases = ctx.upload_bases(self.curve, make_bases(ctx, self.curve, n, seed + 1))
+            mine = shard_range(n, rank, world)
+            nl = len(mine)
+            self.bases = ctx.upload_bases(self.curve, make_bases(ctx, self.curve, nl, 77 + rank))
             if precompute:
                 self.bases.precompute()
-            self.msm_scalars = rand_field((1, n), gen, device)
+            self.msm_scalars = rand_field((1, nl), gen, device)
             self.msm_out = torch.zeros((1, 12), dtype=torch.int64, device=device)
-            self.calls = [("msm", lambda: ctx.msm_device(self.bases, self.msm_scalars.data_ptr(), n, 1, self.msm_out.data_ptr()))]
-            self.alg_bytes_msm_launch = n * 96
+            self.calls = [("msm", lambda: ctx.msm_device(self.bases, self.msm_scalars.data_ptr(), nl, 1, self.msm_out.data_ptr()))]
+            if world > 1:
+                self.fixed_total = True
+                self.total_point = None
+
+                def combine():
+                    self.total_point = combine_msm_partials(self.curve, self.msm_out[0], dist, bzh2.FORM_MONTGOMERY)
+                self.calls.append(("all_gather 96-B partials + local adds", combine))
+            self.alg_bytes_msm_launch = nl * 96
             self.alg_bytes_step = n * 96
-            self.desc = {"msm": "1x2^%d vesta" % k}
+            self.desc = {"msm": "1x2^%d vesta%s" % (k, (", points split over %d ranks (%d each)" % (world, nl)) if world > 1 else "")}
             self.result = self.msm_out
         elif name == "ntt22":
             k = 22
@@ -377,68 +425,6 @@ class Workload:
             self.result = self.data[:, :4].contiguous().view(1, 16)[:, :12].contiguous()
         else:
             raise ValueError(name)
-
-    def _setup_native(self, ctx, device, circ, adv, inst, g, n, seed, batch, concurrency, wb):
-        """proof_k* through bzh_pk_create / bzh_prove_batch: `concurrency` host threads, each with its own ctx + stream +
-        proving key, each proving `batch` witnesses per step in lockstep; witness tensor resident in HBM."""
-        import threading
-        from bzh2 import native as N
-        from bzh2.device import DeviceOps
-        self.workers = []
-        self.npks = []
-        for wi in range(concurrency):
-            if wi == 0:
-                st, wctx = None, ctx
-            else:
-                st = torch.cuda.Stream(device=device)
-                wctx = bzh2.Context(device.index or 0, stream=st.cuda_stream)
-            self.npks.append(N.NativeProvingKey(wctx, circ, self.curve, g[:n], g[n + 1], g[n], window_bits=wb))
-            self.workers.append((st, self.npks[-1]))
-        ops = DeviceOps(ctx, self.field, self.curve, self.npks[0].p, device)
-        adv_b = torch.stack([ops.upload(list(col) + [0] * (n - len(col))) for col in adv]).unsqueeze(0).repeat(batch, 1, 1, 1).contiguous()
-        torch.cuda.synchronize(device)
-        self.adv_b = adv_b
-        nbytes = self.npks[0].rng_bytes
-        self.rng_pool = [np.random.default_rng(seed + 100 + i).bytes(nbytes) for i in range(batch * concurrency + 3)]
-        self.step_no = 0
-        self.last_proof = b""
-        self.distinct = 0
-        self.units_per_step = batch * concurrency
-        self.inst = inst
-
-        def prove_one(wi, sn):
-            rbs = [self.rng_pool[(sn + wi * batch + b) % len(self.rng_pool)] for b in range(batch)]
-            proofs = self.workers[wi][1].prove_batch(None, [self.inst] * batch, rbs, device_ptr=adv_b.data_ptr())
-            self.last_batch[wi] = proofs
-            if wi == 0:
-                self.last_proof = proofs[0]
-                self.distinct = len(set(proofs))
-
-        self.last_batch = [[] for _ in range(concurrency)]
-        self.proof_stride = self.npks[0].max_proof_bytes
-
-        def proof_records():
-            """the last step's proofs of this rank as fixed-stride records {u32 length, bytes}: what the final gather carries"""
-            recs = bytearray()
-            for proofs in self.last_batch:
-                for pr in proofs:
-                    recs += len(pr).to_bytes(4, "little") + pr + bytes(self.proof_stride - len(pr))
-            a = np.frombuffer(bytes(recs), dtype=np.uint8).reshape(-1, 4 + self.proof_stride)
-            return torch.from_numpy(a.copy()).to(device)
-        self.records = proof_records
-
-        def prove():
-            sn = self.step_no
-            self.step_no += 1
-            run_threads(lambda wi: prove_one(wi, sn), concurrency)
-        self.calls = [("bzh_prove_batch", prove)]
-        self.solo_step = lambda: prove_one(0, self.step_no)
-        self.alg_bytes_msm_launch = 0
-        self.alg_bytes_step = 0
-        self.desc = {"k": self.k, "circuit": "synthetic, BattleZips-shaped: 11 advice / 8 fixed / 1 instance, 24 gates, degree 9, "
-                                            "13 permutation columns, one 10-bit lookup (bzh2/synth.py)",
-                     "proof_bytes": None, "driver": "native (bzh_prove_batch)"}
-        self.result = torch.zeros((1, 12), dtype=torch.int64, device=device)
 
     def step(self):
         for _, fn in self.calls:
@@ -513,7 +499,7 @@ def main():
     stream = torch.cuda.current_stream(device)
     ctx = bzh2.Context(local_rank, stream=stream.cuda_stream)
     wl = Workload(args.workload, ctx, device, seed=1234 + rank, precompute=not args.no_precompute, concurrency=args.concurrency, batch=args.batch,
-                  window_bits=args.window_bits, driver=args.driver)
+                  window_bits=args.window_bits, circuit=args.circuit, rank=rank, world=world, mix_divisor=args.mix_divisor, dist=dist)
 
     def barrier():
         torch.cuda.synchronize(device)
@@ -534,8 +520,11 @@ def main():
     if dist is not None:  # the one collective: gather every rank's commitments (fixed-stride records)
         from bzh2.shard import gather_records
         local = wl.records() if hasattr(wl, "records") else wl.result  # complete proofs: the proof records themselves
-        gathered = gather_records(local, [local.shape[0]] * world, dist)
-        assert gathered.shape[0] == local.shape[0] * world
+        counts = wl.record_counts() if hasattr(wl, "record_counts") else [local.shape[0]] * world
+        gathered = gather_records(local, counts, dist)
+        assert gathered.shape[0] == sum(counts)
+        if hasattr(wl, "combine"):
+            wl.combine(gathered)
     barrier()
     elapsed = time.perf_counter() - t0
     timings = ctx.timings()
@@ -558,13 +547,17 @@ def main():
         torch.cuda.synchronize(device)
         solo = ctx.timings()["msm_accumulate"]
         ctx.profile(False)
+    verified = None
+    if hasattr(wl, "verify_last"):  # untimed: every proof of every thread's last batch through bzh_verify_batch
+        verified = bool(wl.verify_last())
+        assert verified, "a proof of the last batch does not verify"
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     if rank == 0:
-        units = wl.units_per_step * args.steps * world
+        units = wl.units_per_step * args.steps * (1 if getattr(wl, "fixed_total", False) else world)
         is_proof = args.workload.startswith(("board", "shot"))
         is_full = args.workload.startswith("proof_k")
         is_verify = args.workload.startswith("verify_k")
@@ -603,13 +596,13 @@ def main():
                 traffic = None
         line = {
             "metric": ("%s proof MSM+NTT workloads per second" % args.workload) if is_proof else
-                      (("complete proofs per second, BattleZips-shaped circuit, k=%d, IPA/Pasta" % wl.k) if is_full
+                      (("complete proofs per second (synthesis + create_proof), %sCircuit, k=%d, IPA/Pasta" % (wl.runner.kind.capitalize(), wl.k)) if is_full
                        else ("%s runs per second" % args.workload)),
             "value": units / elapsed,
             "unit": "proof-workloads/s" if is_proof else ("proofs/s" if is_full else "runs/s"),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if getattr(wl, "fixed_total", False) else "weak", "vs_baseline": None,
             "dtype": "u32x8 (255-bit modular integer, Montgomery)", "data": "synthetic",
             "config": dict({"workload": args.workload, "curve": "vesta/Fp (IPA over Pasta, the reference's locked build)",
                             "stages": "MSM commits + NTT/iNTT/coset-NTT of one proof; NOT included: synthesis, quotient, "
@@ -644,26 +637,27 @@ def main():
                     "note": "same kernel, one batch in flight (2 untimed steps after the timed region); in the timed region "
                             "%d batches share the GPU and every launch stretches accordingly" % len(all_ctx)}
         if is_mixed:
-            line["metric"] = "complete proofs per second, Board-sized (k=14) : Shot-sized (k=11) = 1 : 10, IPA/Pasta"
+            line["metric"] = "complete proofs per second, fixed batch of BoardCircuit (k=14) : ShotCircuit (k=11) = 1 : 10, IPA/Pasta"
             line["unit"] = "proofs/s"
-            line["config"]["stages"] = "complete create_proof for every proof of the mix (bzh_prove_batch), witnesses resident in HBM"
+            line["config"]["stages"] = "witness synthesis + complete create_proof for every proof of the fixed batch, sharded over the ranks"
+            line["config"]["last_batches_verified"] = verified
         if is_verify:
-            line["metric"] = "proof verifications per second, BattleZips-shaped circuit, k=%d, IPA/Pasta" % wl.k
+            line["metric"] = "proof verifications per second, %sCircuit, k=%d, IPA/Pasta" % (wl.runner.kind.capitalize(), wl.k)
             line["unit"] = "verifications/s"
             line["config"]["stages"] = ("complete verify_proof: instance commitments, transcript replay, expected h(x), multiopen "
                                         "recombination, IPA equation (one n-term MSM per proof)")
             line["config"]["accepted_in_last_batch"] = wl.accepted
             assert wl.accepted == wl.units_per_step, "a valid proof was rejected"
         if is_full:
-            line["config"]["stages"] = ("complete create_proof: commitments, lookup, permutation, vanishing, quotient, evaluations, "
-                                        "multiopen, IPA, transcript; witness synthesis excluded (columns resident in HBM)")
-            line["config"]["proof_bytes"] = len(wl.last_proof)
+            line["config"]["stages"] = ("Circuit::synthesize (host C++ witness generation, staged to HBM) + complete create_proof: commitments, "
+                                        "lookup, permutation, vanishing, quotient, evaluations, multiopen, IPA, transcript -- all inside the timed region")
+            line["config"]["proof_bytes"] = len(wl.runner.last_batch[0][0])
+            line["config"]["last_batches_verified"] = verified
             line["config"]["proofs_in_flight_per_gpu"] = args.concurrency * args.batch
             line["config"]["concurrent_batches"] = args.concurrency
             line["config"]["batch"] = args.batch
             line["config"]["srs_window_bits"] = wl.window_bits or "planner"
-            if args.batch > 1 or args.driver == "native":
-                line["config"]["distinct_proofs_in_last_batch"] = wl.distinct
+            line["config"]["distinct_proofs_in_last_batch"] = len(set(wl.runner.last_batch[0]))
         if world == 1 and (is_proof or is_full) and not args.no_cpu_baseline and args.workload != "shot_k11_batch":
             line["cpu_baseline"] = cpu_baseline(args.workload, wl.k)
             if is_full:

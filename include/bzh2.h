@@ -339,6 +339,9 @@ int bzh_fixed_base_tables(int base, uint64_t* z, uint64_t* u, uint64_t* lagrange
 /* ---- host helpers (CPU, no device needed): what `.to_affine()` / `to_bytes()`
  * do on the Rust side; used by tests and benches to compare canonical bytes. */
 int bzh_jacobian_to_affine(int curve, const uint64_t* xyz, size_t n, int form, uint64_t* out_xy);
+/* sum of n Jacobian points (host): the combine step of one MSM whose points are split over several GPUs -- every rank
+ * holds N/R points, returns one 96-byte partial, the partials are all-gathered and added locally. */
+int bzh_jacobian_sum(int curve, const uint64_t* xyz, size_t n, int form, uint64_t* out_xyz);
 /* pasta_curves to_bytes: x little-endian, bit 255 = parity of canonical y, identity = 32 zero bytes.
  * xy in `form`; out: n * 32 bytes. */
 int bzh_affine_compress(int curve, const uint64_t* xy, size_t n, int form, uint8_t* out32);

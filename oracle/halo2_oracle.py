@@ -510,7 +510,8 @@ class _Reader:
         raw[31] &= 0x7f
         x = int.from_bytes(raw, "little")
         if x == 0 and ys == 0:
-            pt = None
+            # upstream's Blake2bRead::common_point errors on the identity ("cannot write points at infinity to the transcript")
+            raise ValueError("identity point in proof")
         else:
             cv = self.cv
             y = cv.base.sqrt((x * x * x + cv.a * x + cv.b) % cv.p)

@@ -603,7 +603,15 @@ def ipa_open(curve: "Curve", g, w, u, poly, blind: int, x3: int, rand_scalars, t
 
 
 def ipa_verify(curve: "Curve", g, w, u, commitment, x3: int, v: int, proof: bytes, transcript: "Blake2bTranscript") -> bool:
-    """sum_j (u_j^-1 L_j + u_j R_j) + P - [v]G_0 + [xi]S == [c]G'_0 + [c b_0 z]U + [f]W."""
+    """sum_j (u_j^-1 L_j + u_j R_j) + P - [v]G_0 + [xi]S == [c]G'_0 + [c b_0 z]U + [f]W.  A malformed proof (a point
+    off the curve, the identity where a transcript point is read) does not verify."""
+    try:
+        return _ipa_verify(curve, g, w, u, commitment, x3, v, proof, transcript)
+    except ValueError:
+        return False
+
+
+def _ipa_verify(curve: "Curve", g, w, u, commitment, x3: int, v: int, proof: bytes, transcript: "Blake2bTranscript") -> bool:
     F = curve.scalar
     p = F.p
     n = len(g)
@@ -615,7 +623,8 @@ def ipa_verify(curve: "Curve", g, w, u, commitment, x3: int, v: int, proof: byte
         raw[31] &= 0x7f
         x = int.from_bytes(raw, "little")
         if x == 0 and ysign == 0:
-            return None
+            # upstream's Blake2bRead::common_point errors on the identity: such a proof does not verify
+            raise ValueError("identity point in proof")
         y = curve.base.sqrt((x * x * x + curve.a * x + curve.b) % curve.p)
         if y is None:
             raise ValueError("not on curve")

@@ -120,6 +120,9 @@ def test_native_verify_batch_agrees_with_oracle_verifier(gpu_ctx, oracle_c, k, w
         cases.append((inst, good[:-32]))                                        # truncated
         cases.append((inst, good[:-32] + (F.p + 1).to_bytes(32, "little")))     # non-canonical final scalar
         cases.append((inst, good + b"\x00" * 32))                               # trailing bytes
+        cases.append((inst, bytes(32) + good[32:]))                             # an identity commitment: upstream's transcript refuses it
+        ipa_start = len(good) - 32 * (2 * k + 3)
+        cases.append((inst, good[:ipa_start] + bytes(32) + good[ipa_start + 32:]))   # identity as the IPA's S
         got = pk.verify_batch([c[0] for c in cases], [c[1] for c in cases])
         want = [H.verify_proof(keys, c[0], c[1], O.Blake2bTranscript(F)) for c in cases]
         assert got == want
