@@ -262,6 +262,9 @@ int poly_kate_division(bzh_ctx* ctx, int field, const uint32_t* d_c, size_t n, s
 // exprvm.hip
 int expr_eval(bzh_ctx* ctx, int field, const void* d_prog, int nops, const uint32_t* const* d_cols, const size_t* d_strides,
               const uint32_t* d_consts, size_t const_stride, size_t size, int result_slot, size_t batch, int nslots, uint32_t* d_out);
+// VM v2 (stack-discipline registers + LDS slot file): the prover's quotient evaluator
+int expr_eval2(bzh_ctx* ctx, int field, const void* d_prog, int nops, const uint32_t* const* d_cols, const size_t* d_strides,
+               const uint32_t* d_consts, size_t const_stride, size_t size, size_t batch, int nlds, uint32_t* d_out);
 // ipa.hip
 int random_field(bzh_ctx* ctx, int field, const uint32_t* d_raw, size_t count, uint32_t* d_out);
 int ipa_open(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_polys, size_t batch, const uint64_t* blinds,

@@ -151,6 +151,114 @@ int expr_eval(bzh_ctx* ctx, int field, const void* d_prog, int nops, const uint3
     return BZH_E_ARG;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// VM v2: the quotient evaluator of the whole-proof driver (csrc/prove.hip, Compiler2).
+//
+// The real Board / Shot constraint systems are 140 / 81 constraint polynomials with ~1100 / ~700 multiplications
+// as trees; after sharing common subexpressions and factoring each gate's selector out of its constraints about half
+// remain, but sharing needs more live values than four, and a register file cannot be indexed dynamically (it turns
+// into scratch memory: see k_expr_eval_regs4).  So:
+//   * four register values r0..r3 used as an evaluation STACK whose depth the compiler tracks: every instruction names
+//     its result register statically, and the interpreter dispatches (a wave-uniform switch, scalar branch) to a body
+//     specialised for that register -- no per-limb selects;
+//   * long-lived values (the folded accumulators, shared subexpressions) live in an LDS slot file
+//     [slot][half][thread] of uint4, conflict-free ds_read/write_b128;
+//   * leaves (column at a rotation, constant, LDS slot) are operands of the instruction that consumes them.
+// Instruction forms: SS r[p] = r[p] op r[p+1];  SL r[p] = r[p] op leaf;  LL r[p] = leafA op leafB;  unary NEG / LOAD /
+// STORE.  op in {ADD, SUB, MUL, RSUB (b - a)}.  Modular-integer VALU work, no MFMA.
+// ---------------------------------------------------------------------------------------------------------------
+struct ExprOp2 {
+    uint8_t code, a_kind, b_kind, pad;
+    int32_t a_idx, b_idx;
+    int16_t a_rot, b_rot;
+};
+static_assert(sizeof(ExprOp2) == 16, "ExprOp2 layout");
+
+static constexpr int kVm2Threads = 128;
+
+template <class P>
+__global__ void __launch_bounds__(kVm2Threads) k_expr_vm2(const ExprOp2* __restrict__ prog, int nops, const uint32_t* const* __restrict__ cols,
+                                                           const size_t* __restrict__ strides, const uint32_t* __restrict__ consts,
+                                                           size_t const_stride, size_t size, uint32_t* __restrict__ out) {
+    extern __shared__ uint4 vm2_lds[];
+    const size_t r = blockIdx.x * (size_t)kVm2Threads + threadIdx.x, v = blockIdx.y;
+    if (r >= size) return;   // size is a multiple of the block size for every domain the prover uses; no barriers below
+    const size_t mask = size - 1;
+    const uint32_t* cv = consts + v * const_stride * 8;
+    const unsigned t = threadIdx.x;
+    Fe<P> r0 = fe_zero<P>(), r1 = r0, r2 = r0, r3 = r0;
+    auto leaf = [&](int kind, int idx, int rot) -> Fe<P> {
+        if (kind == BZH_EXPR_COLUMN) {
+            const size_t row = (r + (size_t)(int64_t)rot) & mask;
+            return fe_load<P>(cols[idx] + (v * strides[idx] + row) * 8);
+        }
+        if (kind == BZH_EXPR_CONST) return fe_load<P>(cv + (size_t)idx * 8);
+        Fe<P> x;   // LDS slot
+        const uint4 lo = vm2_lds[((size_t)idx * 2) * kVm2Threads + t], hi = vm2_lds[((size_t)idx * 2 + 1) * kVm2Threads + t];
+        x.l[0] = lo.x, x.l[1] = lo.y, x.l[2] = lo.z, x.l[3] = lo.w, x.l[4] = hi.x, x.l[5] = hi.y, x.l[6] = hi.z, x.l[7] = hi.w;
+        return x;
+    };
+    auto store = [&](int idx, const Fe<P>& x) {
+        vm2_lds[((size_t)idx * 2) * kVm2Threads + t] = make_uint4(x.l[0], x.l[1], x.l[2], x.l[3]);
+        vm2_lds[((size_t)idx * 2 + 1) * kVm2Threads + t] = make_uint4(x.l[4], x.l[5], x.l[6], x.l[7]);
+    };
+#define VM2_ARITH(OP, A, B) ((OP) == 0 ? fe_add(A, B) : ((OP) == 1 ? fe_sub(A, B) : ((OP) == 2 ? fe_mul(A, B) : fe_sub(B, A))))
+#define VM2_SS(OP, P0, RA, RB) case (0 << 4) | ((OP) << 2) | (P0): RA = VM2_ARITH(OP, RA, RB); break;
+#define VM2_SL(OP, P0, RA)     case (1 << 4) | ((OP) << 2) | (P0): { const Fe<P> b_ = leaf(op.b_kind, op.b_idx, op.b_rot); RA = VM2_ARITH(OP, RA, b_); } break;
+#define VM2_LL(OP, P0, RA)     case (2 << 4) | ((OP) << 2) | (P0): { const Fe<P> a_ = leaf(op.a_kind, op.a_idx, op.a_rot); const Fe<P> b_ = leaf(op.b_kind, op.b_idx, op.b_rot); RA = VM2_ARITH(OP, a_, b_); } break;
+#define VM2_ALLOPS_SS(P0, RA, RB) VM2_SS(0, P0, RA, RB) VM2_SS(1, P0, RA, RB) VM2_SS(2, P0, RA, RB) VM2_SS(3, P0, RA, RB)
+#define VM2_ALLOPS_SL(P0, RA) VM2_SL(0, P0, RA) VM2_SL(1, P0, RA) VM2_SL(2, P0, RA) VM2_SL(3, P0, RA)
+#define VM2_ALLOPS_LL(P0, RA) VM2_LL(0, P0, RA) VM2_LL(1, P0, RA) VM2_LL(2, P0, RA)
+#define VM2_UN(P0, RA)                                                                                   \
+    case (3 << 4) | (0 << 2) | (P0): RA = fe_neg(RA); break;                                              \
+    case (3 << 4) | (1 << 2) | (P0): RA = leaf(op.a_kind, op.a_idx, op.a_rot); break;                     \
+    case (3 << 4) | (2 << 2) | (P0): store(op.a_idx, RA); break;
+    ExprOp2 nxt = prog[0];
+    for (int i = 0; i < nops; i++) {
+        const ExprOp2 op = nxt;       // wave-uniform: scalar loads, scalar branch
+        nxt = prog[i + 1 < nops ? i + 1 : i];   // the next instruction is fetched while this one executes
+        switch (op.code) {
+            VM2_ALLOPS_SS(0, r0, r1) VM2_ALLOPS_SS(1, r1, r2) VM2_ALLOPS_SS(2, r2, r3)
+            VM2_ALLOPS_SL(0, r0) VM2_ALLOPS_SL(1, r1) VM2_ALLOPS_SL(2, r2) VM2_ALLOPS_SL(3, r3)
+            VM2_ALLOPS_LL(0, r0) VM2_ALLOPS_LL(1, r1) VM2_ALLOPS_LL(2, r2) VM2_ALLOPS_LL(3, r3)
+            VM2_UN(0, r0) VM2_UN(1, r1) VM2_UN(2, r2) VM2_UN(3, r3)
+            default: break;
+        }
+    }
+#undef VM2_UN
+#undef VM2_ALLOPS_LL
+#undef VM2_ALLOPS_SL
+#undef VM2_ALLOPS_SS
+#undef VM2_LL
+#undef VM2_SL
+#undef VM2_SS
+#undef VM2_ARITH
+    fe_store(out + (v * size + r) * 8, r0);
+}
+
+// program: ExprOp2[nops] on the device; result in r0; nlds LDS slots (32 bytes per thread each)
+int expr_eval2(bzh_ctx* ctx, int field, const void* d_prog, int nops, const uint32_t* const* d_cols, const size_t* d_strides,
+               const uint32_t* d_consts, size_t const_stride, size_t size, size_t batch, int nlds, uint32_t* d_out) {
+    if (size % kVm2Threads) return BZH_E_ARG;
+    const size_t lds = (size_t)std::max(nlds, 1) * 2 * kVm2Threads * sizeof(uint4);
+    if (lds > 64 * 1024) return BZH_E_RANGE;
+    ScopedTimer t(ctx, BZH_T_POLY);
+    const dim3 grid((unsigned)(size / kVm2Threads), (unsigned)batch), block(kVm2Threads);
+    const ExprOp2* p = (const ExprOp2*)d_prog;
+    switch (field) {
+        case BZH_FIELD_FP:
+            hipLaunchKernelGGL((k_expr_vm2<FpParams>), grid, block, lds, ctx->stream, p, nops, d_cols, d_strides, d_consts, const_stride, size, d_out);
+            break;
+        case BZH_FIELD_FQ:
+            hipLaunchKernelGGL((k_expr_vm2<FqParams>), grid, block, lds, ctx->stream, p, nops, d_cols, d_strides, d_consts, const_stride, size, d_out);
+            break;
+        default: return BZH_E_ARG;
+    }
+    BZH_HIP_TRY(ctx, hipGetLastError());
+    return BZH_OK;
+}
+
 int expr_slots() { return kExprSlots; }
 
 }  // namespace bzh

@@ -160,8 +160,25 @@ struct Program {
 
 struct EPool {
     std::vector<ENode> n;
+    // hash-consing: structurally equal nodes are one node, so that shared subexpressions of the constraint polynomials
+    // (a gate's selector product, x_q - x_p of the addition gates, ...) show up as shared nodes of a DAG
+    struct NodeKey {
+        uint8_t tag;
+        int32_t col, rot, a, b;
+        uint32_t val[8];
+        bool operator<(const NodeKey& o) const { return memcmp(this, &o, sizeof(NodeKey)) < 0; }
+    };
+    std::map<NodeKey, int> interned;
     int push(const ENode& e) {
+        NodeKey k;
+        memset(&k, 0, sizeof(k));
+        k.tag = e.tag;
+        k.col = e.col, k.rot = e.rot, k.a = e.a, k.b = e.b;
+        memcpy(k.val, e.val, 32);
+        auto it = interned.find(k);
+        if (it != interned.end()) return it->second;
         n.push_back(e);
+        interned[k] = (int)n.size() - 1;
         return (int)n.size() - 1;
     }
     template <class F>
@@ -311,6 +328,280 @@ struct Compiler {
     }
 };
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Compiler2: the quotient's program for VM v2 (csrc/exprvm.hip: four stack registers + an LDS slot file).
+//   value = (sum_j term_j y^(N-1-j)) * t_inv, terms in protocol order.  Consecutive terms of the form S * C_j with the
+//   same S (a gate's constraints under its -- compressed -- selector) are folded as
+//       ACC <- ACC y^m + S (C_0 y^(m-1) + ... + C_(m-1))
+//   so the selector product is evaluated and multiplied in once per gate; inside a gate, subexpressions used more than
+//   once are computed once and parked in LDS slots.  The arithmetic is exact field arithmetic: the value, hence every
+//   proof byte, is the same as the plain Horner fold's.
+// ---------------------------------------------------------------------------------------------------------------
+struct ExprOp2 {  // mirrors csrc/exprvm.hip
+    uint8_t code, a_kind, b_kind, pad;
+    int32_t a_idx, b_idx;
+    int16_t a_rot, b_rot;
+};
+enum { BZH_EXPR_LDS = 3 };
+enum { V2_ADD = 0, V2_SUB = 1, V2_MUL = 2, V2_RSUB = 3 };
+enum { V2_SS = 0, V2_SL = 1, V2_LL = 2, V2_UN = 3, V2_NEG = 0, V2_LOAD = 1, V2_STORE = 2 };
+// LDS slots: 0 ACC, 1 IN, then the shared-subexpression slots, spill slots last (allocated only if a program uses them)
+static constexpr int kV2Regs = 4, kV2LdsAcc = 0, kV2LdsInner = 1, kV2LdsCse0 = 2, kV2LdsCseMax = 8, kV2LdsSpills = 2;
+enum { SY_YPOW0 = 4096 /* + m: y^m */ };
+
+struct Program2 {
+    std::vector<ExprOp2> ops;
+    std::vector<ConstEnt> consts;
+    bool ok = true;
+    int nlds = 2;
+};
+
+struct Compiler2 {
+    const EPool& pool;
+    Program2 prog;
+    int depth = 0;                       // registers r0..r(depth-1) hold the evaluation stack
+    std::map<int, int> cse;              // node -> LDS slot holding its value (current scope)
+    std::map<int, int> hoisted;          // node -> registry column holding its precomputed values (proof-independent)
+    std::vector<int> label;              // Sethi-Ullman numbers (leaves 0), memoised per scope
+    int spill_used = 0, cse_slots = 2, max_lds = kV2LdsInner;   // measured (k = 14, batch 16): 2 shared-subexpression slots beat 0, 4, 6, 8 -- occupancy matters more than the last 40 multiplications
+    explicit Compiler2(const EPool& p) : pool(p), label(p.n.size(), -1) {
+        if (const char* e = getenv("BZH_VM2_CSE")) cse_slots = std::max(0, std::min(kV2LdsCseMax, atoi(e)));
+    }
+    int nlds() const { return max_lds + 1; }
+
+    struct Leaf {
+        int kind, idx, rot;
+    };
+    int const_index(int sym, const uint32_t* val) {
+        for (size_t i = 0; i < prog.consts.size(); i++) {
+            const ConstEnt& c = prog.consts[i];
+            if (sym >= 0 ? c.sym == sym : (c.sym < 0 && !memcmp(c.val, val, 32))) return (int)i;
+        }
+        ConstEnt c;
+        c.sym = sym;
+        if (sym < 0) memcpy(c.val, val, 32);
+        prog.consts.push_back(c);
+        return (int)prog.consts.size() - 1;
+    }
+    bool is_leaf(int i) const {
+        const ENode& e = pool.n[i];
+        return e.tag == EX_CONST || e.tag == EX_SYMBOL || e.tag == EX_QUERY || cse.count(i) || hoisted.count(i);
+    }
+    Leaf leaf_of(int i) {
+        auto ih = hoisted.find(i);
+        if (ih != hoisted.end()) return {BZH_EXPR_COLUMN, ih->second, 0};
+        auto it = cse.find(i);
+        if (it != cse.end()) return {BZH_EXPR_LDS, it->second, 0};
+        const ENode& e = pool.n[i];
+        if (e.tag == EX_CONST) return {BZH_EXPR_CONST, const_index(-1, e.val), 0};
+        if (e.tag == EX_SYMBOL) return {BZH_EXPR_CONST, const_index(e.col, nullptr), 0};
+        if (e.rot < -32768 || e.rot > 32767) prog.ok = false;
+        return {BZH_EXPR_COLUMN, e.col, e.rot};
+    }
+    int label_of(int i) {
+        if (is_leaf(i)) return 0;
+        if (label[i] >= 0) return label[i];
+        const ENode& e = pool.n[i];
+        int d;
+        if (e.tag == EX_NEG || e.tag == EX_SCALE) d = std::max(1, label_of(e.a));
+        else {
+            const int la = label_of(e.a), lb = label_of(e.b);
+            d = (la == 0 && lb == 0) ? 1 : (la == lb ? la + 1 : std::max(la, lb));
+        }
+        return label[i] = d;
+    }
+    void op(int form, int o, int pos, Leaf a = {0, 0, 0}, Leaf b = {0, 0, 0}) {
+        if (pos < 0 || pos >= kV2Regs) prog.ok = false;
+        ExprOp2 x;
+        x.code = (uint8_t)((form << 4) | (o << 2) | (pos & 3));
+        x.a_kind = (uint8_t)a.kind, x.b_kind = (uint8_t)b.kind, x.pad = 0;
+        x.a_idx = a.idx, x.b_idx = b.idx;
+        x.a_rot = (int16_t)a.rot, x.b_rot = (int16_t)b.rot;
+        prog.ops.push_back(x);
+    }
+    // a - b is add(a, neg(b)) in the pool: peel the negation so that it costs no instruction
+    bool is_plain_neg(int i) const { return pool.n[i].tag == EX_NEG && !cse.count(i); }
+
+    // emit node i: its value ends up in a new top-of-stack register
+    void emit(int i) {
+        if (is_leaf(i)) {
+            op(V2_UN, V2_LOAD, depth, leaf_of(i));
+            depth++;
+            return;
+        }
+        const ENode& e = pool.n[i];
+        if (e.tag == EX_NEG) {
+            emit(e.a);
+            op(V2_UN, V2_NEG, depth - 1);
+        } else if (e.tag == EX_SCALE) {
+            const Leaf c{BZH_EXPR_CONST, const_index(-1, e.val), 0};
+            if (is_leaf(e.a)) {
+                op(V2_LL, V2_MUL, depth, leaf_of(e.a), c);
+                depth++;
+            } else {
+                emit(e.a);
+                op(V2_SL, V2_MUL, depth - 1, Leaf{0, 0, 0}, c);
+            }
+        } else {
+            int a = e.a, b = e.b, o = e.tag == EX_ADD ? V2_ADD : V2_MUL;
+            if (e.tag == EX_ADD) {   // a + (-b') = a - b' ; (-a') + b = b - a'
+                if (is_plain_neg(b)) b = pool.n[b].a, o = V2_SUB;
+                else if (is_plain_neg(a)) {
+                    const int t = pool.n[a].a;
+                    a = b, b = t, o = V2_SUB;
+                }
+            }
+            binary(o, a, b);
+        }
+        park(i);
+    }
+    void binary(int o, int a, int b) {
+        const bool la = is_leaf(a), lb = is_leaf(b);
+        const int rev = o == V2_SUB ? V2_RSUB : o;   // operands swapped
+        if (la && lb) {
+            op(V2_LL, o, depth, leaf_of(a), leaf_of(b));
+            depth++;
+        } else if (lb) {
+            emit(a);
+            op(V2_SL, o, depth - 1, Leaf{0, 0, 0}, leaf_of(b));
+        } else if (la) {
+            emit(b);
+            op(V2_SL, rev, depth - 1, Leaf{0, 0, 0}, leaf_of(a));
+        } else {
+            const int na = label_of(a), nb = label_of(b);
+            const bool a_first = na >= nb;
+            const int first = a_first ? a : b, second = a_first ? b : a;
+            emit(first);
+            if (depth + std::max(1, label_of(second)) > kV2Regs) {
+                // not enough registers for the other side: park this one in a spill slot and use it as a leaf
+                if (spill_used >= kV2LdsSpills) {
+                    prog.ok = false;
+                    return;
+                }
+                const int sl = kV2LdsCse0 + cse_slots + spill_used++;
+                max_lds = std::max(max_lds, sl);
+                op(V2_UN, V2_STORE, depth - 1, Leaf{BZH_EXPR_LDS, sl, 0});
+                depth--;
+                emit(second);
+                op(V2_SL, a_first ? rev : o, depth - 1, Leaf{0, 0, 0}, Leaf{BZH_EXPR_LDS, sl, 0});
+                spill_used--;
+            } else {
+                emit(second);
+                op(V2_SS, a_first ? o : rev, depth - 2);
+                depth--;
+            }
+        }
+    }
+    // shared subexpression bookkeeping for the current scope
+    std::map<int, int> want;   // node -> LDS slot it is to be parked in after its first evaluation
+    void park(int i) {
+        auto it = want.find(i);
+        if (it == want.end() || cse.count(i)) return;
+        op(V2_UN, V2_STORE, depth - 1, Leaf{BZH_EXPR_LDS, it->second, 0});
+        cse[i] = it->second;
+        std::fill(label.begin(), label.end(), -1);   // nodes above it are cheaper to reach now
+    }
+    void count_uses(int i, std::map<int, int>& uses, std::map<int, int>& weight) {
+        const ENode& e = pool.n[i];
+        if (e.tag == EX_CONST || e.tag == EX_SYMBOL || e.tag == EX_QUERY || hoisted.count(i)) return;
+        if (uses[i]++) return;
+        int w = 1;
+        if (e.a >= 0) {
+            count_uses(e.a, uses, weight);
+            w += weight.count(e.a) ? weight[e.a] : 0;
+        }
+        if (e.b >= 0) {
+            count_uses(e.b, uses, weight);
+            w += weight.count(e.b) ? weight[e.b] : 0;
+        }
+        weight[i] = w;
+    }
+    void open_scope(const std::vector<int>& roots) {
+        cse.clear();
+        want.clear();
+        std::fill(label.begin(), label.end(), -1);
+        std::map<int, int> uses, weight;
+        for (int r : roots) count_uses(r, uses, weight);
+        std::vector<std::pair<long, int>> cand;
+        for (auto& kv : uses) {
+            if (kv.second >= 2) cand.push_back({-(long)(kv.second - 1) * weight[kv.first], kv.first});
+        }
+        std::sort(cand.begin(), cand.end());
+        for (size_t k = 0; k < cand.size() && k < (size_t)cse_slots; k++) {
+            want[cand[k].second] = kV2LdsCse0 + (int)k;
+            max_lds = std::max(max_lds, kV2LdsCse0 + (int)k);
+        }
+    }
+
+    // the whole quotient: terms in protocol order, y = symbol SY_Y, result (times t_inv) in r0
+    void quotient(const std::vector<int>& terms, int tinv_node) {
+        struct Group {
+            int s;                  // shared left factor (-1: none)
+            std::vector<int> c;     // the other factors, or the whole terms
+        };
+        std::vector<Group> groups;
+        for (int t : terms) {
+            const ENode& e = pool.n[t];
+            const int s = (e.tag == EX_MUL) ? e.a : -1;
+            if (s >= 0 && !groups.empty() && groups.back().s == s) groups.back().c.push_back(e.b);
+            else groups.push_back(Group{s, {s >= 0 ? e.b : t}});
+        }
+        const Leaf y{BZH_EXPR_CONST, const_index(SY_Y, nullptr), 0};
+        const Leaf acc{BZH_EXPR_LDS, kV2LdsAcc, 0}, inner{BZH_EXPR_LDS, kV2LdsInner, 0};
+        bool first_group = true;
+        for (auto& g : groups) {
+            std::vector<int> roots = g.c;
+            if (g.s >= 0) roots.push_back(g.s);
+            open_scope(roots);
+            const size_t m = g.c.size();
+            if (m > 64) prog.ok = false;   // y^m symbols are provided up to 64
+            for (size_t j = 0; j < m; j++) {
+                depth = 0;
+                if (j == 0) {
+                    emit(g.c[0]);
+                } else if (label_of(g.c[j]) < kV2Regs) {
+                    op(V2_LL, V2_MUL, 0, inner, y);          // r0 = IN y
+                    depth = 1;
+                    emit(g.c[j]);                            // r1 = C_j
+                    op(V2_SS, V2_ADD, 0);
+                    depth = 1;
+                } else {
+                    emit(g.c[j]);                            // r0 = C_j (needs every register)
+                    op(V2_LL, V2_MUL, 1, inner, y);          // r1 = IN y
+                    op(V2_SS, V2_ADD, 0);
+                }
+                if (j + 1 < m) op(V2_UN, V2_STORE, 0, inner);
+            }
+            // r0 = sum_j C_j y^(m-1-j); times the shared factor
+            if (g.s >= 0) {
+                if (is_leaf(g.s)) {
+                    op(V2_SL, V2_MUL, 0, Leaf{0, 0, 0}, leaf_of(g.s));
+                } else if (label_of(g.s) < kV2Regs) {
+                    depth = 1;
+                    emit(g.s);
+                    op(V2_SS, V2_MUL, 0);
+                } else {
+                    op(V2_UN, V2_STORE, 0, inner);
+                    depth = 0;
+                    emit(g.s);
+                    op(V2_SL, V2_MUL, 0, Leaf{0, 0, 0}, inner);
+                }
+            }
+            if (!first_group) {                              // ACC = ACC y^m + r0
+                const Leaf ym{BZH_EXPR_CONST, const_index(m == 1 ? SY_Y : SY_YPOW0 + (int)m, nullptr), 0};
+                op(V2_LL, V2_MUL, 1, acc, ym);
+                op(V2_SS, V2_ADD, 0);
+            }
+            op(V2_UN, V2_STORE, 0, acc);
+            first_group = false;
+        }
+        cse.clear();
+        want.clear();
+        op(V2_SL, V2_MUL, 0, Leaf{0, 0, 0}, leaf_of(tinv_node));
+    }
+};
+
 // column registry of one batched evaluation: (device pointer, elements between consecutive proofs; 0 = shared)
 struct Cols {
     std::vector<const uint32_t*> ptr;
@@ -436,6 +727,10 @@ struct bzh_pk {
     uint32_t *fixed = nullptr, *fixed_polys = nullptr, *fixed_cosets = nullptr, *sigma = nullptr, *ident = nullptr, *sigma_polys = nullptr,
              *sigma_cosets = nullptr, *l0 = nullptr, *l_last = nullptr, *l_blind = nullptr, *x_col = nullptr, *tinv_col = nullptr;
     std::map<uint64_t, bzh::Program> progs;
+    std::map<uint64_t, bzh::Program2> progs2;   // VM v2 programs (the quotient)
+    // proof-independent subexpressions of the quotient (selector products ...) evaluated once on the extended coset
+    uint32_t* hoist = nullptr;
+    size_t hoist_cols = 0;
     // multiopen structure: rotation sets and the commitments grouped under each
     std::vector<std::vector<int>> rot_sets;
     std::vector<std::vector<uint64_t>> groups;
@@ -1115,6 +1410,128 @@ struct Prover {
                          per_proof ? nc : 0, size, pg.result_slot, B, nslots, d_out);
     }
 
+    // the quotient through VM v2: `build` returns the terms in protocol order and sets *tinv to the 1 / (X^n - 1) column node.
+    // Returns BZH_E_RANGE when the program does not fit VM v2 (the caller falls back to the plain fold through `run`).
+    template <class BuildTerms>
+    int run2(uint64_t pkey, BuildTerms build, const Cols& reg, size_t size, uint32_t* d_out) {
+        if (size % 128) return BZH_E_RANGE;   // VM v2 runs whole 128-row workgroups (tiny test domains take the plain fold)
+        auto it = pk.progs2.find(pkey);
+        if (it == pk.progs2.end()) {
+            EPool ep;
+            int tinv = -1;
+            const std::vector<int> terms = build(ep, &tinv);
+            Compiler2 cc(ep);
+            // Hoisting: maximal subexpressions over proof-independent columns (stride 0: fixed / permutation / Lagrange
+            // columns of the key) and literal constants that contain a multiplication -- the compressed-selector products
+            // q prod (j - q) of every gate -- are evaluated ONCE on the extended coset into columns owned by the key.
+            if (!pk.hoist && !getenv("BZH_NO_HOIST")) {
+                const size_t nn = ep.n.size();
+                std::vector<char> indep(nn, 0);
+                std::vector<int> muls(nn, 0);
+                for (size_t i = 0; i < nn; i++) {   // children precede parents in the pool
+                    const ENode& e = ep.n[i];
+                    if (e.tag == EX_CONST) indep[i] = 1;
+                    else if (e.tag == EX_SYMBOL) indep[i] = 0;
+                    else if (e.tag == EX_QUERY) indep[i] = reg.stride[e.col] == 0;
+                    else if (e.tag == EX_NEG) indep[i] = indep[e.a], muls[i] = muls[e.a];
+                    else if (e.tag == EX_SCALE) indep[i] = indep[e.a], muls[i] = muls[e.a] + 1;
+                    else indep[i] = indep[e.a] && indep[e.b], muls[i] = muls[e.a] + muls[e.b] + (e.tag == EX_MUL);
+                }
+                std::vector<int> picked;
+                std::vector<char> seen(nn, 0);
+                std::vector<int> stack(terms.begin(), terms.end());
+                while (!stack.empty()) {
+                    const int i = stack.back();
+                    stack.pop_back();
+                    if (seen[i]) continue;
+                    seen[i] = 1;
+                    const ENode& e = ep.n[i];
+                    if (e.tag == EX_CONST || e.tag == EX_SYMBOL || e.tag == EX_QUERY) continue;
+                    if (indep[i] && muls[i] >= 1) {
+                        picked.push_back(i);
+                        continue;
+                    }
+                    if (e.a >= 0) stack.push_back(e.a);
+                    if (e.b >= 0) stack.push_back(e.b);
+                }
+                std::sort(picked.begin(), picked.end());
+                if (!picked.empty() && picked.size() <= 512) {
+                    uint32_t* buf = nullptr;
+                    if (hipMalloc((void**)&buf, picked.size() * size * 32) == hipSuccess) {
+                        pk.hoist = buf;
+                        pk.hoist_cols = picked.size();
+                        const size_t ncols = reg.ptr.size();
+                        for (size_t hi = 0; hi < picked.size(); hi++) {
+                            Compiler c1(ep);
+                            c1.prog.result_slot = c1.emit(picked[hi]);
+                            if (c1.overflow) return BZH_E_RANGE;
+                            const Program& pg = c1.prog;
+                            std::vector<uint32_t> cv(std::max<size_t>(pg.consts.size(), 1) * 8);
+                            for (size_t i = 0; i < pg.consts.size(); i++) memcpy(&cv[i * 8], pg.consts[i].val, 32);
+                            char* stage = (char*)pk.arena.alloc(cv.size() * 4 + pg.ops.size() * sizeof(bzh_expr_op) + ncols * 16 + 1024);
+                            if (!stage) return BZH_E_OOM;
+                            uint32_t* d_consts = (uint32_t*)stage;
+                            char* d_prog = stage + ((cv.size() * 4 + 255) & ~(size_t)255);
+                            char* d_ptrs = d_prog + ((pg.ops.size() * sizeof(bzh_expr_op) + 255) & ~(size_t)255);
+                            char* d_strides = d_ptrs + ((ncols * 8 + 255) & ~(size_t)255);
+                            PV_TRY(h2d_small(ctx, d_consts, cv.data(), cv.size() * 4));
+                            PV_TRY(h2d_small(ctx, d_prog, pg.ops.data(), pg.ops.size() * sizeof(bzh_expr_op)));
+                            PV_TRY(h2d_small(ctx, d_ptrs, reg.ptr.data(), ncols * 8));
+                            PV_TRY(h2d_small(ctx, d_strides, reg.stride.data(), ncols * 8));
+                            int nslots = pg.result_slot + 1;
+                            for (auto& o : pg.ops) nslots = std::max(nslots, (int)o.dst + 1);
+                            PV_TRY(expr_eval(ctx, field, d_prog, (int)pg.ops.size(), (const uint32_t* const*)d_ptrs, (const size_t*)d_strides,
+                                             d_consts, 0, size, pg.result_slot, 1, nslots, pk.hoist + hi * size * 8));
+                            cc.hoisted[picked[hi]] = (int)(ncols + hi);
+                        }
+                    }
+                }
+            }
+            cc.quotient(terms, tinv);
+            cc.prog.nlds = cc.nlds();
+            if (getenv("BZH_PROVE_TRACE")) {
+                size_t muls = 0;
+                for (auto& o : cc.prog.ops) muls += ((o.code >> 4) < 3 && ((o.code >> 2) & 3) == V2_MUL);
+                fprintf(stderr, "[bzh_prove_batch] quotient program (VM v2): %zu terms, %zu ops, %zu multiplications, %d LDS slots, %zu constants, %zu hoisted columns%s\n",
+                        terms.size(), cc.prog.ops.size(), muls, cc.prog.nlds, cc.prog.consts.size(), pk.hoist_cols, cc.prog.ok ? "" : " -- NOT usable");
+            }
+            it = pk.progs2.insert({pkey, std::move(cc.prog)}).first;
+        }
+        const Program2& pg = it->second;
+        if (!pg.ok) return BZH_E_RANGE;
+        const size_t nc = pg.consts.size(), ncols = reg.ptr.size() + pk.hoist_cols;
+        std::vector<const uint32_t*> ptrs(reg.ptr);
+        std::vector<size_t> strides(reg.stride);
+        for (size_t hi = 0; hi < pk.hoist_cols; hi++) {
+            ptrs.push_back(pk.hoist + hi * size * 8);
+            strides.push_back(0);
+        }
+        std::vector<uint32_t> cv(std::max<size_t>(B * nc, 1) * 8);
+        for (size_t b = 0; b < B; b++)
+            for (size_t i = 0; i < nc; i++) {
+                const ConstEnt& c = pg.consts[i];
+                if (c.sym >= 0) {
+                    auto f = env[b].find(c.sym);
+                    if (f == env[b].end()) return BZH_E_ARG;
+                    memcpy(&cv[(b * nc + i) * 8], f->second.l, 32);
+                } else {
+                    memcpy(&cv[(b * nc + i) * 8], c.val, 32);
+                }
+            }
+        char* stage = (char*)pk.arena.alloc(cv.size() * 4 + pg.ops.size() * sizeof(ExprOp2) + ncols * 16 + 1024);
+        if (!stage) return BZH_E_OOM;
+        uint32_t* d_consts = (uint32_t*)stage;
+        char* d_prog = stage + ((cv.size() * 4 + 255) & ~(size_t)255);
+        char* d_ptrs = d_prog + ((pg.ops.size() * sizeof(ExprOp2) + 255) & ~(size_t)255);
+        char* d_strides = d_ptrs + ((ncols * 8 + 255) & ~(size_t)255);
+        PV_TRY(h2d_small(ctx, d_consts, cv.data(), cv.size() * 4));
+        PV_TRY(h2d_small(ctx, d_prog, pg.ops.data(), pg.ops.size() * sizeof(ExprOp2)));
+        PV_TRY(h2d_small(ctx, d_ptrs, ptrs.data(), ncols * 8));
+        PV_TRY(h2d_small(ctx, d_strides, strides.data(), ncols * 8));
+        return expr_eval2(ctx, field, d_prog, (int)pg.ops.size(), (const uint32_t* const*)d_ptrs, (const size_t*)d_strides, d_consts, nc, size, B,
+                          pg.nlds, d_out);
+    }
+
     int prove(const uint32_t* d_advice_in, const uint64_t* instances, size_t inst_rows, uint8_t* proofs, size_t proof_stride,
               size_t* proof_lens);
 };
@@ -1379,6 +1796,13 @@ int Prover<C>::prove(const uint32_t* d_advice_in, const uint64_t* instances, siz
     for (size_t b = 0; b < B; b++) {
         bzh_transcript_write_point(T[b], C::id, &xy[b * 8]);
         env[b][SY_Y] = squeeze(b);
+        {
+            Fe<SF> yp = env[b][SY_Y];
+            for (int mpow = 2; mpow <= 64; mpow++) {   // y^m for the gate-factored fold (m = constraints per gate)
+                yp = fe_mul(yp, env[b][SY_Y]);
+                env[b][SY_YPOW0 + mpow] = yp;
+            }
+        }
         Fe<SF> bd = env[b][SY_BETA];
         for (size_t gj = 0; gj < m; gj++) {
             env[b][SY_BD0 + (int)gj] = bd;
@@ -1407,7 +1831,7 @@ int Prover<C>::prove(const uint32_t* d_advice_in, const uint64_t* instances, siz
         reg.add(key(K_MISC, M_X), pk.x_col, 0);
         reg.add(key(K_MISC, M_TINV), pk.tinv_col, 0);
         const int e = (int)ext;
-        PV_TRY(run(key(40, 0), [&](EPool& ep) {
+        auto build_terms = [&](EPool& ep, int* tinv) -> std::vector<int> {
             auto Q = [&](uint64_t kk, int rot = 0) { return ep.query(reg.at(kk), rot); };
             auto col_q = [&](std::pair<int, int> col) {
                 return Q(key(col.first == CX_ADVICE ? K_ADV : (col.first == CX_FIXED ? K_FIX : K_INST), col.second));
@@ -1453,8 +1877,19 @@ int Prover<C>::prove(const uint32_t* d_advice_in, const uint64_t* instances, siz
                 terms.push_back(ep.mul(l0(), ep.sub(a_p(), s_p())));
                 terms.push_back(ep.mul(ep.mul(active(), ep.sub(a_p(), s_p())), ep.sub(a_p(), Q(key(K_LA, i), -e))));
             }
-            return ep.mul(ep.horner(terms, ep.sym(SY_Y)), Q(key(K_MISC, M_TINV)));
-        }, reg, en, h));
+            *tinv = Q(key(K_MISC, M_TINV));
+            return terms;
+        };
+        // VM v2 (gate-factored fold, shared subexpressions in LDS); the plain Horner fold through VM v1 if it does not fit
+        int qrc = getenv("BZH_QUOTIENT_V1") ? BZH_E_RANGE : run2(key(41, 0), build_terms, reg, en, h);
+        if (qrc == BZH_E_RANGE) {
+            qrc = run(key(40, 0), [&](EPool& ep) {
+                int tinv = -1;
+                const std::vector<int> terms = build_terms(ep, &tinv);
+                return ep.mul(ep.horner(terms, ep.sym(SY_Y)), tinv);
+            }, reg, en, h);
+        }
+        PV_TRY(qrc);
     }
     PV_TRY(ntt_run(ctx, field, h, pk.ek, B, pk.eomega, pk.zeta, 1, BZH_FORM_MONTGOMERY));
     uint32_t* d_flag = (uint32_t*)pk.arena.alloc(256);
@@ -2293,6 +2728,7 @@ int bzh_pk_free(bzh_ctx* ctx, bzh_pk* pk) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (pk->dev) (void)hipFree(pk->dev);
+    if (pk->hoist) (void)hipFree(pk->hoist);
     pk->arena.release();
     delete pk;
     return BZH_OK;

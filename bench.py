@@ -336,6 +336,9 @@ class Workload:
             self.units_per_step = nb + ns                 # whole-job units: the fixed batch (every rank adds its share)
             self.local_units_per_step = len(mine_b) + len(mine_s)
             self.fixed_total = True
+            stride = max(p.proof_stride for p in self.provers)     # one record format for both circuits
+            for p in self.provers:
+                p.proof_stride = stride
             self.records = lambda: torch.cat([p.proof_records() for p in self.provers if p.has_records()], dim=0)
             self.record_counts = lambda: [len(shard_range(nb, r, world)) + len(shard_range(ns, r, world)) for r in range(world)]
             self.verify_last = lambda: all(p.verify_last() for p in self.provers)
