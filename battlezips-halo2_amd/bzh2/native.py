@@ -20,6 +20,7 @@ def _bind():
         return L
     L.bzh_pk_create.argtypes = [_VP, _VP, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(_VP)]
     L.bzh_pk_free.argtypes = [_VP, _VP]
+    L.bzh_pk_set_lagrange.argtypes = [_VP, _VP]
     L.bzh_pk_info.argtypes = [_VP, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_uint32),
                               ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]
     L.bzh_verify_batch.argtypes = [_VP, _VP, ctypes.c_size_t, _VP, ctypes.c_size_t, _VP, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t), _VP,
@@ -33,13 +34,23 @@ def _bind():
 class NativeProvingKey:
     """keygen_pk on the device.  g: the n SRS points, w / u: Params.w / Params.u (affine canonical int pairs)."""
 
-    def __init__(self, ctx: Context, circuit: Circuit, curve: int, g, w, u, vk_repr: int = 0x1234, window_bits: int = 0):
+    def __init__(self, ctx: Context, circuit: Circuit, curve: int, g=None, w=None, u=None, vk_repr: int = 0x1234, window_bits: int = 0,
+                 params=None):
+        """SRS either as explicit points (g, w, u) or as a bzh2.params.Params (Params::new(k): its tables are used as they
+        are, and commitments the upstream prover makes in the Lagrange basis are made in it)."""
         self.ctx, self.c, self.curve = ctx, circuit, curve
         self.field = CURVE_SCALAR_FIELD[curve]
         self.p = MODULI[self.field]
-        tbl = np.stack([np.concatenate([int_to_limbs(pt[0]), int_to_limbs(pt[1])]) for pt in list(g) + [u, w]])
-        self.bases: Bases = ctx.upload_bases(curve, tbl).precompute(window_bits)
-        self._g0_u_w = np.ascontiguousarray(np.stack([tbl[0], tbl[-2], tbl[-1]]))
+        self._own_bases = params is None
+        if params is None:
+            tbl = np.stack([np.concatenate([int_to_limbs(pt[0]), int_to_limbs(pt[1])]) for pt in list(g) + [u, w]])
+            self.bases: Bases = ctx.upload_bases(curve, tbl).precompute(window_bits)
+            self._g0_u_w = np.ascontiguousarray(np.stack([tbl[0], tbl[-2], tbl[-1]]))
+        else:
+            self.bases = params.bases
+            gp, _, wp, up, _ = params.points(want_lagrange=False)
+            self._g0_u_w = np.ascontiguousarray(np.stack([gp[0], np.concatenate([int_to_limbs(up[0]), int_to_limbs(up[1])]),
+                                                          np.concatenate([int_to_limbs(wp[0]), int_to_limbs(wp[1])])]))
         # a circuit built by the C++ front end (bzh2.circuits.CircuitLayout.blob()) arrives already serialised
         blob = bytes(circuit) if isinstance(circuit, (bytes, bytearray)) else serialize_circuit(circuit, self.p, vk_repr)
         L = _bind()
@@ -50,12 +61,20 @@ class NativeProvingKey:
         na, nr, ur = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32()
         ctx._check(L.bzh_pk_info(h, ctypes.byref(rb), ctypes.byref(mp), ctypes.byref(na), ctypes.byref(nr), ctypes.byref(ur)), "bzh_pk_info")
         self.rng_bytes, self.max_proof_bytes, self.num_advice, self.n, self.usable_rows = rb.value, mp.value, na.value, nr.value, ur.value
+        if params is not None:
+            self.set_lagrange(params.bases_lagrange)
+
+    def set_lagrange(self, bases_lagrange):
+        """Params::commit_lagrange for the columns upstream commits in the Lagrange basis (None: back to coefficients)."""
+        self.ctx._check(_bind().bzh_pk_set_lagrange(self.handle, bases_lagrange.handle if bases_lagrange is not None else None),
+                        "bzh_pk_set_lagrange")
 
     def close(self):
         if self.handle is not None:
             _bind().bzh_pk_free(self.ctx.handle, self.handle)
             self.handle = None
-            self.bases.free()
+            if self._own_bases:
+                self.bases.free()
 
     def _instances(self, instances):
         B = len(instances)

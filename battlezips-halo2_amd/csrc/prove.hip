@@ -715,6 +715,7 @@ struct bzh_pk {
     size_t usable = 0;
     uint64_t vk_repr[4] = {0};
     const bzh_bases* srs = nullptr;
+    const bzh_bases* srs_lagrange = nullptr;   // (g_lagrange | u | w): Params::commit_lagrange for the columns upstream commits in that basis
     std::vector<bzh::CNode> cx;
     std::vector<int> gates;
     std::vector<std::pair<int, int>> perm_columns;  // (kind tag CX_*, index)
@@ -1317,7 +1318,11 @@ struct Prover {
         return ntt_run(ctx, field, dst, pk.ek, count, pk.eomega, pk.zeta, 0, BZH_FORM_MONTGOMERY);
     }
     // Params::commit for `count` polynomials (rows of `pitch` elements): affine canonical points out
-    int commit(const uint32_t* polys, size_t pitch, size_t count, const std::vector<Fe<SF>>& blinds, std::vector<uint64_t>& xy) {
+    // (lagrange: the rows are evaluations over the domain and the bases g_lagrange -- Params::commit_lagrange; the group
+    // element is the same as committing the interpolated coefficients to g, but witness columns are sparse and small in
+    // this basis, so most window digits are zero and cost the MSM nothing)
+    int commit(const uint32_t* polys, size_t pitch, size_t count, const std::vector<Fe<SF>>& blinds, std::vector<uint64_t>& xy,
+               bool lagrange = false) {
         xy.assign(count * 8, 0);
         if (!count) return BZH_OK;
         uint32_t* sc = dalloc(count * (n + 2));
@@ -1328,7 +1333,7 @@ struct Prover {
         PV_TRY(copy2d(sc, n + 2, polys, pitch, n, count));
         PV_TRY(upload(bl, blinds.data(), count));
         PV_TRY(copy2d(sc + (n + 1) * 8, n + 2, bl, 1, 1, count));
-        PV_TRY(msm_run(ctx, pk.srs, sc, n + 2, count, BZH_FORM_MONTGOMERY, d_out));
+        PV_TRY(msm_run(ctx, lagrange ? pk.srs_lagrange : pk.srs, sc, n + 2, count, BZH_FORM_MONTGOMERY, d_out));
         std::vector<uint64_t> jac(count * 12);
         PV_TRY(d2h_async(ctx, jac.data(), d_out, count * 96));
         PV_TRY(d2h_finish(ctx));
@@ -1566,7 +1571,8 @@ int Prover<C>::prove(const uint32_t* d_advice_in, const uint64_t* instances, siz
         }
         PV_TRY(to_coeff(inst_polys, inst, B * ni));
         blinds.assign(B * ni, fe_one<SF>());
-        PV_TRY(commit(inst_polys, n, B * ni, blinds, xy));
+        if (pk.srs_lagrange) PV_TRY(commit(inst, n, B * ni, blinds, xy, true));
+        else PV_TRY(commit(inst_polys, n, B * ni, blinds, xy));
         for (size_t b = 0; b < B; b++)
             for (int i = 0; i < ni; i++) bzh_transcript_common_point(T[b], &xy[(b * ni + i) * 8]);
     }
@@ -1587,7 +1593,8 @@ int Prover<C>::prove(const uint32_t* d_advice_in, const uint64_t* instances, siz
     for (size_t b = 0; b < B; b++)
         for (int i = 0; i < na; i++) adv_blinds[b * na + i] = draw(b);
     PV_TRY(to_coeff(adv_polys, adv, B * na));
-    PV_TRY(commit(adv_polys, n, B * na, adv_blinds, xy));
+    if (pk.srs_lagrange) PV_TRY(commit(adv, n, B * na, adv_blinds, xy, true));
+    else PV_TRY(commit(adv_polys, n, B * na, adv_blinds, xy));
     for (size_t b = 0; b < B; b++) {
         for (int i = 0; i < na; i++) bzh_transcript_write_point(T[b], C::id, &xy[(b * na + i) * 8]);
         env[b][SY_THETA] = squeeze(b);
@@ -1684,7 +1691,8 @@ int Prover<C>::prove(const uint32_t* d_advice_in, const uint64_t* instances, siz
             d.blinds[2 * b + 1] = draw(b);
         }
         PV_TRY(to_coeff(d.polys, d.as, B * 2));
-        PV_TRY(commit(d.polys, n, B * 2, d.blinds, xy));
+        if (pk.srs_lagrange) PV_TRY(commit(d.as, n, B * 2, d.blinds, xy, true));
+        else PV_TRY(commit(d.polys, n, B * 2, d.blinds, xy));
         for (size_t b = 0; b < B; b++) {
             bzh_transcript_write_point(T[b], C::id, &xy[(2 * b) * 8]);
             bzh_transcript_write_point(T[b], C::id, &xy[(2 * b + 1) * 8]);
@@ -1767,7 +1775,8 @@ int Prover<C>::prove(const uint32_t* d_advice_in, const uint64_t* instances, siz
     }
     if (nz) {
         PV_TRY(to_coeff(z_polys, zs, B * nz));
-        PV_TRY(commit(z_polys, n, B * nz, z_blinds, xy));
+        if (pk.srs_lagrange) PV_TRY(commit(zs, n, B * nz, z_blinds, xy, true));
+        else PV_TRY(commit(z_polys, n, B * nz, z_blinds, xy));
         for (size_t b = 0; b < B; b++)
             for (int i = 0; i < nz; i++) bzh_transcript_write_point(T[b], C::id, &xy[(b * nz + i) * 8]);
         mark(" gp:commit");
@@ -2731,6 +2740,15 @@ int bzh_pk_free(bzh_ctx* ctx, bzh_pk* pk) {
     if (pk->hoist) (void)hipFree(pk->hoist);
     pk->arena.release();
     delete pk;
+    return BZH_OK;
+}
+
+int bzh_pk_set_lagrange(bzh_pk* pk, const bzh_bases* g_lagrange) {
+    if (!pk) return BZH_E_ARG;
+    if (g_lagrange && (g_lagrange->n != pk->n + 2 || g_lagrange->curve != pk->curve || g_lagrange->device != pk->device || !g_lagrange->pre_c))
+        return BZH_E_ARG;
+    std::lock_guard<std::mutex> lk(pk->mu);
+    pk->srs_lagrange = g_lagrange;
     return BZH_OK;
 }
 

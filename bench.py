@@ -186,8 +186,10 @@ class ProofRunner:
                              % (kind.capitalize(), kind, len(d["gates"]), d["num_polys"], d["num_advice"], d["num_fixed"],
                                 d["num_fixed"] - 10, d["degree"], len(d["permutation"]), len(d["regions"]), d["rows_used"], k))
         n = 1 << k
-        as_pt = lambda a: (bzh2.limbs_to_int(a[:4]), bzh2.limbs_to_int(a[4:]))
-        g = [as_pt(a) for a in make_bases(ctx, bzh2.CURVE_VESTA, n + 2, 4242 + k)]   # same SRS on every rank
+        # the reference's own SRS: Params::<vesta::Affine>::new(k) (benches/shot.rs:58, benches/board.rs:51) -- hash-to-curve
+        # generators, g_lagrange by a device group FFT, cached on disk; one pair of window tables shared by every worker
+        from bzh2 import params as Pm
+        self.params = Pm.Params(first_ctx if first_ctx is not None else ctx, k, window_bits=window_bits)
         rng = random.Random(seed)
         self.pool = []
         for _ in range(self.POOL):
@@ -205,7 +207,9 @@ class ProofRunner:
                 wctx = bzh2.Context(device.index or 0, stream=st.cuda_stream)
             self.streams.append(st)
             self.ctxs.append(wctx)
-            self.pks.append(N.NativeProvingKey(wctx, blob, bzh2.CURVE_VESTA, g[:n], g[n + 1], g[n], window_bits=window_bits))
+            self.pks.append(N.NativeProvingKey(wctx, blob, bzh2.CURVE_VESTA, params=self.params))
+            if os.environ.get("BZH_BENCH_COEFF_COMMITS"):   # experiment: coefficient-basis commitments everywhere
+                self.pks[-1].set_lagrange(None)
             self.adv.append(torch.zeros((batch, self.layout.num_advice, n, 4), dtype=torch.int64, device=device))
         torch.cuda.synchronize(device)
         self.rng_bytes = self.pks[0].rng_bytes

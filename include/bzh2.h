@@ -267,6 +267,11 @@ int bzh_ipa_verify(bzh_ctx* ctx, const bzh_bases* bases, const uint64_t* commitm
 typedef struct bzh_pk bzh_pk;
 int bzh_pk_create(bzh_ctx* ctx, const bzh_bases* srs, const uint8_t* circuit, size_t circuit_len, bzh_pk** out);
 int bzh_pk_free(bzh_ctx* ctx, bzh_pk* pk);
+/* Params::commit_lagrange: with the table (g_lagrange | u | w) of bzh_params_create set, the instance, advice, permuted-lookup and
+ * grand-product columns are committed in the Lagrange basis, as upstream does -- the same group elements (hence the same proof
+ * bytes) as committing their coefficients to g, but sparse / small witness columns then cost the MSM almost nothing.
+ * NULL returns to coefficient-basis commitments.  The table must outlive the key. */
+int bzh_pk_set_lagrange(bzh_pk* pk, const bzh_bases* g_lagrange);
 int bzh_pk_info(const bzh_pk* pk, size_t* rng_bytes_per_proof, size_t* max_proof_bytes, uint32_t* num_advice, uint32_t* n_rows,
                 uint32_t* usable_rows);
 /* bzh_verify_batch  plonk::verify_proof (SingleVerifier; benches/board.rs:80-86) for `batch` proofs of the key's circuit:
@@ -277,6 +282,27 @@ int bzh_verify_batch(bzh_ctx* ctx, bzh_pk* pk, size_t batch, const uint64_t* ins
 int bzh_prove_batch(bzh_ctx* ctx, bzh_pk* pk, size_t batch, const uint64_t* advice, int form, int mem, const uint64_t* instances,
                     size_t instance_rows, const uint8_t* rng, size_t rng_stride, uint8_t* proofs, size_t proof_stride,
                     size_t* proof_lens);
+
+/* ---- Params::new (halo2_proofs poly::commitment::Params; benches/shot.rs:58, benches/board.rs:51, and on every call of
+ * the wasm exports, src/wasm/circuit_wasm.rs:57,97,145,180) -------------------------------------------------------
+ * A pure function of k: g[i] = hash_to_curve("Halo2-Parameters")(0u8 || i as u32 LE), g_lagrange = inverse group FFT of
+ * g, w = hash_to_curve(..)([1]), u = hash_to_curve(..)([2]) on Vesta.
+ *   bzh_hash_to_curve      pasta_curves' CurveExt::hash_to_curve(domain_prefix)(msg) on Pallas / Vesta (host): the reference's
+ *                          own call site is src/utils/pedersen.rs:19-21 ("battlezips:hash2curve", b"v" / b"r").
+ *   bzh_params_generators  g (n x 8 canonical limbs), w, u on the host (threads over i; 0 = auto).
+ *   bzh_group_ifft         g -> g_lagrange on the device (n/2 log n + n point-by-scalar multiplications).
+ *   bzh_params_create      both of the above, cached on disk keyed by (curve, k) under cache_dir (NULL: next to the library
+ *                          or $BZH_CACHE_DIR; "": no cache), then the two commitment-base tables (g | u | w) and
+ *                          (g_lagrange | u | w) uploaded with fixed-base window tables: what bzh_pk_create /
+ *                          bzh_pk_set_lagrange take.  The params own the tables (bzh_params_free releases them). */
+typedef struct bzh_params bzh_params;
+int bzh_hash_to_curve(int curve, const char* domain_prefix, const uint8_t* msg, size_t len, uint64_t* out_xy);
+int bzh_params_generators(unsigned k, uint64_t* g_xy, uint64_t* w_xy, uint64_t* u_xy, unsigned threads);
+int bzh_group_ifft(bzh_ctx* ctx, int curve, const uint64_t* g_xy, unsigned k, uint64_t* out_xy);
+int bzh_params_create(bzh_ctx* ctx, unsigned k, const char* cache_dir, int window_bits, bzh_params** out);
+int bzh_params_free(bzh_ctx* ctx, bzh_params* p);
+int bzh_params_bases(const bzh_params* p, bzh_bases** g, bzh_bases** g_lagrange);
+int bzh_params_points(const bzh_params* p, uint64_t* g_xy, uint64_t* g_lagrange_xy, uint64_t* w_xy, uint64_t* u_xy, int* from_cache);
 
 /* ---- circuits: the reference's ShotCircuit / BoardCircuit as data + their witness synthesis -------------------------
  * The reference-side interface this replaces is `impl Circuit<pallas::Base> for {ShotCircuit, BoardCircuit}`
