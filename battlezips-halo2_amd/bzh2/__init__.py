@@ -300,6 +300,7 @@ def _bind_poly(L):
 
 EXPORTS += ["bzh_field_convert", "bzh_random_field", "bzh_batch_invert", "bzh_prefix_product", "bzh_eval_polynomial", "bzh_inner_product", "bzh_fold", "bzh_vec_mul"]
 TIMER_NAMES[5] = "poly"
+TIMER_NAMES[6] = "quotient"
 
 
 def _as_elems(a):
@@ -446,7 +447,7 @@ class Transcript:
 
 # ---- IPA opening --------------------------------------------------------------------------------
 EXPORTS += ["bzh_ipa_open", "bzh_ipa_open_batch", "bzh_ipa_verify"]
-EXPORTS += ["bzh_pk_create", "bzh_pk_free", "bzh_pk_set_lagrange", "bzh_pk_info", "bzh_prove_batch", "bzh_verify_batch"]
+EXPORTS += ["bzh_pk_create", "bzh_pk_free", "bzh_pk_set_lagrange", "bzh_pk_quotient_stats", "bzh_pk_info", "bzh_prove_batch", "bzh_verify_batch"]
 # Params::new (bzh2/params.py)
 EXPORTS += ["bzh_hash_to_curve", "bzh_params_generators", "bzh_group_ifft", "bzh_params_create", "bzh_params_free", "bzh_params_bases",
             "bzh_params_points"]

@@ -64,6 +64,13 @@ class NativeProvingKey:
         if params is not None:
             self.set_lagrange(params.bases_lagrange)
 
+    def quotient_stats(self) -> dict:
+        L = _bind()
+        L.bzh_pk_quotient_stats.argtypes = [_VP] + [ctypes.POINTER(ctypes.c_uint32)] * 4
+        v = [ctypes.c_uint32() for _ in range(4)]
+        self.ctx._check(L.bzh_pk_quotient_stats(self.handle, *[ctypes.byref(x) for x in v]), "bzh_pk_quotient_stats")
+        return {"ops": v[0].value, "multiplications_per_row": v[1].value, "lds_slots": v[2].value, "hoisted_columns": v[3].value}
+
     def set_lagrange(self, bases_lagrange):
         """Params::commit_lagrange for the columns upstream commits in the Lagrange basis (None: back to coefficients)."""
         self.ctx._check(_bind().bzh_pk_set_lagrange(self.handle, bases_lagrange.handle if bases_lagrange is not None else None),

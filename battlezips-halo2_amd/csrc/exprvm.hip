@@ -243,7 +243,7 @@ int expr_eval2(bzh_ctx* ctx, int field, const void* d_prog, int nops, const uint
     if (size % kVm2Threads) return BZH_E_ARG;
     const size_t lds = (size_t)std::max(nlds, 1) * 2 * kVm2Threads * sizeof(uint4);
     if (lds > 64 * 1024) return BZH_E_RANGE;
-    ScopedTimer t(ctx, BZH_T_POLY);
+    ScopedTimer t(ctx, BZH_T_QUOTIENT);
     const dim3 grid((unsigned)(size / kVm2Threads), (unsigned)batch), block(kVm2Threads);
     const ExprOp2* p = (const ExprOp2*)d_prog;
     switch (field) {

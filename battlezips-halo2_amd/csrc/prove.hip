@@ -1533,6 +1533,11 @@ struct Prover {
         PV_TRY(h2d_small(ctx, d_prog, pg.ops.data(), pg.ops.size() * sizeof(ExprOp2)));
         PV_TRY(h2d_small(ctx, d_ptrs, ptrs.data(), ncols * 8));
         PV_TRY(h2d_small(ctx, d_strides, strides.data(), ncols * 8));
+        if (ctx->profiling) {   // the quotient pass reads every extended column once and writes h: per-proof columns
+            double cols_read = 0;   // count per proof, columns of the key once per launch
+            for (size_t i = 0; i < reg.stride.size(); i++) cols_read += reg.stride[i] ? (double)B : 1.0;
+            ctx->alg_bytes[BZH_T_QUOTIENT] += (cols_read + (double)B) * (double)size * 32.0;
+        }
         return expr_eval2(ctx, field, d_prog, (int)pg.ops.size(), (const uint32_t* const*)d_ptrs, (const size_t*)d_strides, d_consts, nc, size, B,
                           pg.nlds, d_out);
     }
@@ -2749,6 +2754,22 @@ int bzh_pk_set_lagrange(bzh_pk* pk, const bzh_bases* g_lagrange) {
         return BZH_E_ARG;
     std::lock_guard<std::mutex> lk(pk->mu);
     pk->srs_lagrange = g_lagrange;
+    return BZH_OK;
+}
+
+int bzh_pk_quotient_stats(bzh_pk* pk, uint32_t* ops, uint32_t* multiplications, uint32_t* lds_slots, uint32_t* hoisted_columns) {
+    if (!pk) return BZH_E_ARG;
+    std::lock_guard<std::mutex> lk(pk->mu);
+    uint32_t no = 0, nm = 0, nl = 0;
+    for (auto& kv : pk->progs2) {   // the quotient program (compiled at the first proof)
+        no = (uint32_t)kv.second.ops.size();
+        nl = (uint32_t)kv.second.nlds;
+        for (auto& o : kv.second.ops) nm += ((o.code >> 4) < 3 && ((o.code >> 2) & 3) == bzh::V2_MUL);
+    }
+    if (ops) *ops = no;
+    if (multiplications) *multiplications = nm;
+    if (lds_slots) *lds_slots = nl;
+    if (hoisted_columns) *hoisted_columns = (uint32_t)pk->hoist_cols;
     return BZH_OK;
 }
 

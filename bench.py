@@ -103,14 +103,14 @@ def parse():
                     help="gloo + several ranks on one GPU rehearses the multi-rank path on a single-GPU box (ranks share device "
                          "local_rank %% device_count); the driver's multi-GPU runs use nccl (RCCL)")
     ap.add_argument("--no-precompute", action="store_true", help="plain bases: no fixed-base window table for the SRS")
-    ap.add_argument("--batch", type=int, default=24,
+    ap.add_argument("--batch", type=int, default=16,
                     help="proof_k* workloads: witnesses synthesised and proved in lockstep per bzh_prove_batch call; "
                          "1 = the single-proof latency path")
     ap.add_argument("--circuit", default="auto", choices=["auto", "shot", "board"],
                     help="proof_k* workloads: which of the reference's circuits (auto: ShotCircuit at k = 11, BoardCircuit otherwise)")
     ap.add_argument("--mix-divisor", type=int, default=1, help="mixed_board_shot: divide the fixed batch (256 Board + 2560 Shot) by this")
     ap.add_argument("--window-bits", type=int, default=0, help="SRS window-table width (0: 8 for --batch 1, else the planner's)")
-    ap.add_argument("--concurrency", type=int, default=4,
+    ap.add_argument("--concurrency", type=int, default=8,
                     help="proof_k* workloads: independent proofs in flight per GPU (host threads, one ctx + stream each)")
     return ap.parse_args()
 
@@ -438,18 +438,22 @@ class Workload:
             fn()
 
 
-def cpu_baseline(workload_name, k):
-    """Time the C oracle ("port": CPU restatement, not the Rust crate) on one full step's worth of
-    MSM+NTT work for the proof workloads, all host cores."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import coracle as C
-    import pasta as O
-    import random
+def _cpu_cores():
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 16))  # the 1-GPU box's CPU share; more threads only shrink the per-thread windows
+    return max(1, min(cores, 16))  # the 1-GPU box's CPU share; more threads only shrink the per-thread windows
+
+
+def cpu_baseline(workload_name, k):
+    """MSM + NTT schedule workloads (board_k14 ...): the C oracle ("port": CPU restatement, not the Rust crate) on one step's
+    worth of MSM + NTT work, all host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import coracle as C
+    import pasta as O
+    import random
+    cores = _cpu_cores()
     n, ext = 1 << k, 1 << (k + 3)
     rng = np.random.default_rng(99)
 
@@ -480,6 +484,98 @@ def cpu_baseline(workload_name, k):
             "sample": "C oracle (liboracle.so, halo2-style chunked Pippenger + radix-2 FFT): %d MSM 2^%d, %d iNTT 2^%d, "
                       "%d coset NTT 2^%d timed, scaled to 28/17/19 per step" % (n_msm, k, n_intt, k, n_cntt, k + 3),
             "seconds_per_step": per_step}
+
+
+def cpu_baseline_proof(runner):
+    """A COMPLETE create_proof schedule for the runner's real circuit on the host cores with the C oracle (oracle/oracle.c:
+    restatements of upstream's best_multiexp, best_fft, the per-row gate evaluation and the IPA generator collapse), every
+    stage of SURVEY section 3.1 steps 1-9 timed on a bounded sample of the real data and scaled to one proof:
+      commitments (instance / advice / permuted lookup in the Lagrange basis on the REAL witness columns -- sparse, as upstream
+      sees them -- and the dense z / random / h / f / s ones), iNTT + coset NTT of every committed column, the quotient's gate
+      evaluation over the 2^(k+3) rows (all constraint polynomials of the real circuit, y-fold), evaluations at x, and the k
+      IPA rounds (two half-size MSMs + the generator collapse each).  Witness synthesis is the product's (not timed here)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import blob as Bm
+    import coracle as C
+    import pasta as O
+    cores = _cpu_cores()
+    k = runner.k
+    n, ext = 1 << k, 1 << (k + 3)
+    F = O.FP
+    circ = Bm.decode(runner.layout.blob())
+    g, gl, w, u, _ = runner.params.points()
+    adv, _ = runner.layout.synthesize(runner._circuits(0, 1))          # one real witness, canonical, host
+    rng = np.random.default_rng(7)
+
+    def rnd(m):
+        a = np.frombuffer(rng.bytes(m * 32), dtype=np.uint64).reshape(m, 4).copy()
+        a[:, 3] &= (1 << 61) - 1
+        return a
+
+    def timed(fn, reps=1):
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        return (time.perf_counter() - t0) / reps
+    parts = {}
+    na = adv.shape[1]
+    # 1. commitments: advice + instance in the Lagrange basis on the real columns; lookup A', S' hold 10-bit table values
+    parts["commit_advice_lagrange_x%d" % na] = sum(timed(lambda c=c: C.msm(0, np.ascontiguousarray(adv[0, c]), gl, cores)) for c in range(na))
+    small = np.zeros((n, 4), dtype=np.uint64)
+    small[:, 0] = rng.integers(0, 1024, n, dtype=np.uint64)
+    parts["commit_lookup_permuted_x2"] = 2 * timed(lambda: C.msm(0, small, gl, cores))
+    dense = rnd(n)
+    t_dense = timed(lambda: C.msm(0, dense, g, cores), 2)
+    parts["commit_dense_x15 (instance, 3 z, random, 8 h, f, s)"] = 15 * t_dense
+    # 2. transforms of every committed column
+    col = rnd(n)
+    parts["intt_n_x17"] = 17 * timed(lambda: C.ntt(0, col, F.omega(k), inverse=True, threads=cores), 2)
+    e = rnd(ext)
+    parts["coset_ntt_8n_x18 + ext_intt"] = 19 * timed(lambda: C.ntt(0, e, F.omega(k + 3), coset_shift=F.g, threads=cores), 2)
+    # 3. quotient: all constraint polynomials of the real circuit on a sample of the extended rows
+    prog, consts, colmap = C.compile_gates(circ.gates)
+    sz = 4096
+    cols = [rnd(sz) for _ in range(len(colmap))]
+    sample = 2048
+    t_q = timed(lambda: C.gate_eval(0, prog, consts, cols, 12345, 0, sample, threads=cores, rot_scale=8))
+    parts["quotient_gates_8n_rows"] = t_q * (ext / sample)
+    # 4. evaluations at x (Horner): every queried (column, rotation) + z / lookup / sigma / h evaluations
+    nq = len(circ.queries[0]) + len(circ.queries[1]) + len(circ.queries[2]) + len(circ.perm_columns) + 16 if circ.queries else 80
+    parts["evaluations_x%d" % nq] = nq * timed(lambda: C.eval_poly(0, col, 987654321), 4)
+    # 5. IPA: round j works on half = n / 2^(j+1) points: two MSMs + the generator collapse; rounds 0 and 1 timed, the
+    #    rest follows the halving (sum over rounds = 2 x round 0 up to the small rounds)
+    half = n // 2
+    t_r0_msm = timed(lambda: C.msm(0, dense[:half], g[:half], cores), 2) * 2
+    t_r0_col = timed(lambda: C.generator_collapse(0, g, 0x1234567890abcdef1234567890abcdef, cores))
+    parts["ipa_%d_rounds (2 MSM + generator collapse each)" % k] = 2.0 * (t_r0_msm + t_r0_col)
+    per_proof = sum(parts.values())
+    return {"value": 1.0 / per_proof, "unit": "proofs/s", "cores": cores, "kind": "port",
+            "sample": "C oracle (oracle/oracle.c: best_multiexp / best_fft / per-row gate evaluation / generator collapse restated from "
+                      "halo2_proofs 0.2.0) on the real %sCircuit at k=%d: every stage of create_proof (SURVEY 3.1 steps 1-9) timed on a "
+                      "bounded sample and scaled to one proof; not the Rust crate (no toolchain)" % (runner.kind.capitalize(), k),
+            "seconds_per_proof": per_proof, "stages_s": {kk: round(v, 4) for kk, v in parts.items()}}
+
+
+def ubench_peaks():
+    """ALU yardsticks from the tracked microbench record (tools/ubench_field.hip run on this GPU model): the best rate of
+    the XYZZ mixed addition and of the field multiplication in isolation."""
+    import glob
+    import re
+    best = {"xyzz_madd": None, "fe_mul": None, "source": None}
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_ubench_field_gfx950.txt")))
+    if not files:
+        return best
+    best["source"] = os.path.relpath(files[-1], ROOT)
+    for line in open(files[-1]):
+        m = re.search(r"([\d.]+) Gop/s", line)
+        if not m:
+            continue
+        v = float(m.group(1))
+        if line.startswith("xyzz_madd"):
+            best["xyzz_madd"] = max(best["xyzz_madd"] or 0, v)
+        elif line.startswith("fe_mul<Fp>"):
+            best["fe_mul"] = max(best["fe_mul"] or 0, v)
+    return best
 
 
 def main():
@@ -552,7 +648,7 @@ def main():
         for _ in range(2):
             wl.solo_step()
         torch.cuda.synchronize(device)
-        solo = ctx.timings()["msm_accumulate"]
+        solo = ctx.timings()
         ctx.profile(False)
     verified = None
     if hasattr(wl, "verify_last"):  # untimed: every proof of every thread's last batch through bzh_verify_batch
@@ -571,34 +667,43 @@ def main():
         is_mixed = args.workload == "mixed_board_shot"
         acc = timings["msm_accumulate"]
         nt = timings["ntt"]
+        qt = timings.get("quotient", {"ms": 0.0, "launches": 0, "algorithmic_bytes": 0.0})
+        peaks = ubench_peaks()
         if args.workload == "ntt22":
             dom_ms = nt["ms"] / max(nt["launches"], 1) * (nt["launches"] / max(args.steps, 1))  # all passes of one NTT
             alg = wl.alg_bytes_step
             dom_name = "k_ntt_pass (all passes of one 2^22 NTT)"
+        elif (is_full or is_mixed) and qt["ms"] > acc["ms"]:
+            # the gate evaluation over the extended coset is the largest kernel class of this run
+            dom_ms = qt["ms"] / max(qt["launches"], 1)
+            alg = qt["algorithmic_bytes"] / max(qt["launches"], 1)
+            dom_name = "k_expr_vm2 (quotient gate evaluation, one launch per batch)"
+            wl.alg_bytes_step = (acc["algorithmic_bytes"] + nt["algorithmic_bytes"] + qt["algorithmic_bytes"]) / max(args.steps, 1)
         elif is_full or is_verify or is_mixed:
-            # MSM launches of a proof differ in size (28 column commits batched by phase, then the halving IPA
-            # rounds): average the bytes the library counted per launch (bzh_ctx_work) over the same launches
+            # MSM launches of a proof differ in size (28 column commits batched by phase, then the IPA rounds): average the
+            # bytes the library counted per launch (bzh_ctx_work) over the same launches
             dom_ms = acc["ms"] / max(acc["launches"], 1)
             alg = acc["algorithmic_bytes"] / max(acc["launches"], 1)
             dom_name = "k_msm_accumulate (mean over the %d launches of one step)" % (acc["launches"] // max(args.steps, 1))
-            wl.alg_bytes_step = (acc["algorithmic_bytes"] + nt["algorithmic_bytes"]) / max(args.steps, 1)
+            wl.alg_bytes_step = (acc["algorithmic_bytes"] + nt["algorithmic_bytes"] + qt["algorithmic_bytes"]) / max(args.steps, 1)
         else:
             dom_ms = acc["ms"] / max(acc["launches"], 1)
             alg = wl.alg_bytes_msm_launch
             dom_name = "k_msm_accumulate"
         achieved = alg / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        # HBM-side traffic of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
-        # WRITE_SIZE in separate runs of this same command; tools/pmc_traffic.py), if one exists for this workload
+        # HBM-side traffic of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+        # separate runs of this same command), if one exists for this workload and kernel
         traffic, traffic_src = None, None
-        for tag in ("r01_h", "r01_e"):
+        want_kernel = "k_expr_vm2" if dom_name.startswith("k_expr_vm2") else "k_msm_accumulate"
+        for tag in ("r02", "r01_h", "r01_e"):
             tj = os.path.join(ROOT, "profiles", "%s_%s_pmc_traffic.json" % (tag, args.workload))
             if traffic is not None or not os.path.exists(tj) or args.workload == "ntt22":
                 continue
             try:
                 for e in json.load(open(tj))["kernels"]:
-                    if "k_msm_accumulate" in e["kernel"] and ("512" in e["kernel"] or e.get("workgroup", 0) >= 512):
+                    if want_kernel in e["kernel"] and (want_kernel != "k_msm_accumulate" or "512" in e["kernel"] or e.get("workgroup", 0) >= 512):
                         traffic = e["read_bytes_raw"] + e["write_bytes"]
-                        traffic_src = os.path.relpath(tj, ROOT) + " (raw FETCH_SIZE: 64-B gathers, see its correction note)"
+                        traffic_src = os.path.relpath(tj, ROOT) + (" (real circuit)" if tag == "r02" else " (round-1 synthetic circuit: stale for the real one)")
             except Exception:
                 traffic = None
         line = {
@@ -623,26 +728,45 @@ def main():
             "kernel_ms": {kname: v for kname, v in timings.items() if v["launches"]},
         }
         line["config"]["host_threads_pinned_to_numa_node"] = numa_node
-        if (is_full or is_verify) and acc["ms"] > 0:
-            # the bound that actually binds this kernel: bucket additions per second against the rate
-            # the same XYZZ mixed addition reaches in isolation (profiles/r01_ubench_field_gfx950.txt), i.e. the integer
-            # multiplier peak; kernel time is summed over the host threads' contexts, so overlapping batches understate it
+        if (is_full or is_verify or is_mixed) and acc["ms"] > 0:
+            # the bounds that actually bind these kernels: integer-multiplier rates against the same
+            # operation in isolation (profiles/r*_ubench_field_gfx950.txt, read here); kernel time is summed over the host threads'
+            # contexts, so overlapping batches understate the rates of the timed region
             wb = getattr(wl, "window_bits", 0) or 11
             nwin = (256 + wb - 1) // wb
-            npts = (1 << wl.k) + 2
-            scalars = (acc["algorithmic_bytes"] - 64.0 * npts * acc["launches"]) / 32.0
-            adds = scalars * nwin
-            line["roofline"]["alu_equivalent"] = {"unit": "G mixed additions/s", "achieved": adds / (acc["ms"] * 1e-3) / 1e9, "peak": 14.2,
-                                                  "frac": adds / (acc["ms"] * 1e-3) / 1e9 / 14.2, "table_rows": nwin}
-            if solo is not None and solo["ms"] > 0:
-                s_ms = solo["ms"] / max(solo["launches"], 1)
-                s_alg = solo["algorithmic_bytes"] / max(solo["launches"], 1)
-                s_adds = (solo["algorithmic_bytes"] - 64.0 * npts * solo["launches"]) / 32.0 * nwin
-                line["roofline"]["single_batch_in_flight"] = {
-                    "avg_launch_ms": s_ms, "achieved": s_alg / (s_ms * 1e-3) / 1e9, "frac": s_alg / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                    "alu_equivalent": {"achieved": s_adds / (solo["ms"] * 1e-3) / 1e9, "peak": 14.2, "frac": s_adds / (solo["ms"] * 1e-3) / 1e9 / 14.2},
-                    "note": "same kernel, one batch in flight (2 untimed steps after the timed region); in the timed region "
-                            "%d batches share the GPU and every launch stretches accordingly" % len(all_ctx)}
+            alu = {"peaks_source": peaks["source"]}
+            if is_full and qt["ms"] > 0:
+                st = wl.runner.pks[0].quotient_stats()
+                rows = (1 << (wl.k + 3)) * wl.units_per_step * args.steps
+                rate = st["multiplications_per_row"] * rows / (qt["ms"] * 1e-3) / 1e9
+                alu["quotient"] = {"unit": "G field multiplications/s", "achieved": rate, "peak": peaks["fe_mul"],
+                                   "frac": rate / peaks["fe_mul"] if peaks["fe_mul"] else None, "program": st}
+            line["roofline"]["alu_equivalent"] = alu
+            line["roofline"]["other_kernels"] = {
+                "k_msm_accumulate": {"avg_launch_ms": acc["ms"] / max(acc["launches"], 1),
+                                     "achieved_GBps": acc["algorithmic_bytes"] / max(acc["ms"], 1e-9) / 1e6,
+                                     "frac": acc["algorithmic_bytes"] / max(acc["ms"], 1e-9) / 1e6 / HBM_PEAK_GBS},
+                "k_expr_vm2": {"avg_launch_ms": qt["ms"] / max(qt["launches"], 1),
+                               "achieved_GBps": qt["algorithmic_bytes"] / max(qt["ms"], 1e-9) / 1e6,
+                               "frac": qt["algorithmic_bytes"] / max(qt["ms"], 1e-9) / 1e6 / HBM_PEAK_GBS} if qt["ms"] else None,
+                "k_ntt_pass": {"achieved_GBps": nt["algorithmic_bytes"] / max(nt["ms"], 1e-9) / 1e6,
+                               "frac": nt["algorithmic_bytes"] / max(nt["ms"], 1e-9) / 1e6 / HBM_PEAK_GBS} if nt["ms"] else None}
+            if solo is not None and solo["msm_accumulate"]["ms"] > 0:
+                s_acc, s_q = solo["msm_accumulate"], solo.get("quotient", {"ms": 0, "launches": 0, "algorithmic_bytes": 0})
+                one = {"note": "the same kernels with ONE batch in flight (2 untimed steps after the timed region); in the timed region "
+                               "%d batches share the GPU and every launch stretches accordingly" % len(all_ctx),
+                       "k_msm_accumulate": {"avg_launch_ms": s_acc["ms"] / max(s_acc["launches"], 1),
+                                            "achieved_GBps": s_acc["algorithmic_bytes"] / s_acc["ms"] / 1e6,
+                                            "frac": s_acc["algorithmic_bytes"] / s_acc["ms"] / 1e6 / HBM_PEAK_GBS}}
+                if s_q["ms"] > 0:
+                    st = wl.runner.pks[0].quotient_stats()
+                    rows = (1 << (wl.k + 3)) * wl.runner.batch * 2
+                    rate = st["multiplications_per_row"] * rows / (s_q["ms"] * 1e-3) / 1e9
+                    one["k_expr_vm2"] = {"avg_launch_ms": s_q["ms"] / max(s_q["launches"], 1),
+                                         "achieved_GBps": s_q["algorithmic_bytes"] / s_q["ms"] / 1e6,
+                                         "frac": s_q["algorithmic_bytes"] / s_q["ms"] / 1e6 / HBM_PEAK_GBS,
+                                         "G_field_multiplications_per_s": rate, "frac_of_fe_mul_peak": rate / peaks["fe_mul"] if peaks["fe_mul"] else None}
+                line["roofline"]["single_batch_in_flight"] = one
         if is_mixed:
             line["metric"] = "complete proofs per second, fixed batch of BoardCircuit (k=14) : ShotCircuit (k=11) = 1 : 10, IPA/Pasta"
             line["unit"] = "proofs/s"
@@ -658,6 +782,7 @@ def main():
         if is_full:
             line["config"]["stages"] = ("Circuit::synthesize (host C++ witness generation, staged to HBM) + complete create_proof: commitments, "
                                         "lookup, permutation, vanishing, quotient, evaluations, multiopen, IPA, transcript -- all inside the timed region")
+            line["config"]["srs"] = "Params::new(%d): hash_to_curve generators + g_lagrange (csrc/params.hip); witness / lookup / grand-product columns committed in the Lagrange basis" % wl.k
             line["config"]["proof_bytes"] = len(wl.runner.last_batch[0][0])
             line["config"]["last_batches_verified"] = verified
             line["config"]["proofs_in_flight_per_gpu"] = args.concurrency * args.batch
@@ -665,12 +790,11 @@ def main():
             line["config"]["batch"] = args.batch
             line["config"]["srs_window_bits"] = wl.window_bits or "planner"
             line["config"]["distinct_proofs_in_last_batch"] = len(set(wl.runner.last_batch[0]))
-        if world == 1 and (is_proof or is_full) and not args.no_cpu_baseline and args.workload != "shot_k11_batch":
-            line["cpu_baseline"] = cpu_baseline(args.workload, wl.k)
+        if world == 1 and not args.no_cpu_baseline:
             if is_full:
-                line["cpu_baseline"]["unit"] = "proofs/s (upper bound)"
-                line["cpu_baseline"]["sample"] += ("; only the proof's MSM+NTT schedule is timed on the CPU, so a CPU prover's "
-                                                   "complete-proof rate is below this figure")
+                line["cpu_baseline"] = cpu_baseline_proof(wl.runner)
+            elif is_proof and args.workload != "shot_k11_batch":
+                line["cpu_baseline"] = cpu_baseline(args.workload, wl.k)
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()

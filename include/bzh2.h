@@ -75,6 +75,7 @@ typedef enum {
     BZH_T_MSM_FINALIZE = 3,
     BZH_T_NTT = 4,
     BZH_T_POLY = 5,
+    BZH_T_QUOTIENT = 6, /* the quotient's gate evaluation over the extended coset (k_expr_vm2) */
     BZH_T_COUNT = 8
 } bzh_timer;
 
@@ -272,6 +273,9 @@ int bzh_pk_free(bzh_ctx* ctx, bzh_pk* pk);
  * bytes) as committing their coefficients to g, but sparse / small witness columns then cost the MSM almost nothing.
  * NULL returns to coefficient-basis commitments.  The table must outlive the key. */
 int bzh_pk_set_lagrange(bzh_pk* pk, const bzh_bases* g_lagrange);
+/* the quotient's evaluator program (compiled at the key's first proof; zeros before): instructions, field multiplications per
+ * extended-domain row, LDS slots, proof-independent subexpressions hoisted into key-owned coset columns */
+int bzh_pk_quotient_stats(bzh_pk* pk, uint32_t* ops, uint32_t* multiplications, uint32_t* lds_slots, uint32_t* hoisted_columns);
 int bzh_pk_info(const bzh_pk* pk, size_t* rng_bytes_per_proof, size_t* max_proof_bytes, uint32_t* num_advice, uint32_t* n_rows,
                 uint32_t* usable_rows);
 /* bzh_verify_batch  plonk::verify_proof (SingleVerifier; benches/board.rs:80-86) for `batch` proofs of the key's circuit:

@@ -41,6 +41,10 @@ def lib():
         _LIB.orc_field_inv.argtypes = [ctypes.c_int, u64p, u64p]
         _LIB.orc_field_consts.argtypes = [ctypes.c_int, u64p, u64p, u64p, u64p]
         _LIB.orc_eval_poly.argtypes = [ctypes.c_int, u64p, ctypes.c_size_t, u64p, u64p]
+        _LIB.orc_gate_eval.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_int32), ctypes.c_size_t, u64p, ctypes.c_size_t,
+                                       ctypes.POINTER(u64p), ctypes.c_size_t, ctypes.c_uint, u64p, ctypes.c_size_t, ctypes.c_size_t,
+                                       ctypes.c_int, u64p]
+        _LIB.orc_generator_collapse.argtypes = [ctypes.c_int, u64p, ctypes.c_size_t, u64p, ctypes.c_int]
     return _LIB
 
 
@@ -135,3 +139,79 @@ def eval_poly(field_id: int, coeffs: np.ndarray, x: int) -> int:
     out = np.zeros(4, dtype=np.uint64)
     lib().orc_eval_poly(field_id, _p(np.ascontiguousarray(coeffs)), coeffs.shape[0], _p(int_to_limbs(x)), _p(out))
     return limbs_to_int(out)
+
+
+def compile_gates(gates):
+    """halo2-style expression trees (oracle/halo2_oracle.py AST) -> the postfix program of orc_gate_eval:
+    (prog (m, 3) int32, consts list of ints).  One 'end of polynomial' op per gate: acc = acc * y + value."""
+    prog, consts, cidx = [], [], {}
+
+    def const(v):
+        if v not in cidx:
+            cidx[v] = len(consts)
+            consts.append(v)
+        return cidx[v]
+
+    def emit(e, colmap):
+        t = e[0]
+        if t == 'const':
+            prog.append((0, const(e[1]), 0))
+        elif t in ('advice', 'fixed', 'instance'):
+            prog.append((1, colmap[(t, e[1])], e[2]))
+        elif t == 'neg':
+            emit(e[1], colmap)
+            prog.append((2, 0, 0))
+        elif t == 'scale':
+            emit(e[1], colmap)
+            prog.append((5, const(e[2]), 0))
+        else:
+            emit(e[1], colmap)
+            emit(e[2], colmap)
+            prog.append((3 if t == 'add' else 4, 0, 0))
+    colmap = {}
+
+    def cols_of(e):
+        t = e[0]
+        if t in ('advice', 'fixed', 'instance'):
+            colmap.setdefault((t, e[1]), len(colmap))
+        elif t in ('neg', 'scale'):
+            cols_of(e[1])
+        elif t in ('add', 'mul'):
+            cols_of(e[1])
+            cols_of(e[2])
+    for g in gates:
+        cols_of(g)
+    for g in gates:
+        emit(g, colmap)
+        prog.append((6, 0, 0))
+    return np.array(prog, dtype=np.int32).reshape(-1, 3), consts, colmap
+
+
+def gate_eval(field_id: int, prog: np.ndarray, consts, cols, y: int, row_lo: int, row_hi: int, threads: int = 1, rot_scale: int = 1):
+    """cols: list of (size, 4) uint64 canonical arrays (size a power of two); rotations in the program are multiplied by
+    rot_scale (extended-domain steps per row rotation).  Returns (row_hi - row_lo, 4) uint64."""
+    size = cols[0].shape[0]
+    log_size = size.bit_length() - 1
+    pg = np.ascontiguousarray(prog, dtype=np.int32).copy()
+    if rot_scale != 1:
+        m = pg[:, 0] == 1
+        pg[m, 2] *= rot_scale
+    cs = ints_to_array(consts) if consts else np.zeros((1, 4), dtype=np.uint64)
+    u64p = ctypes.POINTER(ctypes.c_uint64)
+    arr = (u64p * len(cols))(*[_p(np.ascontiguousarray(c)) for c in cols])
+    keep = [np.ascontiguousarray(c) for c in cols]
+    arr = (u64p * len(cols))(*[_p(c) for c in keep])
+    out = np.zeros((row_hi - row_lo, 4), dtype=np.uint64)
+    rc = lib().orc_gate_eval(field_id, pg.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), pg.shape[0], _p(cs), len(consts), arr, len(cols),
+                             log_size, _p(int_to_limbs(y)), row_lo, row_hi, threads, _p(out))
+    assert rc == 0
+    return out
+
+
+def generator_collapse(curve_id: int, g: np.ndarray, u: int, threads: int = 1) -> np.ndarray:
+    """g: (2 * half, 8) affine points; returns the (half, 8) collapsed generators g_lo + [u] g_hi."""
+    a = np.ascontiguousarray(g, dtype=np.uint64).copy()
+    half = a.shape[0] // 2
+    rc = lib().orc_generator_collapse(curve_id, _p(a), half, _p(int_to_limbs(u)), threads)
+    assert rc == 0
+    return a[:half]

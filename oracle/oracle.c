@@ -452,3 +452,131 @@ int orc_eval_poly(int field_id, const uint64_t *coeffs, size_t n, const uint64_t
     f_from_mont(F, &acc, &acc); memcpy(out, &acc, 32);
     return 0;
 }
+
+/* ------------------------------------------------------------------------ */
+/* Gate evaluation on the extended domain, as halo2_proofs 0.2.0 does it in    */
+/* plonk/prover.rs + poly/evaluator.rs (UPSTREAM): every constraint polynomial */
+/* is an AST walked per row (here: a postfix program, one field op per node),  */
+/* the results folded with y.  prog: int32 triples (op, a, b):                 */
+/*   0 const a | 1 column a at rotation b | 2 neg | 3 add | 4 mul | 5 scale by */
+/*   const a | 6 end of polynomial (fold: acc = acc * y + top)                 */
+/* cols: ncols pointers to `size` canonical elements each; rows [row_lo,row_hi)*/
+/* are evaluated (a bounded sample of the 2^(k+3) rows for the CPU baseline),  */
+/* out[r - row_lo] = folded value.  Plain restatement: no CSE, no factoring.   */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+    const field_t *F; const int32_t *prog; size_t nprog; const fe *consts; const fe *const *cols; size_t size;
+    fe y; size_t lo, hi, row_lo; fe *out;
+} gate_job;
+static void *gate_worker(void *arg) {
+    gate_job *j = (gate_job *)arg;
+    const field_t *F = j->F;
+    fe stack[64];
+    for (size_t r = j->lo; r < j->hi; r++) {
+        fe acc; memset(&acc, 0, sizeof(acc));
+        int sp = 0;
+        for (size_t i = 0; i < j->nprog; i++) {
+            const int32_t op = j->prog[3 * i], a = j->prog[3 * i + 1], b = j->prog[3 * i + 2];
+            switch (op) {
+                case 0: stack[sp++] = j->consts[a]; break;
+                case 1: stack[sp++] = j->cols[a][(r + (size_t)(int64_t)b) & (j->size - 1)]; break;
+                case 2: f_neg(F, &stack[sp - 1], &stack[sp - 1]); break;
+                case 3: f_add(F, &stack[sp - 2], &stack[sp - 2], &stack[sp - 1]); sp--; break;
+                case 4: f_mul(F, &stack[sp - 2], &stack[sp - 2], &stack[sp - 1]); sp--; break;
+                case 5: f_mul(F, &stack[sp - 1], &stack[sp - 1], &j->consts[a]); break;
+                default: f_mul(F, &acc, &acc, &j->y); f_add(F, &acc, &acc, &stack[--sp]); break;
+            }
+        }
+        j->out[r - j->row_lo] = acc;
+    }
+    return NULL;
+}
+int orc_gate_eval(int field_id, const int32_t *prog, size_t nprog, const uint64_t *consts, size_t nconsts,
+                  const uint64_t *const *cols, size_t ncols, unsigned log_size, const uint64_t *y,
+                  size_t row_lo, size_t row_hi, int threads, uint64_t *out) {
+    init_fields();
+    if (field_id < 0 || field_id > 3 || threads < 1 || row_hi < row_lo) return -1;
+    const field_t *F = &FIELDS[field_id];
+    const size_t size = (size_t)1 << log_size, rows = row_hi - row_lo;
+    /* inputs to Montgomery form once (the prover keeps its columns in that form) */
+    fe *cm = (fe *)malloc((nconsts ? nconsts : 1) * sizeof(fe));
+    for (size_t i = 0; i < nconsts; i++) { fe t; memcpy(&t, consts + 4 * i, 32); f_to_mont(F, &cm[i], &t); }
+    fe **colm = (fe **)malloc((ncols ? ncols : 1) * sizeof(fe *));
+    for (size_t c = 0; c < ncols; c++) {
+        colm[c] = (fe *)malloc(size * sizeof(fe));
+        for (size_t r = 0; r < size; r++) { fe t; memcpy(&t, cols[c] + 4 * r, 32); f_to_mont(F, &colm[c][r], &t); }
+    }
+    fe ym, t; memcpy(&t, y, 32); f_to_mont(F, &ym, &t);
+    fe *o = (fe *)malloc((rows ? rows : 1) * sizeof(fe));
+    if (threads > 64) threads = 64;
+    pthread_t th[64]; gate_job jobs[64];
+    const size_t per = (rows + (size_t)threads - 1) / (size_t)threads;
+    int used = 0;
+    for (int i = 0; i < threads; i++) {
+        size_t lo = row_lo + (size_t)i * per, hi = lo + per < row_hi ? lo + per : row_hi;
+        if (lo >= hi) break;
+        jobs[i] = (gate_job){F, prog, nprog, cm, (const fe *const *)colm, size, ym, lo, hi, row_lo, o};
+        pthread_create(&th[i], NULL, gate_worker, &jobs[i]);
+        used++;
+    }
+    for (int i = 0; i < used; i++) pthread_join(th[i], NULL);
+    for (size_t r = 0; r < rows; r++) { fe v; f_from_mont(F, &v, &o[r]); memcpy(out + 4 * r, &v, 32); }
+    for (size_t c = 0; c < ncols; c++) free(colm[c]);
+    free(colm); free(cm); free(o);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* IPA generator collapse of halo2_proofs 0.2.0 poly/commitment/prover.rs     */
+/* `parallel_generator_collapse` (UPSTREAM): g'[i] = g_lo[i] + [u] g_hi[i] for */
+/* i < half, i.e. half variable-base scalar multiplications + additions per    */
+/* round, then a batch normalisation.  g_xy: 2 * half affine points in, the    */
+/* first half overwritten with the collapsed generators.                      */
+/* ------------------------------------------------------------------------ */
+typedef struct { const field_t *F; const fe *u_repr; aff *g; jac *out; size_t half, lo, hi; } collapse_job;
+static void *collapse_worker(void *arg) {
+    collapse_job *j = (collapse_job *)arg;
+    const field_t *F = j->F;
+    for (size_t i = j->lo; i < j->hi; i++) {
+        jac acc; jac_set_id(&acc);
+        const aff *hi = &j->g[j->half + i];
+        for (int bit = 255; bit >= 0; bit--) {
+            jac_double(F, &acc, &acc);
+            if ((j->u_repr->l[bit >> 6] >> (bit & 63)) & 1) jac_add_affine(F, &acc, &acc, hi);
+        }
+        jac_add_affine(F, &acc, &acc, &j->g[i]);
+        j->out[i] = acc;
+    }
+    return NULL;
+}
+int orc_generator_collapse(int curve_id, uint64_t *g_xy, size_t half, const uint64_t *u, int threads) {
+    init_fields();
+    if (curve_id < 0 || curve_id > 2 || threads < 1) return -1;
+    const field_t *F = &FIELDS[CURVE_BASE[curve_id]];
+    aff *g = (aff *)malloc(2 * (half ? half : 1) * sizeof(aff));
+    for (size_t i = 0; i < 2 * half; i++) {
+        fe x, y; memcpy(&x, g_xy + 8 * i, 32); memcpy(&y, g_xy + 8 * i + 4, 32);
+        f_to_mont(F, &g[i].x, &x); f_to_mont(F, &g[i].y, &y);
+    }
+    fe ur; memcpy(&ur, u, 32);
+    jac *out = (jac *)malloc((half ? half : 1) * sizeof(jac));
+    if (threads > 64) threads = 64;
+    pthread_t th[64]; collapse_job jobs[64];
+    const size_t per = (half + (size_t)threads - 1) / (size_t)threads;
+    int used = 0;
+    for (int i = 0; i < threads; i++) {
+        size_t lo = (size_t)i * per, hi = lo + per < half ? lo + per : half;
+        if (lo >= hi) break;
+        jobs[i] = (collapse_job){F, &ur, g, out, half, lo, hi};
+        pthread_create(&th[i], NULL, collapse_worker, &jobs[i]);
+        used++;
+    }
+    for (int i = 0; i < used; i++) pthread_join(th[i], NULL);
+    for (size_t i = 0; i < half; i++) {
+        aff a; jac_to_affine(F, &a, &out[i]);
+        fe x, y; f_from_mont(F, &x, &a.x); f_from_mont(F, &y, &a.y);
+        memcpy(g_xy + 8 * i, &x, 32); memcpy(g_xy + 8 * i + 4, &y, 32);
+    }
+    free(g); free(out);
+    return 0;
+}

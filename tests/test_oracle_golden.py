@@ -138,3 +138,41 @@ def test_eval_polynomial(oracle_c):
     cs = [rng.randrange(F.p) for _ in range(33)]
     x = rng.randrange(F.p)
     assert C.eval_poly(0, C.ints_to_array(cs), x) == O.eval_polynomial(cs, x, F)
+
+
+def test_c_oracle_gate_eval_and_generator_collapse_match_the_bigint_oracle():
+    """The two C restatements the CPU baseline times (oracle/oracle.c: orc_gate_eval, orc_generator_collapse) against the
+    big-int oracle: y-folded constraint polynomials of the real ShotCircuit on random columns, and g_lo + [u] g_hi."""
+    import random
+    import numpy as np
+    import blob as Bm
+    import coracle as Cc
+    import halo2_oracle as Hh
+    import pasta as Oo
+    from bzh2 import circuits as Cm
+    lay = Cm.CircuitLayout(Cm.SHOT, 11)
+    circ = Bm.decode(lay.blob())
+    lay.close()
+    F = Oo.FP
+    rng = random.Random(3)
+    gates = circ.gates[:40]
+    prog, consts, colmap = Cc.compile_gates(gates)
+    size = 64
+    cols_int = {key: [rng.randrange(F.p) for _ in range(size)] for key in colmap}
+    cols = [None] * len(colmap)
+    for key, idx in colmap.items():
+        cols[idx] = Cc.ints_to_array(cols_int[key])
+    y = rng.randrange(F.p)
+    got = Cc.array_to_ints(Cc.gate_eval(0, prog, consts, cols, y, 5, 9, threads=2, rot_scale=8))
+    for r, g in zip(range(5, 9), got):
+        acc = 0
+        for e in gates:
+            v = Hh.expr_eval(e, lambda t, c, rot, r=r: cols_int[(t, c)][(r + 8 * rot) % size], F.p)
+            acc = (acc * y + v) % F.p
+        assert g == acc
+    cv = Oo.VESTA
+    pts = [cv.random_point(rng) for _ in range(8)]
+    u = rng.randrange(F.p)
+    want = [cv.add(pts[i], cv.mul(u, pts[4 + i])) for i in range(4)]
+    got = Cc.generator_collapse(0, Cc.points_to_array(pts), u, threads=2)
+    assert [Cc.array_to_point(got[i]) for i in range(4)] == want
