@@ -39,7 +39,7 @@ CURVE_SCALAR_FIELD = {CURVE_VESTA: FIELD_FP, CURVE_PALLAS: FIELD_FQ, CURVE_BN254
 # every symbol include/bzh2.h declares
 EXPORTS = [
     "bzh_version", "bzh_strerror", "bzh_device_count", "bzh_ctx_create", "bzh_ctx_create_on_stream",
-    "bzh_ctx_destroy", "bzh_ctx_sync", "bzh_last_error", "bzh_ctx_profile", "bzh_ctx_timings", "bzh_ctx_work",
+    "bzh_ctx_destroy", "bzh_ctx_sync", "bzh_last_error", "bzh_ctx_profile", "bzh_ctx_timings", "bzh_ctx_work", "bzh_ctx_msm_additions",
     "bzh_bases_upload", "bzh_bases_precompute", "bzh_bases_free", "bzh_bases_len", "bzh_msm", "bzh_ntt",
     "bzh_jacobian_to_affine", "bzh_jacobian_sum", "bzh_affine_compress", "bzh_field_omega",
 ]
@@ -183,6 +183,14 @@ class Context:
         load().bzh_ctx_work.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]
         self._check(load().bzh_ctx_work(self.handle, wb), "bzh_ctx_work")
         return {TIMER_NAMES[i]: {"ms": ms[i], "launches": int(n[i]), "algorithmic_bytes": wb[i]} for i in TIMER_NAMES}
+
+    def msm_additions(self) -> int:
+        """bucket additions made by the MSM accumulation since profile(True)"""
+        v = ctypes.c_uint64()
+        L = load()
+        L.bzh_ctx_msm_additions.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
+        self._check(L.bzh_ctx_msm_additions(self.handle, ctypes.byref(v)), "bzh_ctx_msm_additions")
+        return int(v.value)
 
     # ---- bases ----
     def upload_bases(self, curve: int, xy, n: int | None = None, form: int = FORM_CANONICAL, device_ptr: bool = False) -> Bases:
@@ -521,11 +529,11 @@ EXPORTS += ["bzh_expr_eval", "bzh_expr_eval_batch"]
 
 
 def _ctx_expr_eval(self, field: int, program, columns, form: int = FORM_CANONICAL) -> np.ndarray:
-    """Evaluate a compiled bzh2.expr.Program at every row; columns: list of (size, 4) uint64 arrays."""
-    from . import expr as _expr
+    """Evaluate a straight-line program (bzh_expr_op records: anything with .as_array() -> ctypes array of them, .ops, .consts,
+    .result_slot; tests/helpers/expr.py compiles expression trees into one) at every row; columns: list of (size, 4) uint64 arrays."""
     L = load()
     vp = ctypes.c_void_p
-    L.bzh_expr_eval.argtypes = [vp, ctypes.c_int, ctypes.POINTER(_expr.ExprOp), ctypes.c_size_t, ctypes.POINTER(vp), ctypes.c_size_t,
+    L.bzh_expr_eval.argtypes = [vp, ctypes.c_int, vp, ctypes.c_size_t, ctypes.POINTER(vp), ctypes.c_size_t,
                                 vp, ctypes.c_size_t, ctypes.c_uint, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]
     cols = [_as_elems(c) for c in columns]
     size = cols[0].shape[0] if cols else 1
@@ -536,7 +544,7 @@ def _ctx_expr_eval(self, field: int, program, columns, form: int = FORM_CANONICA
                                   else np.zeros((1, 4), dtype=np.uint64))
     out = np.zeros((size, 4), dtype=np.uint64)
     ops = program.as_array()
-    rc = L.bzh_expr_eval(self.handle, field, ops, len(program.ops), ptrs, len(cols), _vp(consts), len(program.consts), log_size,
+    rc = L.bzh_expr_eval(self.handle, field, ctypes.cast(ops, vp), len(program.ops), ptrs, len(cols), _vp(consts), len(program.consts), log_size,
                          program.result_slot, form, MEM_HOST, _vp(out))
     self._check(rc, "bzh_expr_eval")
     return out

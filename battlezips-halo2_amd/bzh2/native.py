@@ -1,7 +1,7 @@
 """Binding of the native whole-proof entry points (include/bzh2.h: bzh_pk_create / bzh_prove_batch).
 
 The reference-side call this stands behind is halo2_proofs::plonk::{keygen_pk, create_proof} (benches/shot.rs:58-71,
-benches/board.rs:51-71); the circuit crosses the boundary as data (bzh2.prover.serialize_circuit)."""
+benches/board.rs:51-71); the circuit crosses the boundary as data (bzh2.circuit_data.serialize_circuit, or a blob of bzh2.circuits.CircuitLayout)."""
 from __future__ import annotations
 
 import ctypes
@@ -9,7 +9,7 @@ import ctypes
 import numpy as np
 
 from . import CURVE_SCALAR_FIELD, FORM_CANONICAL, FORM_MONTGOMERY, MEM_DEVICE, MEM_HOST, Bases, Context, int_to_limbs, load
-from .prover import MODULI, Circuit, serialize_circuit
+from .circuit_data import MODULI, Circuit, serialize_circuit
 
 _VP = ctypes.c_void_p
 

@@ -290,6 +290,7 @@ int bzh_ctx_destroy(bzh_ctx* ctx) {
     ntt_cache_drop(ctx);
     for (int i = 0; i < bzh_ctx::kWsSlots; i++)
         if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
+    if (ctx->d_add_counter) (void)hipFree(ctx->d_add_counter);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
     if (ctx->pin_big) (void)hipHostFree(ctx->pin_big);
     for (auto& s : ctx->spans) {
@@ -336,7 +337,25 @@ int bzh_ctx_profile(bzh_ctx* ctx, int enable) {
         ctx->acc_n[i] = 0;
         ctx->alg_bytes[i] = 0;
     }
+    if (enable && !ctx->d_add_counter) {
+        BZH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+        BZH_HIP_TRY(ctx, hipMalloc((void**)&ctx->d_add_counter, 8));
+    }
+    if (ctx->d_add_counter) BZH_HIP_TRY(ctx, hipMemsetAsync(ctx->d_add_counter, 0, 8, ctx->stream));
     ctx->profiling = enable != 0;
+    return BZH_OK;
+}
+
+int bzh_ctx_msm_additions(bzh_ctx* ctx, uint64_t* additions) {
+    if (!ctx || !additions) return BZH_E_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    *additions = 0;
+    if (!ctx->d_add_counter) return BZH_OK;
+    BZH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    unsigned long long v = 0;
+    BZH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    BZH_HIP_TRY(ctx, hipMemcpy(&v, ctx->d_add_counter, 8, hipMemcpyDeviceToHost));
+    *additions = v;
     return BZH_OK;
 }
 

@@ -42,6 +42,7 @@ struct bzh_ctx {
     uint64_t acc_n[BZH_T_COUNT] = {0};
     double alg_bytes[BZH_T_COUNT] = {0};  // algorithmic bytes of the launches timed while profiling
     int num_cu = 256;
+    unsigned long long* d_add_counter = nullptr;   // device counter of bucket additions (non-zero window digits), while profiling
     bool msm_attr_set[3] = {false, false, false};  // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done on this ctx's device, per curve
     // pinned upload ring: small host->device copies stay asynchronous (a pageable hipMemcpyAsync waits for the copy)
     char* pin = nullptr;

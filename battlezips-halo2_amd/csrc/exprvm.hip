@@ -11,7 +11,7 @@
 //     CONST(i)        i-th constant (challenges, y, selectors folded by the host, ...)
 //     SLOT(s)         an earlier intermediate
 // with ops ADD / SUB / MUL / NEG / COPY, compiled on the host from halo2-style expression trees
-// (battlezips-halo2_amd/bzh2/expr.py).  One thread per row; intermediates live in a small private
+// (csrc/prove.hip: Compiler; tests/helpers/expr.py for the public bzh_expr_eval).  One thread per row; intermediates live in a small private
 // slot file.  Modular-integer VALU work, no MFMA.
 #include "ctx.hpp"
 #include "field.cuh"

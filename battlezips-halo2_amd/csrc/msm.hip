@@ -233,7 +233,8 @@ __global__ void __launch_bounds__(T) k_msm_accumulate(const uint32_t* __restrict
                                                                   const uint16_t* __restrict__ digits, size_t n, int nwin,
                                                                   int M, size_t chunk, uint4* __restrict__ buckets,
                                                                   uint4* __restrict__ partials, size_t row_len,
-                                                                  size_t row_stride, size_t dup_from) {
+                                                                  size_t row_stride, size_t dup_from,
+                                                                  unsigned long long* __restrict__ add_counter) {
     using P = typename C::Base;
     extern __shared__ __align__(16) uint32_t lds[];
     uint32_t* cnt = lds;  // index m in [0, M]; cnt[0] stays 0
@@ -308,6 +309,7 @@ __global__ void __launch_bounds__(T) k_msm_accumulate(const uint32_t* __restrict
     const bool remap = row_len != 0 && row_len != row_stride;
     const uint32_t* base0 = bases + c0 * 16;
     const uint32_t total = cnt[M], maxpop = scratch[31];
+    if (add_counter && tid == 0 && total) atomicAdd(add_counter, (unsigned long long)total);   // profiling: bucket additions actually made
     const uint32_t L = (total + T - 1) / T;
     const uint32_t start = min((uint32_t)tid * L, total), end = min(start + L, total);
 
@@ -1110,7 +1112,7 @@ static int msm_run_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_sca
 #define BZH_LAUNCH_ACC(TT)                                                                                              \
     hipLaunchKernelGGL((k_msm_accumulate<C, TT>), grid, dim3(TT), acc_lds, ctx->stream, bases->d_xy,                      \
                        (const uint16_t*)d_digits, n_eff, acc_nwin, M_acc, p.chunk, (uint4*)d_buckets, d_partials, row_len, \
-                       row_stride, pair_in ? n - 2 : (size_t)0)
+                       row_stride, pair_in ? n - 2 : (size_t)0, ctx->profiling ? ctx->d_add_counter : nullptr)
             if (acc_threads == 1024) BZH_LAUNCH_ACC(1024);
             else if (acc_threads == 512) BZH_LAUNCH_ACC(512);
             else BZH_LAUNCH_ACC(256);

@@ -6,7 +6,7 @@
 // src/circuits/shot.rs:915-930, src/circuits/board.rs:907-922: one call proves `batch` independent
 // witnesses of one circuit in lockstep -- every MSM, NTT, gate evaluation, scan and IPA round is ONE launch
 // carrying all of them -- with the protocol, message order and randomness draw order per proof of
-// create_proof, so each proof is byte-identical to the single-proof drivers (bzh2/prover_dev.py,
+// create_proof, so each proof is byte-identical to proving its witness alone (the staged test drivers tests/helpers/prover_dev.py,
 // oracle/halo2_oracle.py) under the same randomness stream.
 //
 // The circuit arrives as DATA (serialised constraint system + fixed assignment, format below): the reference's
@@ -225,8 +225,8 @@ struct EPool {
     }
 };
 
-// Sethi-Ullman ordered emission into at most BZH_EXPR_MAX_SLOTS live intermediates (bzh2/expr.py is the
-// Python twin); leaves are free operands
+// Sethi-Ullman ordered emission into at most BZH_EXPR_MAX_SLOTS live intermediates (VM v1; tests/helpers/expr.py
+// compiles the same format for the public bzh_expr_eval entry point); leaves are free operands
 struct Compiler {
     const EPool& pool;
     Program prog;

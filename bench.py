@@ -631,6 +631,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     timings = ctx.timings()
+    msm_adds = sum(c.msm_additions() for c in all_ctx)     # bucket additions actually made in the timed region (all contexts)
     for c in all_ctx[1:]:  # proofs in flight on their own ctx + stream: sum their kernel classes into the report
         for kname, v in c.timings().items():
             for f in v:
@@ -649,6 +650,7 @@ def main():
             wl.solo_step()
         torch.cuda.synchronize(device)
         solo = ctx.timings()
+        solo["msm_additions"] = ctx.msm_additions()
         ctx.profile(False)
     verified = None
     if hasattr(wl, "verify_last"):  # untimed: every proof of every thread's last batch through bzh_verify_batch
@@ -735,6 +737,11 @@ def main():
             wb = getattr(wl, "window_bits", 0) or 11
             nwin = (256 + wb - 1) // wb
             alu = {"peaks_source": peaks["source"]}
+            rate_a = msm_adds / (acc["ms"] * 1e-3) / 1e9
+            alu["k_msm_accumulate"] = {"unit": "G mixed additions/s", "achieved": rate_a, "peak": peaks["xyzz_madd"],
+                                       "frac": rate_a / peaks["xyzz_madd"] if peaks["xyzz_madd"] else None,
+                                       "additions_per_step": msm_adds / max(args.steps, 1), "table_rows": nwin,
+                                       "note": "bucket additions counted by the kernel (non-zero window digits only)"}
             if is_full and qt["ms"] > 0:
                 st = wl.runner.pks[0].quotient_stats()
                 rows = (1 << (wl.k + 3)) * wl.units_per_step * args.steps
@@ -757,7 +764,10 @@ def main():
                                "%d batches share the GPU and every launch stretches accordingly" % len(all_ctx),
                        "k_msm_accumulate": {"avg_launch_ms": s_acc["ms"] / max(s_acc["launches"], 1),
                                             "achieved_GBps": s_acc["algorithmic_bytes"] / s_acc["ms"] / 1e6,
-                                            "frac": s_acc["algorithmic_bytes"] / s_acc["ms"] / 1e6 / HBM_PEAK_GBS}}
+                                            "frac": s_acc["algorithmic_bytes"] / s_acc["ms"] / 1e6 / HBM_PEAK_GBS,
+                                            "G_mixed_additions_per_s": solo["msm_additions"] / (s_acc["ms"] * 1e-3) / 1e9,
+                                            "frac_of_xyzz_madd_peak": (solo["msm_additions"] / (s_acc["ms"] * 1e-3) / 1e9 / peaks["xyzz_madd"])
+                                            if peaks["xyzz_madd"] else None}}
                 if s_q["ms"] > 0:
                     st = wl.runner.pks[0].quotient_stats()
                     rows = (1 << (wl.k + 3)) * wl.runner.batch * 2

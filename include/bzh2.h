@@ -104,6 +104,9 @@ int bzh_ctx_timings(bzh_ctx* ctx, double* ms, uint64_t* launches);
 /* Algorithmic bytes (MSM 32*B*N + 64*N per launch, NTT 64*N per transform) of the launches timed since
  * profiling was enabled, per kernel class (BZH_T_COUNT entries); divides by bzh_ctx_timings' ms for GB/s. */
 int bzh_ctx_work(bzh_ctx* ctx, double* algorithmic_bytes);
+/* bucket additions the MSM accumulation made since profiling was enabled (one per non-zero window digit: zero scalars and
+ * zero digits of small scalars cost nothing) -- the work the integer multipliers actually did, for the ALU-side roofline */
+int bzh_ctx_msm_additions(bzh_ctx* ctx, uint64_t* additions);
 
 /* ---- commitment bases (Params.g / Params.g_lagrange of halo2's IPA params) -
  * Replaces the `bases: &[C]` argument of best_multiexp for tables that live

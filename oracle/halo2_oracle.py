@@ -12,7 +12,7 @@ the upstream source is unavailable, so byte parity with upstream is UNPINNED.  T
 rules, constraint order and multiopen grouping below follow the upstream design as documented in the halo2
 book and remembered from the crate; where that memory could be wrong the proof would differ from upstream in
 bytes but not in soundness -- the verifier below is an independent check of every prover message.  This module
-is what the GPU driver (battlezips-halo2_amd/bzh2/prover.py) is compared against, byte for byte, under a shared
+is what the product prover (csrc/prove.hip, bzh_prove_batch) is compared against, byte for byte, under a shared
 RNG stream.
 """
 from __future__ import annotations

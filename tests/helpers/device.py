@@ -1,4 +1,5 @@
-"""Device-resident field-element arrays for the prover pipeline: torch supplies HBM allocations and the
+"""TEST HELPER (not product code; the product path is libbzh2.so behind include/bzh2.h).
+Device-resident field-element arrays for the prover pipeline: torch supplies HBM allocations and the
 stream, every operation is a libbzh2.so call with BZH_MEM_DEVICE pointers in Montgomery form.  No torch
 type crosses the C ABI (only data_ptr() integers)."""
 from __future__ import annotations
@@ -8,7 +9,7 @@ import ctypes
 import numpy as np
 import torch
 
-from . import FORM_MONTGOMERY, MEM_DEVICE, Bases, Context, int_to_limbs, jacobian_to_affine, limbs_to_int, load
+from bzh2 import FORM_MONTGOMERY, MEM_DEVICE, Bases, Context, int_to_limbs, jacobian_to_affine, limbs_to_int, load
 from . import expr as X
 
 R256 = 1 << 256

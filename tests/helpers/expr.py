@@ -1,4 +1,5 @@
-"""Host-side expression trees and their compiler for bzh_expr_eval (row a13).
+"""TEST HELPER (not product code; the product path is libbzh2.so behind include/bzh2.h).
+Host-side expression trees and their compiler for bzh_expr_eval (row a13).
 
 Mirrors halo2_proofs::plonk::Expression<F> (UPSTREAM 0.2.0; built by every `meta.create_gate`
 of the reference: src/chips/bitify.rs:63-88, src/chips/placement.rs:126-265,

@@ -1,4 +1,5 @@
-"""Lockstep batch prover: B independent proofs of the same circuit advance phase by phase, so that every MSM, NTT,
+"""TEST HELPER (not product code; the product path is libbzh2.so behind include/bzh2.h).
+Lockstep batch prover: B independent proofs of the same circuit advance phase by phase, so that every MSM, NTT,
 gate-evaluation, scan and IPA round is ONE launch carrying all B proofs (throughput mode: the kernels of a single
 proof are latency-bound).  Protocol, message order and randomness draw order per proof are those of
 bzh2/prover_dev.create_proof, so proof b is byte-identical to what create_proof emits for witness b alone.
@@ -17,7 +18,7 @@ from concurrent.futures import ThreadPoolExecutor
 import numpy as np
 import torch
 
-from . import FORM_MONTGOMERY, permute_expression_pair
+from bzh2 import FORM_MONTGOMERY, permute_expression_pair
 from . import expr as X
 from .prover import _lagrange_interpolate, _query_sets, _Rng
 from .prover_dev import DeviceProvingKey, _horner

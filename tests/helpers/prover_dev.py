@@ -1,4 +1,5 @@
-"""Device-resident create_proof: the same protocol and message order as bzh2/prover.py (and therefore the same
+"""TEST HELPER (not product code; the product path is libbzh2.so behind include/bzh2.h).
+Device-resident create_proof: the same protocol and message order as bzh2/prover.py (and therefore the same
 proof bytes), with every polynomial kept in HBM as a Montgomery-form tensor.  Only challenges, blinds, a few
 single-row reads (the z(X) hand-over values), the lookup sort and the transcript run on the host.
 
@@ -9,7 +10,7 @@ from __future__ import annotations
 import numpy as np
 import torch
 
-from . import CURVE_SCALAR_FIELD, FORM_MONTGOMERY, Transcript, int_to_limbs, permute_expression_pair
+from bzh2 import CURVE_SCALAR_FIELD, FORM_MONTGOMERY, Transcript, int_to_limbs, permute_expression_pair
 from . import expr as X
 from .device import DeviceOps
 from .prover import MODULI, MULT_GEN, TWO_ADICITY, Circuit, _build_permutation, _lagrange_interpolate, _query_sets, _Rng

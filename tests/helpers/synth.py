@@ -1,4 +1,5 @@
-"""Synthetic circuits with the SHAPE of the reference's Shot / Board circuits, for benchmarking the prover.
+"""TEST HELPER (not product code; the product path is libbzh2.so behind include/bzh2.h).
+Synthetic circuits with the SHAPE of the reference's Shot / Board circuits, for benchmarking the prover.
 
 The real gate polynomials cannot be restated: 19 of Shot's 24 / Board's 57 gates come from the `halo2_gadgets`
 crate, which is not on disk.  What fixes the prover's cost is the shape:
@@ -11,7 +12,7 @@ from __future__ import annotations
 
 import random
 
-from .prover import Circuit, MODULI
+from bzh2.circuit_data import Circuit, MODULI
 
 
 def battlezips_shaped(k: int, seed: int = 1, field: int = 0):

@@ -87,7 +87,7 @@ def test_normalize_and_compress_match_oracle(bzh2_lib, cid):
 
 
 def test_cpp_example_client_compiles_against_the_header():
-    """examples/prove_batch.cpp is the compiled-code client of include/bzh2.h (what a Rust shim's call sequence looks like):
+    """examples/shot_prover.cpp (the reference's benches/shot.rs against the C ABI) is the compiled-code client of include/bzh2.h (what a Rust shim's call sequence looks like):
     it has to keep compiling with a plain C++ compiler against the header alone (no HIP, no torch)."""
     import shutil
     import subprocess
@@ -96,4 +96,4 @@ def test_cpp_example_client_compiles_against_the_header():
         pytest.skip("no g++")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     subprocess.check_call([cxx, "-std=c++17", "-fsyntax-only", "-Wall", "-I", os.path.join(root, "include"),
-                           os.path.join(root, "examples", "prove_batch.cpp")])
+                           os.path.join(root, "examples", "shot_prover.cpp")])

@@ -1,4 +1,4 @@
-"""Host logic of the gate-expression compiler (bzh2/expr.py, the Python twin of csrc/prove.hip's Compiler): the
+"""Host logic of the gate-expression compiler (tests/helpers/expr.py: compiles expression trees into the bzh_expr_op programs of the public bzh_expr_eval entry point): the
 straight-line program interpreted on the CPU must equal direct tree evaluation, with challenges bound late through
 Symbol leaves, within the evaluator's slot budget.  Mirrors halo2_proofs::plonk::Expression evaluation as used
 by the reference's gates (src/chips/bitify.rs:63-88, src/chips/placement.rs:126-265)."""
@@ -10,7 +10,7 @@ P = 0x40000000000000000000000000000000224698fc094cf91b992d30ed00000001
 
 
 def interpret(prog, consts, columns, row, size):
-    from bzh2 import expr as X
+    from helpers import expr as X
     slots = [None] * X.MAX_SLOTS
 
     def operand(o):
@@ -34,7 +34,7 @@ def interpret(prog, consts, columns, row, size):
 
 
 def random_tree(rng, depth, ncols):
-    from bzh2 import expr as X
+    from helpers import expr as X
     if depth == 0 or rng.random() < 0.15:
         r = rng.random()
         if r < 0.5:
@@ -53,7 +53,7 @@ def random_tree(rng, depth, ncols):
 
 @pytest.mark.parametrize("seed", range(6))
 def test_compiled_program_matches_tree_evaluation_with_late_bound_symbols(seed):
-    from bzh2 import expr as X
+    from helpers import expr as X
     rng = random.Random(seed)
     size, ncols = 16, 5
     cols = [[rng.randrange(P) for _ in range(size)] for _ in range(ncols)]
@@ -69,7 +69,7 @@ def test_compiled_program_matches_tree_evaluation_with_late_bound_symbols(seed):
 
 def test_horner_chain_of_many_terms_stays_within_the_slot_budget():
     """The quotient numerator is a Horner chain in y over dozens of gate terms: depth grows, live intermediates must not."""
-    from bzh2 import expr as X
+    from helpers import expr as X
     rng = random.Random(9)
     size = 8
     cols = [[rng.randrange(P) for _ in range(size)] for _ in range(4)]
@@ -86,10 +86,10 @@ def test_horner_chain_of_many_terms_stays_within_the_slot_budget():
 
 
 def test_serialized_circuit_blob_layout():
-    """bzh2.prover.serialize_circuit: the header and section counts of the blob bzh_pk_create parses (csrc/prove.hip)."""
+    """bzh2.circuit_data.serialize_circuit: the header and section counts of the blob bzh_pk_create parses (csrc/prove.hip)."""
     import halo2_oracle  # noqa: F401  (oracle path on sys.path via conftest)
     import sample_circuit as S
-    from bzh2 import prover as PR
+    from helpers import prover as PR
     cs, fixed, copies, adv, inst = S.build(k=4, seed=1, with_lookup=True)
     circ = PR.Circuit(cs.k, cs.num_advice, cs.num_fixed, cs.num_instance, cs.gates, cs.perm_columns, cs.lookups, fixed, copies)
     blob = PR.serialize_circuit(circ, P, vk_repr=7)

@@ -67,7 +67,8 @@ def test_k17_native_proof_passes_the_oracle_verifier(gpu_ctx, oracle_c, monkeypa
     delegated to the C oracle -- same definitions, the big-int loops would take hours), a tampered copy rejected."""
     import bzh2
     import halo2_oracle as H
-    from bzh2 import native as N, synth
+    from bzh2 import native as N
+    from helpers import synth
     cv, F = O.VESTA, O.FP
     k = 17
     circ, adv, inst = synth.battlezips_shaped(k, seed=1717)

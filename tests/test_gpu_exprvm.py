@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 
 def rand_tree(rng, ncols, depth, p):
-    from bzh2.expr import Constant, Negated, Product, Query, Scaled, Sum
+    from helpers.expr import Constant, Negated, Product, Query, Scaled, Sum
     if depth == 0 or rng.random() < 0.15:
         if rng.random() < 0.75:
             return Query(rng.randrange(ncols), rng.choice([0, 0, 8, -8, 16, -24]))
@@ -32,7 +32,7 @@ def rand_tree(rng, ncols, depth, p):
 
 @pytest.mark.parametrize("seed", range(8))
 def test_random_expression_trees(gpu_ctx, seed):
-    from bzh2 import expr
+    from helpers import expr
     F = O.FP
     rng = random.Random(seed)
     size, ncols = 256, 6
@@ -48,7 +48,7 @@ def test_num2bits_and_permutation_shaped_gates_folded_with_y(gpu_ctx):
     """Gate shapes of the reference folded Horner-style with a challenge y, as vanishing::construct does:
     bitify (src/chips/bitify.rs:63-88): bit*(1-bit), e2' - 2*e2, lc1' - lc1 - bit*e2;
     plus a permutation-product shaped term z(wX)*(a+beta*s+gamma) - z(X)*(a+beta*id+gamma)."""
-    from bzh2.expr import Constant, Product, Query, Sum, compile_expression, evaluate_tree
+    from helpers.expr import Constant, Product, Query, Sum, compile_expression, evaluate_tree
     F = O.FQ
     rng = random.Random(42)
     size, ext = 1 << 10, 8
@@ -73,7 +73,7 @@ def test_num2bits_and_permutation_shaped_gates_folded_with_y(gpu_ctx):
 
 def test_program_validation(gpu_ctx):
     import bzh2
-    from bzh2 import expr
+    from helpers import expr
     prog = expr.compile_expression(expr.Query(0) * expr.Query(3), O.P)   # column 3 does not exist below
     with pytest.raises(bzh2.BzhError):
         gpu_ctx.expr_eval(0, prog, [np.zeros((8, 4), dtype=np.uint64)])

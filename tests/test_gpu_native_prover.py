@@ -29,7 +29,7 @@ def _adv_array(adv, n):
 @pytest.mark.parametrize("k,with_lookup,degree,batch", [(4, False, None, 1), (5, True, None, 3), (6, True, 9, 2)])
 def test_native_prove_batch_matches_oracle(gpu_ctx, oracle_c, k, with_lookup, degree, batch):
     import bzh2
-    from bzh2 import native as N, prover as P
+    from bzh2 import native as N, circuit_data as P
     cv, F = O.VESTA, O.FP
     cases = [S.build(k=k, seed=500 + 11 * b + k, with_lookup=with_lookup, degree=degree) for b in range(batch)]
     cs, fixed, copies = cases[0][:3]
@@ -59,10 +59,11 @@ def test_native_prove_batch_matches_oracle(gpu_ctx, oracle_c, k, with_lookup, de
 
 
 def test_native_prover_battlezips_shaped_and_unsatisfied_witness(gpu_ctx, oracle_c):
-    """The benchmark circuit (bzh2/synth.py) at k = 7 through the native entry point; a broken witness must come back
+    """The benchmark circuit (tests/helpers/synth.py) at k = 7 through the native entry point; a broken witness must come back
     as BZH_E_RANGE (surplus quotient coefficients) or as a proof the oracle verifier rejects."""
     import bzh2
-    from bzh2 import native as N, synth
+    from bzh2 import native as N
+    from helpers import synth
     cv, F = O.VESTA, O.FP
     built = [synth.battlezips_shaped(7, seed=60 + b) for b in range(2)]
     circ = built[0][0]
@@ -99,7 +100,7 @@ def test_native_verify_batch_agrees_with_oracle_verifier(gpu_ctx, oracle_c, k, w
     valid proofs (made by the ORACLE prover, so prover and verifier here are independent), and rejects a wrong instance,
     flipped bytes in every section of the proof, a truncated proof and a non-canonical scalar."""
     import bzh2
-    from bzh2 import native as N, prover as P
+    from bzh2 import native as N, circuit_data as P
     cv, F = O.VESTA, O.FP
     cs, fixed, copies, adv, inst = S.build(k=k, seed=900 + k, with_lookup=with_lookup, degree=degree)
     rng, g, w, u = _setup(cs, 5000 + k)
@@ -134,7 +135,8 @@ def test_native_verify_batch_agrees_with_oracle_verifier(gpu_ctx, oracle_c, k, w
 def test_native_prove_then_verify_roundtrip_shaped(gpu_ctx, oracle_c):
     """The benchmark circuit at k = 8: bzh_prove_batch -> bzh_verify_batch accepts all; swapping instances rejects."""
     import bzh2
-    from bzh2 import native as N, synth
+    from bzh2 import native as N
+    from helpers import synth
     built = [synth.battlezips_shaped(8, seed=80 + b) for b in range(3)]
     circ = built[0][0]
     cs = H.ConstraintSystem(circ.k, 11, 8, 1, circ.gates, circ.perm_columns, circ.lookups, degree=9)
@@ -157,8 +159,8 @@ def test_native_prover_device_resident_witness_and_error_paths(gpu_ctx, oracle_c
     host canonical path; a short randomness stream is BZH_E_ARG; a lookup input outside its table is BZH_E_RANGE."""
     import torch
     import bzh2
-    from bzh2 import native as N, prover as P
-    from bzh2.device import DeviceOps
+    from bzh2 import native as N, circuit_data as P
+    from helpers.device import DeviceOps
     cv, F = O.VESTA, O.FP
     cs, fixed, copies, adv, inst = S.build(k=5, seed=31, with_lookup=True)
     rng, g, w, u = _setup(cs, 6001)
@@ -200,7 +202,7 @@ def test_native_prover_minimal_circuit_without_instance_permutation_or_lookup(gp
     """Degenerate shapes: no instance column, no permutation argument, no lookup -- one multiplication gate with a rotated
     query.  Prover bytes equal the oracle's, both verifiers accept, a broken row is rejected."""
     import bzh2
-    from bzh2 import native as N, prover as P
+    from bzh2 import native as N, circuit_data as P
     cv, F = O.VESTA, O.FP
     p = F.p
     k, n = 4, 16
@@ -246,7 +248,8 @@ def test_reference_size_native_proofs_pass_the_oracle_verifier(gpu_ctx, oracle_c
     checked by the ORACLE's verify_proof (its n-term MSMs delegated to the C oracle, or the big-int sums would take hours);
     a proof with one flipped byte is rejected by both verifiers."""
     import bzh2
-    from bzh2 import native as N, synth
+    from bzh2 import native as N
+    from helpers import synth
     cv, F = O.VESTA, O.FP
     circ, adv, inst = synth.battlezips_shaped(k, seed=123)
     cs = H.ConstraintSystem(circ.k, 11, 8, 1, circ.gates, circ.perm_columns, circ.lookups, degree=9)

@@ -1,4 +1,4 @@
-"""Row a1: the GPU create_proof driver (bzh2/prover.py) against the big-int oracle prover
+"""Row a1: the staged Python drivers over the leaf C ABI (tests/helpers/prover*.py: test helpers, not the product prover) against the big-int oracle prover
 (oracle/halo2_oracle.py): SAME proof bytes under a shared RNG byte stream, and the oracle verifier
 accepts them (and rejects a wrong instance).  Call sites of the reference: create_proof
 benches/shot.rs:68, src/circuits/board.rs:913-920; verify_proof benches/board.rs:80-86."""
@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("k,with_lookup,degree", [(4, False, None), (5, True, None), (5, True, 6), (6, True, 9)])
 def test_create_proof_bytes_match_oracle(gpu_ctx, oracle_c, k, with_lookup, degree):
     import bzh2
-    from bzh2 import prover as P
+    from helpers import prover as P
     cv, F = O.VESTA, O.FP
     cs, fixed, copies, adv, inst = S.build(k=k, seed=10 + k, with_lookup=with_lookup, degree=degree)
     rng = random.Random(1000 + k)
@@ -44,7 +44,7 @@ def test_unsatisfied_witness_yields_a_rejected_proof(gpu_ctx, oracle_c):
     """create_proof does not check satisfiability (neither does upstream: benches/shot.rs proves an
     unsatisfiable witness); the proof it emits for a broken witness must not verify."""
     import bzh2
-    from bzh2 import prover as P
+    from helpers import prover as P
     cv, F = O.VESTA, O.FP
     cs, fixed, copies, adv, inst = S.build(k=5, seed=3, with_lookup=False)
     adv[2][0] = (adv[2][0] + 1) % F.p                   # break the running-sum gate
@@ -77,7 +77,7 @@ def stream_ctx(gpu_ctx):
 def test_device_resident_prover_bytes_match_oracle(stream_ctx, oracle_c, k, with_lookup, degree):
     import torch
     import bzh2
-    from bzh2 import prover as P, prover_dev as D
+    from helpers import prover as P, prover_dev as D
     cv, F = O.VESTA, O.FP
     cs, fixed, copies, adv, inst = S.build(k=k, seed=20 + k, with_lookup=with_lookup, degree=degree)
     rng = random.Random(2000 + k)
@@ -97,11 +97,11 @@ def test_device_resident_prover_bytes_match_oracle(stream_ctx, oracle_c, k, with
 
 
 def test_battlezips_shaped_circuit_proof_matches_oracle(stream_ctx, oracle_c):
-    """The benchmark circuit (bzh2/synth.py: 11 advice / 8 fixed / 13 permutation columns / degree 9 / one lookup /
+    """The benchmark circuit (tests/helpers/synth.py: 11 advice / 8 fixed / 13 permutation columns / degree 9 / one lookup /
     24 gates) at k = 7: device-resident proof == oracle proof, and the oracle verifier accepts it."""
     import torch
     import bzh2
-    from bzh2 import prover_dev as D, synth
+    from helpers import prover_dev as D, synth
     cv, F = O.VESTA, O.FP
     circ, adv, inst = synth.battlezips_shaped(7, seed=5)
     cs = H.ConstraintSystem(circ.k, 11, 8, 1, circ.gates, circ.perm_columns, circ.lookups, degree=9)
@@ -122,12 +122,12 @@ def test_battlezips_shaped_circuit_proof_matches_oracle(stream_ctx, oracle_c):
 
 @pytest.mark.parametrize("k,with_lookup,degree,batch", [(4, False, None, 2), (5, True, None, 3), (6, True, 9, 3)])
 def test_lockstep_batch_prover_each_proof_matches_oracle(stream_ctx, oracle_c, k, with_lookup, degree, batch):
-    """bzh2/prover_batch.create_proofs: `batch` different witnesses of one circuit proven in lockstep (one launch per
+    """tests/helpers/prover_batch.create_proofs: `batch` different witnesses of one circuit proven in lockstep (one launch per
     kernel class per phase for all of them); proof b must be byte-identical to the oracle's proof of witness b under
     proof b's own randomness stream."""
     import torch
     import bzh2
-    from bzh2 import prover as P, prover_batch as PB, prover_dev as D
+    from helpers import prover as P, prover_batch as PB, prover_dev as D
     cv, F = O.VESTA, O.FP
     cases = [S.build(k=k, seed=300 + 7 * b + k, with_lookup=with_lookup, degree=degree) for b in range(batch)]
     cs, fixed, copies = cases[0][:3]
@@ -160,7 +160,7 @@ def test_lockstep_batch_prover_battlezips_shaped(stream_ctx, oracle_c):
     """The benchmark circuit at k = 7, two witnesses in lockstep with the witness tensor resident in HBM (bench.py's path)."""
     import torch
     import bzh2
-    from bzh2 import prover_batch as PB, prover_dev as D, synth
+    from helpers import prover_batch as PB, prover_dev as D, synth
     cv, F = O.VESTA, O.FP
     built = [synth.battlezips_shaped(7, seed=40 + b) for b in range(2)]
     circ = built[0][0]
