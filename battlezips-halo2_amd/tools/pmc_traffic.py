@@ -32,7 +32,8 @@ def main():
         f, nf = fetch.get(k, (0.0, 0))
         w, nw = write.get(k, (0.0, 0))
         out["kernels"].append({"kernel": k[0], "workgroup": int(k[1]), "grid": int(k[2]), "launches": max(nf, nw),
-                               "read_bytes": f * 1024 * 2, "write_bytes": w * 1024, "hbm_bytes": f * 1024 * 2 + w * 1024})
+                               "read_bytes": f * 1024 * 2, "read_bytes_raw": f * 1024, "write_bytes": w * 1024,
+                               "hbm_bytes": f * 1024 * 2 + w * 1024})
     json.dump(out, open(sys.argv[3], "w"), indent=1)
     for e in out["kernels"]:
         if "bzh" in e["kernel"]:
