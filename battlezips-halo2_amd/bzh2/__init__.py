@@ -40,7 +40,7 @@ CURVE_SCALAR_FIELD = {CURVE_VESTA: FIELD_FP, CURVE_PALLAS: FIELD_FQ, CURVE_BN254
 EXPORTS = [
     "bzh_version", "bzh_strerror", "bzh_device_count", "bzh_ctx_create", "bzh_ctx_create_on_stream",
     "bzh_ctx_destroy", "bzh_ctx_sync", "bzh_last_error", "bzh_ctx_profile", "bzh_ctx_timings", "bzh_ctx_work", "bzh_ctx_msm_additions",
-    "bzh_bases_upload", "bzh_bases_precompute", "bzh_bases_free", "bzh_bases_len", "bzh_msm", "bzh_ntt",
+    "bzh_bases_upload", "bzh_bases_precompute", "bzh_bases_free", "bzh_bases_len", "bzh_msm", "bzh_ntt", "bzh_coeff_to_extended",
     "bzh_jacobian_to_affine", "bzh_jacobian_sum", "bzh_affine_compress", "bzh_field_omega",
 ]
 
@@ -243,6 +243,29 @@ class Context:
                             _u64(cs) if cs is not None else None, int(inverse), form, MEM_HOST)
         self._check(rc, "bzh_ntt")
         return a.reshape(shape)
+
+    def coeff_to_extended(self, field: int, coeffs: np.ndarray, log_ext: int, omega_ext: int | None = None,
+                          coset_shift: int | None = None, form: int = FORM_CANONICAL) -> np.ndarray:
+        """EvaluationDomain::coeff_to_extended over (batch, n, 4) or (n, 4) uint64 coefficients -> (batch, 2^log_ext, 4)."""
+        a = np.ascontiguousarray(coeffs, dtype=np.uint64)
+        squeeze = a.ndim == 2
+        if squeeze:
+            a = a.reshape(1, *a.shape)
+        batch, n = a.shape[0], a.shape[1]
+        log_n = n.bit_length() - 1
+        if n != 1 << log_n:
+            raise BzhError(E_ARG, "bzh_coeff_to_extended", "length must be a power of two")
+        w = field_omega(field, log_ext, form) if omega_ext is None else int_to_limbs(omega_ext)
+        sh = None if coset_shift is None else int_to_limbs(coset_shift)
+        out = np.zeros((batch, 1 << log_ext, 4), dtype=np.uint64)
+        L = load()
+        L.bzh_coeff_to_extended.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint, ctypes.c_void_p, ctypes.c_uint,
+                                            ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64),
+                                            ctypes.c_int, ctypes.c_int]
+        rc = L.bzh_coeff_to_extended(self.handle, field, ctypes.c_void_p(a.ctypes.data), log_n, ctypes.c_void_p(out.ctypes.data), log_ext,
+                                     batch, _u64(w), _u64(sh) if sh is not None else None, form, MEM_HOST)
+        self._check(rc, "bzh_coeff_to_extended")
+        return out[0] if squeeze else out
 
     def ntt_device(self, field: int, data_ptr: int, log_n: int, batch: int, omega: np.ndarray,
                    coset_shift: np.ndarray | None = None, inverse: bool = False, form: int = FORM_MONTGOMERY):

@@ -474,6 +474,62 @@ int bzh_ntt(bzh_ctx* ctx, int field, uint64_t* data, unsigned log_n, size_t batc
     return BZH_OK;
 }
 
+// 4 host limbs, canonical -> Montgomery in place
+static int host_to_montgomery(int field, uint64_t* v) {
+    switch (field) {
+        case BZH_FIELD_FP: store_host<FpParams>(v, load_host<FpParams>(v, BZH_FORM_CANONICAL), BZH_FORM_MONTGOMERY); return BZH_OK;
+        case BZH_FIELD_FQ: store_host<FqParams>(v, load_host<FqParams>(v, BZH_FORM_CANONICAL), BZH_FORM_MONTGOMERY); return BZH_OK;
+        case BZH_FIELD_BN254_FR: store_host<BnFrParams>(v, load_host<BnFrParams>(v, BZH_FORM_CANONICAL), BZH_FORM_MONTGOMERY); return BZH_OK;
+        case BZH_FIELD_BN254_FQ: store_host<BnFqParams>(v, load_host<BnFqParams>(v, BZH_FORM_CANONICAL), BZH_FORM_MONTGOMERY); return BZH_OK;
+    }
+    return BZH_E_ARG;
+}
+
+int bzh_coeff_to_extended(bzh_ctx* ctx, int field, const uint64_t* coeffs, unsigned log_n, uint64_t* out, unsigned log_ext,
+                          size_t batch, const uint64_t* omega_ext, const uint64_t* coset_shift, int form, int mem) {
+    if (!ctx || !coeffs || !out || !omega_ext || !valid_field(field) || !valid_form(form) || !valid_mem(mem)) return BZH_E_ARG;
+    if (log_ext > field_two_adicity(field) || log_ext > 30 || log_n > log_ext) return BZH_E_RANGE;
+    if (batch == 0) return BZH_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    BZH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t in_elems = batch << log_n, out_elems = batch << log_ext;
+    const uint32_t* d_in = (const uint32_t*)coeffs;
+    uint32_t* d_out = (uint32_t*)out;
+    void* stage = nullptr;
+    if (mem == BZH_MEM_HOST || form == BZH_FORM_CANONICAL) {
+        // staged copy of the coefficients (host memory, or canonical device input that may not be written to)
+        int rc = ws_ensure(ctx, 3, (in_elems + (mem == BZH_MEM_HOST ? out_elems : 0)) * 32, &stage);
+        if (rc) return rc;
+        BZH_HIP_TRY(ctx, hipMemcpyAsync(stage, coeffs, in_elems * 32, mem == BZH_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice,
+                                        ctx->stream));
+        d_in = (const uint32_t*)stage;
+        if (mem == BZH_MEM_HOST) d_out = (uint32_t*)stage + in_elems * 8;
+        if (form == BZH_FORM_CANONICAL) {
+            rc = field_convert(ctx, field, (uint32_t*)stage, in_elems, 1);
+            if (rc) return rc;
+        }
+    }
+    uint64_t w[4], sh[4];
+    memcpy(w, omega_ext, 32);
+    if (coset_shift) memcpy(sh, coset_shift, 32);
+    if (form == BZH_FORM_CANONICAL) {
+        int rc = host_to_montgomery(field, w);
+        if (!rc && coset_shift) rc = host_to_montgomery(field, sh);
+        if (rc) return rc;
+    }
+    int rc = ntt_run_padded(ctx, field, d_out, d_in, log_n, log_ext, batch, w, coset_shift ? sh : nullptr);
+    if (rc) return rc;
+    if (form == BZH_FORM_CANONICAL) {
+        rc = field_convert(ctx, field, d_out, out_elems, 0);
+        if (rc) return rc;
+    }
+    if (mem == BZH_MEM_HOST) {
+        BZH_HIP_TRY(ctx, hipMemcpyAsync(out, d_out, out_elems * 32, hipMemcpyDeviceToHost, ctx->stream));
+        BZH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return BZH_OK;
+}
+
 #define BZH_POLY_PROLOGUE(cond_args)                                                            \
     if (!ctx || !valid_field(field) || !valid_form(form) || !valid_mem(mem) || (cond_args)) return BZH_E_ARG; \
     std::lock_guard<std::mutex> lk(ctx->mu);                                                    \

@@ -14,6 +14,15 @@
 // (B = 1) reads W rows whose digit-reversed indices are consecutive and writes
 // X[digitrev(a) + A*k_r], which makes the final order natural with W*32-byte
 // contiguous runs on both sides.  Modular-integer work, no MFMA.
+//
+// Inside a tile the radix-2 stages run three at a time on 8 rows held in registers (stage_group): one LDS
+// round trip and one barrier per three stages, and the twiddles equal to 1 in the first group are skipped.
+// The inter-pass twiddles omega_N^(A*row*j) come from a per-pass R x B table read like the data (one multiply
+// per element instead of two; domains up to 2^20), the two-level power table above that.  coeff_to_extended
+// (ntt_run_padded) reads only the 2^k coefficients: the first log2(8) stages of a zero-padded vector only
+// replicate values, so pass 0 skips them along with 7/8 of its loads and the padded copy.
+// Measured (tools/ubench_ntt.py, profiles/r02_ubench_ntt.txt): the kernel runs at ~70 % of the VALU bound its
+// own multiply/add counts give at two waves per SIMD.
 #include <cstring>
 #include <vector>
 
@@ -23,7 +32,7 @@
 namespace bzh {
 
 static constexpr int kTileElems = 2048;  // 64 KiB of LDS per workgroup
-static constexpr int kNttThreads = 256;  // 512 measured slower (130 VGPRs: still one 8-wave workgroup per CU)
+static constexpr int kNttThreads = 256;  // two 4-wave workgroups per CU (LDS-bound); 172 VGPRs
 
 struct NttPassArgs {
     const uint32_t* src;  // pass input  (same index map as dst)
@@ -40,6 +49,7 @@ struct NttPassArgs {
     const uint32_t* sub_tw;  // omega_R^j, j < R/2
     const uint32_t* tw_lo;   // omega_N^e, e < 2^h
     const uint32_t* tw_hi;   // omega_N^(e << h)
+    const uint32_t* tw_direct;  // this pass's inter-pass twiddles as an R x B table (row-major, read like the data); or null
     int h;
     const uint32_t* pre_lo;  // first pass: element n *= pre(n)   (coset shift^n)
     const uint32_t* pre_hi;
@@ -50,6 +60,8 @@ struct NttPassArgs {
     int cube_pre;   // first pass: element n *= cube[n % 3] (cube[0] == 1 is skipped)
     int cube_post;  // last pass:  output k *= cube[k % 3]
     int tw_always;  // this pass's twiddle table carries a folded n^-1: apply it even when the exponent is 0
+    int nz;         // first pass of a zero-padded transform: the source holds N >> nz coefficients per vector (rows
+                    // >= R >> nz are zero and are not read); the first nz stages then only replicate values
     uint32_t cube[3][8];
 };
 
@@ -81,8 +93,46 @@ __device__ __forceinline__ Fe<P> cube_const(const NttPassArgs& g, unsigned i) {
 }
 __device__ __forceinline__ uint32_t bitrev(uint32_t x, int bits) { return bits ? (__brev(x) >> (32 - bits)) : 0u; }
 
+// C consecutive radix-2 DIT stages (s0 .. s0+C-1) on 2^C tile rows held in registers: one LDS read and one
+// LDS write per element for the C stages.  Rows of a group: (hi << (s0+C)) | (m << s0) | lo, m < 2^C.
+// FIRST (s0 == 0): the stage twiddles are the compile-time powers of omega_2^C, and the ones equal to 1 are skipped.
+template <class P, int C, bool FIRST>
+__device__ __forceinline__ void stage_group(uint4* tile, const NttPassArgs& g, int s0, int items, int tid) {
+    constexpr int E = 1 << C;
+    const int r = g.r, logW = g.logW, W = 1 << logW;
+    const int ngroups = items >> C;
+    const int stride = 1 << (s0 + logW);
+    for (int gi = tid; gi < ngroups; gi += kNttThreads) {
+        const int col = gi & (W - 1), gg = gi >> logW;
+        const int lo = gg & ((1 << s0) - 1), hi = gg >> s0;
+        const int base = ((((hi << C) << s0) | lo) << logW) + col;
+        Fe<P> x[E];
+#pragma unroll
+        for (int m = 0; m < E; m++) x[m] = tile_get<P>(tile, base + m * stride);
+#pragma unroll
+        for (int t = 0; t < C; t++) {
+            const int sh = r - 1 - (s0 + t);  // stage s = s0 + t uses omega_R^(j << sh), j < 2^s
+#pragma unroll
+            for (int b = 0; b < E / 2; b++) {
+                const int jm = b & ((1 << t) - 1), top = ((b >> t) << (t + 1)) + jm, bot = top + (1 << t);
+                Fe<P> v = x[bot];
+                if (!(FIRST && jm == 0)) {
+                    const int j = FIRST ? jm : (lo | (jm << s0));
+                    v = fe_mul(v, fe_load<P>(g.sub_tw + ((size_t)j << sh) * 8));
+                }
+                x[bot] = fe_sub(x[top], v);
+                x[top] = fe_add(x[top], v);
+            }
+            // keep the next stage's twiddle loads behind this stage: hoisting all of them costs ~90 VGPRs and spills
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int m = 0; m < E; m++) tile_put(tile, base + m * stride, x[m]);
+    }
+}
+
 template <class P>
-__global__ void __launch_bounds__(kNttThreads) k_ntt_pass(NttPassArgs g) {
+__global__ void __launch_bounds__(kNttThreads) __attribute__((amdgpu_waves_per_eu(2))) k_ntt_pass(NttPassArgs g) {
     __shared__ __align__(16) uint4 tile[2 * kTileElems];
     const int tid = threadIdx.x, T = kNttThreads;
     const int r = g.r, R = 1 << r, logW = g.logW, W = 1 << logW;
@@ -97,6 +147,21 @@ __global__ void __launch_bounds__(kNttThreads) k_ntt_pass(NttPassArgs g) {
         const size_t tiles_per_a = B >> logW;
         const size_t a = tile_id / tiles_per_a, j0 = (tile_id - a * tiles_per_a) << logW;
         const uint32_t* base = vin + ((a << (r + g.logB)) + j0) * 8;
+        if (g.nz) {  // A == 1, a == 0
+            const uint32_t* sv = g.src + (size_t)blockIdx.y * (N >> g.nz) * 8 + j0 * 8;
+            const int live = items >> g.nz;
+            for (int it = tid; it < live; it += T) {
+                const int col = it & (W - 1), row = it >> logW;
+                Fe<P> v = fe_load<P>(sv + ((size_t)row * B + col) * 8);
+                if (g.pre_lo) v = fe_mul(v, pow_table<P>(g.pre_lo, g.pre_hi, g.h, (size_t)row * B + j0 + col));
+                if (g.cube_pre) {
+                    const unsigned c3 = (unsigned)(((size_t)row * B + j0 + col) % 3);
+                    if (c3) v = fe_mul(v, cube_const<P>(g, c3));
+                }
+                const int p0 = (int)(bitrev((uint32_t)row, r) << logW) + col;  // low nz bits of the tile row are zero
+                for (int m = 0; m < (1 << g.nz); m++) tile_put(tile, p0 + (m << logW), v);
+            }
+        } else
         for (int it = tid; it < items; it += T) {
             const int col = it & (W - 1), row = it >> logW;
             Fe<P> v = fe_load<P>(base + ((size_t)row * B + col) * 8);
@@ -122,19 +187,27 @@ __global__ void __launch_bounds__(kNttThreads) k_ntt_pass(NttPassArgs g) {
             tile_put(tile, (int)(bitrev((uint32_t)rr, r) << logW) + i, v);
         }
     }
-    // radix-2 DIT stages over the tile rows
-    const int nbf = items >> 1;
-    for (int s = 0; s < r; s++) {
-        __syncthreads();
-        const int half = 1 << s;
-        for (int it = tid; it < nbf; it += T) {
-            const int col = it & (W - 1), bf = it >> logW;
-            const int j = bf & (half - 1), grp = bf >> s;
-            const int top = (((grp << (s + 1)) + j) << logW) + col, bot = top + (half << logW);
-            Fe<P> u = tile_get<P>(tile, top), v = tile_get<P>(tile, bot);
-            if (s > 0) v = fe_mul(v, fe_load<P>(g.sub_tw + ((size_t)j << (r - 1 - s)) * 8));
-            tile_put(tile, top, fe_add(u, v));
-            tile_put(tile, bot, fe_sub(u, v));
+    // radix-2 DIT stages over the tile rows, up to three stages per LDS round trip (stage_group)
+    {
+        int s0 = g.nz ? g.nz : (r < 3 ? r : 3);
+        if (!g.nz) {
+            __syncthreads();
+            switch (s0) {
+                case 1: stage_group<P, 1, true>(tile, g, 0, items, tid); break;
+                case 2: stage_group<P, 2, true>(tile, g, 0, items, tid); break;
+                default: stage_group<P, 3, true>(tile, g, 0, items, tid); break;
+            }
+        }
+        int ngr = (r - s0 + 2) / 3;
+        for (; ngr > 0; ngr--) {
+            const int c = (r - s0 + ngr - 1) / ngr;  // split what is left as evenly as possible
+            __syncthreads();
+            switch (c) {
+                case 1: stage_group<P, 1, false>(tile, g, s0, items, tid); break;
+                case 2: stage_group<P, 2, false>(tile, g, s0, items, tid); break;
+                default: stage_group<P, 3, false>(tile, g, s0, items, tid); break;
+            }
+            s0 += c;
         }
     }
     __syncthreads();
@@ -146,8 +219,12 @@ __global__ void __launch_bounds__(kNttThreads) k_ntt_pass(NttPassArgs g) {
         for (int it = tid; it < items; it += T) {
             const int col = it & (W - 1), row = it >> logW;
             Fe<P> v = tile_get<P>(tile, it);
-            const size_t e = ((size_t)row * (j0 + col)) << g.logA;
-            if (e || g.tw_always) v = fe_mul(v, pow_table<P>(g.tw_lo, g.tw_hi, g.h, e));
+            if (g.tw_direct) {
+                v = fe_mul(v, fe_load<P>(g.tw_direct + ((size_t)row * B + j0 + col) * 8));
+            } else {
+                const size_t e = ((size_t)row * (j0 + col)) << g.logA;
+                if (e || g.tw_always) v = fe_mul(v, pow_table<P>(g.tw_lo, g.tw_hi, g.h, e));
+            }
             fe_store(base + ((size_t)row * B + col) * 8, v);
         }
     } else {
@@ -179,6 +256,7 @@ struct NttDomain {
     int shift_is_cube;        // shift^3 == 1, shift != 1
     uint32_t cube[3][8];      // forward: 1, s, s^2 ; inverse: n^-1, n^-1 s^-1, n^-1 s^-2 (s = 1 without a shift)
     size_t off_sub[12];  // sub-NTT twiddles for radix bits 1..11
+    size_t off_direct[4];  // per non-final pass: omega^(A*row*j) (x n^-1 on pass 0 of a plain inverse), R x B; 0 = none
 };
 
 struct NttCache {
@@ -220,6 +298,19 @@ static Fe<P> pow2k(Fe<P> x, int k) {
     return x;
 }
 
+// Pass plan: one pass up to 2^11, else ceil(k/9) passes of near-equal radix bits.
+static int plan_passes(unsigned log_n, int* bits) {
+    if (log_n <= 11) {
+        bits[0] = (int)log_n;
+        return 1;
+    }
+    const int np = (int)((log_n + 8) / 9);
+    const int base = (int)log_n / np, extra = (int)log_n % np;
+    for (int i = 0; i < np; i++) bits[i] = base + (i < extra ? 1 : 0);
+    return np;
+}
+static constexpr unsigned kDirectTwiddleMaxLog = 20;  // 32 MiB per table at 2^20; larger domains use the two-level table
+
 template <class P>
 static int build_domain(bzh_ctx* ctx, NttDomain& d, const Fe<P>& omega_m, const Fe<P>* shift_m) {
     const unsigned k = d.log_n;
@@ -236,6 +327,17 @@ static int build_domain(bzh_ctx* ctx, NttDomain& d, const Fe<P>& omega_m, const 
     for (int rb = 1; rb <= 11; rb++) {
         d.off_sub[rb] = words;
         if ((unsigned)rb <= k) words += ((size_t)1 << (rb - 1)) * 8;
+    }
+    int bits[5];
+    const int np = plan_passes(k, bits);
+    for (int p = 0; p < 4; p++) d.off_direct[p] = 0;
+    if (np >= 2 && k <= kDirectTwiddleMaxLog) {
+        int logA = 0;
+        for (int p = 0; p + 1 < np; p++) {
+            d.off_direct[p] = words;
+            words += (N >> logA) * 8;
+            logA += bits[p];
+        }
     }
     std::vector<uint32_t> host(words, 0u);
     fill_pows<P>(host, d.off_tw_lo, w, fe_one<P>(), nlo);
@@ -266,6 +368,20 @@ static int build_domain(bzh_ctx* ctx, NttDomain& d, const Fe<P>& omega_m, const 
         Fe<P> wr = pow2k(w, (int)k - rb);  // omega_N^(N/R)
         fill_pows<P>(host, d.off_sub[rb], wr, fe_one<P>(), (size_t)1 << (rb - 1));
     }
+    if (d.off_direct[0]) {
+        int logA = 0;
+        for (int p = 0; p + 1 < np; p++) {
+            const size_t R = (size_t)1 << bits[p], B = N >> (logA + bits[p]);
+            const Fe<P> wa = pow2k(w, logA);  // omega^A
+            const Fe<P> first = (p == 0 && d.inverse && !d.has_shift) ? first_hi : fe_one<P>();
+            Fe<P> wrow = fe_one<P>();         // omega^(A*row)
+            for (size_t row = 0; row < R; row++) {
+                fill_pows<P>(host, d.off_direct[p] + row * B * 8, wrow, first, B);
+                wrow = fe_mul(wrow, wa);
+            }
+            logA += bits[p];
+        }
+    }
     BZH_HIP_TRY(ctx, hipMalloc((void**)&d.d_tables, words * 4));
     BZH_HIP_TRY(ctx, hipMemcpyAsync(d.d_tables, host.data(), words * 4, hipMemcpyHostToDevice, ctx->stream));
     BZH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // host vector goes out of scope
@@ -274,7 +390,7 @@ static int build_domain(bzh_ctx* ctx, NttDomain& d, const Fe<P>& omega_m, const 
 
 template <class P>
 static int ntt_run_t(bzh_ctx* ctx, uint32_t* d_data, unsigned log_n, size_t batch, const uint64_t* omega,
-                     const uint64_t* coset_shift, int inverse, int form) {
+                     const uint64_t* coset_shift, int inverse, int form, const uint32_t* d_src = nullptr, unsigned src_log = 0) {
     if (log_n == 0) return BZH_OK;  // size-1 transform is the identity (n^-1 = 1, shift^0 = 1)
     Fe<P> w, sh = fe_one<P>();
     for (int i = 0; i < 4; i++) {
@@ -318,14 +434,20 @@ static int ntt_run_t(bzh_ctx* ctx, uint32_t* d_data, unsigned log_n, size_t batc
         if (rc) return rc;
     }
     // plan passes
-    int bits[5], np;
-    if (log_n <= 11) {
-        np = 1;
-        bits[0] = (int)log_n;
-    } else {
-        np = (int)((log_n + 8) / 9);
-        int base = (int)log_n / np, extra = (int)log_n % np;
-        for (int i = 0; i < np; i++) bits[i] = base + (i < extra ? 1 : 0);
+    int bits[5];
+    const int np = plan_passes(log_n, bits);
+    // zero-padded source (coeff_to_extended): 2^src_log coefficients per vector, read straight from d_src by pass 0
+    int nz = 0;
+    if (d_src) {
+        if (src_log > log_n || form != BZH_FORM_MONTGOMERY) return BZH_E_ARG;
+        nz = (int)(log_n - src_log);
+        if (np < 2 || nz > bits[0] || nz == 0) {  // single-pass sizes: pad in memory and run the plain transform
+            BZH_HIP_TRY(ctx, hipMemsetAsync(d_data, 0, total * 32, ctx->stream));
+            BZH_HIP_TRY(ctx, hipMemcpy2DAsync(d_data, ((size_t)32) << log_n, d_src, ((size_t)32) << src_log, ((size_t)32) << src_log, batch,
+                                              hipMemcpyDeviceToDevice, ctx->stream));
+            nz = 0;
+            d_src = nullptr;
+        }
     }
     // np >= 2: pass 0 data -> scratch, middle passes in scratch, last pass scratch -> data
     uint32_t* d_scratch = nullptr;
@@ -340,7 +462,8 @@ static int ntt_run_t(bzh_ctx* ctx, uint32_t* d_data, unsigned log_n, size_t batc
     int logA = 0;
     for (int p = 0; p < np; p++) {
         NttPassArgs a;
-        a.src = (p == 0) ? d_data : d_scratch;
+        a.src = (p == 0) ? (nz ? d_src : d_data) : d_scratch;
+        a.nz = (p == 0) ? nz : 0;
         a.dst = (p == np - 1) ? d_data : d_scratch;
         a.log_n = log_n;
         a.r = bits[p];
@@ -356,6 +479,7 @@ static int ntt_run_t(bzh_ctx* ctx, uint32_t* d_data, unsigned log_n, size_t batc
         a.sub_tw = dom->d_tables + dom->off_sub[a.r];
         a.tw_lo = dom->d_tables + dom->off_tw_lo;
         a.tw_hi = dom->d_tables + dom->off_tw_hi;
+        a.tw_direct = (p + 1 < np && dom->off_direct[p]) ? dom->d_tables + dom->off_direct[p] : nullptr;
         a.h = dom->h;
         a.pre_lo = (pre && p == 0) ? dom->d_tables + dom->off_sc_lo : nullptr;
         a.pre_hi = dom->d_tables + dom->off_sc_hi;
@@ -384,11 +508,12 @@ static int ntt_run_t(bzh_ctx* ctx, uint32_t* d_data, unsigned log_n, size_t batc
         const size_t tiles = ((size_t)1 << log_n) >> (a.r + logW);
         {
             ScopedTimer t(ctx, BZH_T_NTT);
-            if (ctx->profiling && p == 0) ctx->alg_bytes[BZH_T_NTT] += 64.0 * (double)batch * (double)((size_t)1 << log_n);
+            if (ctx->profiling && p == 0)
+                ctx->alg_bytes[BZH_T_NTT] += (32.0 + (nz ? 32.0 / (double)(1 << nz) : 32.0)) * (double)batch * (double)((size_t)1 << log_n);
             for (size_t b0 = 0; b0 < batch; b0 += 65535) {
                 size_t nb = batch - b0 < 65535 ? batch - b0 : 65535;
                 NttPassArgs aa = a;
-                aa.src = a.src + (b0 << log_n) * 8;
+                aa.src = a.src + (b0 << (log_n - (unsigned)a.nz)) * 8;
                 aa.dst = a.dst + (b0 << log_n) * 8;
                 hipLaunchKernelGGL((k_ntt_pass<P>), dim3((unsigned)tiles, (unsigned)nb), dim3(kNttThreads), 0, ctx->stream, aa);
             }
@@ -432,6 +557,20 @@ int ntt_run(bzh_ctx* ctx, int field, uint32_t* d_data, unsigned log_n, size_t ba
         case BZH_FIELD_FQ: return ntt_run_t<FqParams>(ctx, d_data, log_n, batch, omega, coset_shift, inverse, form);
         case BZH_FIELD_BN254_FR: return ntt_run_t<BnFrParams>(ctx, d_data, log_n, batch, omega, coset_shift, inverse, form);
         case BZH_FIELD_BN254_FQ: return ntt_run_t<BnFqParams>(ctx, d_data, log_n, batch, omega, coset_shift, inverse, form);
+    }
+    return BZH_E_ARG;
+}
+
+// coeff_to_extended without the padded copy: `batch` polynomials of 2^src_log coefficients at d_src (pitch 2^src_log)
+// -> their evaluations over the 2^log_n coset at d_dst (pitch 2^log_n).  Montgomery form.
+int ntt_run_padded(bzh_ctx* ctx, int field, uint32_t* d_dst, const uint32_t* d_src, unsigned src_log, unsigned log_n, size_t batch,
+                   const uint64_t* omega, const uint64_t* coset_shift) {
+    const int f = BZH_FORM_MONTGOMERY;
+    switch (field) {
+        case BZH_FIELD_FP: return ntt_run_t<FpParams>(ctx, d_dst, log_n, batch, omega, coset_shift, 0, f, d_src, src_log);
+        case BZH_FIELD_FQ: return ntt_run_t<FqParams>(ctx, d_dst, log_n, batch, omega, coset_shift, 0, f, d_src, src_log);
+        case BZH_FIELD_BN254_FR: return ntt_run_t<BnFrParams>(ctx, d_dst, log_n, batch, omega, coset_shift, 0, f, d_src, src_log);
+        case BZH_FIELD_BN254_FQ: return ntt_run_t<BnFqParams>(ctx, d_dst, log_n, batch, omega, coset_shift, 0, f, d_src, src_log);
     }
     return BZH_E_ARG;
 }

@@ -1123,9 +1123,7 @@ static int pk_create_t(bzh_ctx* ctx, const bzh_bases* srs, const uint8_t* blob, 
     };
     auto to_extended = [&](uint32_t* dst, const uint32_t* polys, size_t count) -> int {
         if (!count) return BZH_OK;
-        BZH_HIP_TRY(ctx, hipMemsetAsync(dst, 0, count * en * 32, st));
-        BZH_HIP_TRY(ctx, hipMemcpy2DAsync(dst, en * 32, polys, n * 32, n * 32, count, hipMemcpyDeviceToDevice, st));
-        return ntt_run(ctx, pk.field, dst, pk.ek, count, pk.eomega, pk.zeta, 0, BZH_FORM_MONTGOMERY);
+        return ntt_run_padded(ctx, pk.field, dst, polys, pk.k, pk.ek, count, pk.eomega, pk.zeta);
     };
     PV_TRY(up(pk.fixed, fixed_h.data(), nf * n));
     PV_TRY(to_coeff(pk.fixed_polys, pk.fixed, nf));
@@ -1313,9 +1311,7 @@ struct Prover {
     }
     int to_extended(uint32_t* dst, const uint32_t* polys, size_t count) {
         if (!count) return BZH_OK;
-        PV_TRY(zero(dst, count * en));
-        PV_TRY(copy2d(dst, en, polys, n, n, count));
-        return ntt_run(ctx, field, dst, pk.ek, count, pk.eomega, pk.zeta, 0, BZH_FORM_MONTGOMERY);
+        return ntt_run_padded(ctx, field, dst, polys, pk.k, pk.ek, count, pk.eomega, pk.zeta);
     }
     // Params::commit for `count` polynomials (rows of `pitch` elements): affine canonical points out
     // (lagrange: the rows are evaluations over the domain and the bases g_lagrange -- Params::commit_lagrange; the group

@@ -144,6 +144,14 @@ int bzh_msm(bzh_ctx* ctx, const bzh_bases* bases, const uint64_t* scalars, size_
 int bzh_ntt(bzh_ctx* ctx, int field, uint64_t* data, unsigned log_n, size_t batch, const uint64_t* omega,
             const uint64_t* coset_shift, int inverse, int form, int mem);
 
+/* EvaluationDomain::coeff_to_extended (halo2_proofs 0.2.0 poly/domain.rs, UPSTREAM; reached from create_proof at
+ * benches/shot.rs:68): `batch` polynomials of 2^log_n coefficients at `coeffs` (contiguous) -> their evaluations over
+ * the 2^log_ext-point coset shift*<omega_ext> at `out` (contiguous vectors of 2^log_ext).  Same result as zero-padding
+ * each polynomial to 2^log_ext and calling bzh_ntt(..., coset_shift, inverse = 0), without the padded copy: the first
+ * pass reads only the 2^log_n coefficients.  `coeffs` is not written; `out` must not overlap it. */
+int bzh_coeff_to_extended(bzh_ctx* ctx, int field, const uint64_t* coeffs, unsigned log_n, uint64_t* out, unsigned log_ext,
+                          size_t batch, const uint64_t* omega_ext, const uint64_t* coset_shift, int form, int mem);
+
 /* ---- prover-stage vector primitives (N4, N5, N6) ------------
  * Field elements in `form`; `mem` applies to every pointer of the call.  With BZH_MEM_DEVICE the
  * read-only inputs must already be in Montgomery form (the library does not write to them).

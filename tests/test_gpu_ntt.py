@@ -118,3 +118,58 @@ def test_plain_inverse_all_pass_counts(gpu_ctx, oracle_c, k):
     a = rand_elems(rng, 1 << k, 1)
     w = F.omega(k)
     assert (gpu_ctx.ntt(1, a, omega=w, inverse=True) == C.ntt(1, a, w, inverse=True, threads=8)).all()
+
+
+@pytest.mark.parametrize("k,ext", [(3, 3), (5, 2), (8, 3), (9, 3), (11, 3), (11, 2), (12, 1), (14, 3), (10, 4)])
+@pytest.mark.parametrize("shift", ["zeta", "generator", None])
+def test_coeff_to_extended_matches_padded_oracle_ntt(gpu_ctx, oracle_c, k, ext, shift):
+    """bzh_coeff_to_extended reads only the 2^k coefficients; the result is the coset NTT of the zero-padded vector
+    (EvaluationDomain::coeff_to_extended).  ZETA is the shift create_proof uses (a cube root of unity: three-valued
+    scaling path); the multiplicative generator exercises the general power table; None the plain transform."""
+    F = O.FP
+    batch = 3
+    rng = np.random.default_rng(1000 * k + ext)
+    a = rand_elems(rng, batch << k).reshape(batch, 1 << k, 4)
+    ek = k + ext
+    w = F.omega(ek)
+    s = {"zeta": pow(F.g, (F.p - 1) // 3, F.p), "generator": F.g, None: None}[shift]
+    got = gpu_ctx.coeff_to_extended(0, a, ek, omega_ext=w, coset_shift=s)
+    assert got.shape == (batch, 1 << ek, 4)
+    for b in range(batch):
+        padded = np.zeros((1 << ek, 4), dtype=np.uint64)
+        padded[: 1 << k] = a[b]
+        assert (got[b] == C.ntt(0, padded, w, coset_shift=s, threads=8)).all()
+
+
+def test_coeff_to_extended_montgomery_device_path_leaves_source_intact(gpu_ctx, oracle_c):
+    import ctypes
+    import torch
+    import bzh2
+    F = O.FP
+    k, ek, batch = 11, 14, 5
+    rng = np.random.default_rng(99)
+    a = rand_elems(rng, batch << k).reshape(batch, 1 << k, 4)
+    R, p = F.R, F.p
+    am = C.ints_to_array([x * R % p for x in C.array_to_ints(a.reshape(-1, 4))]).reshape(batch, 1 << k, 4)
+    src = torch.from_numpy(am.view(np.int64)).cuda()
+    dst = torch.empty((batch, 1 << ek, 4), dtype=torch.int64, device="cuda")
+    zeta = pow(F.g, (F.p - 1) // 3, F.p)
+    L = bzh2.load()
+    L.bzh_coeff_to_extended.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint, ctypes.c_void_p, ctypes.c_uint,
+                                        ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64),
+                                        ctypes.c_int, ctypes.c_int]
+    wm = bzh2.int_to_limbs(F.omega(ek) * R % p)
+    zm = bzh2.int_to_limbs(zeta * R % p)
+    torch.cuda.synchronize()
+    rc = L.bzh_coeff_to_extended(gpu_ctx.handle, 0, ctypes.c_void_p(src.data_ptr()), k, ctypes.c_void_p(dst.data_ptr()), ek, batch,
+                                 wm.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), zm.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)),
+                                 bzh2.FORM_MONTGOMERY, bzh2.MEM_DEVICE)
+    assert rc == 0
+    gpu_ctx.sync()
+    assert (src.cpu().numpy().view(np.uint64) == am).all()
+    got = dst.cpu().numpy().view(np.uint64)
+    for b in range(batch):
+        padded = np.zeros((1 << ek, 4), dtype=np.uint64)
+        padded[: 1 << k] = a[b]
+        want = C.array_to_ints(C.ntt(0, padded, F.omega(ek), coset_shift=zeta, threads=8))
+        assert C.array_to_ints(got[b]) == [x * R % p for x in want]
