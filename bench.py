@@ -702,13 +702,18 @@ def main():
             if traffic is not None or not os.path.exists(tj) or args.workload == "ntt22":
                 continue
             try:
+                tot, launches = 0.0, 0
                 for e in json.load(open(tj))["kernels"]:
                     if want_kernel in e["kernel"] and (want_kernel != "k_msm_accumulate" or "512" in e["kernel"] or e.get("workgroup", 0) >= 512):
                         # coalesced 16-B-per-lane streams (the evaluator's column reads): FETCH_SIZE doubled as the guide prescribes;
                         # the accumulate kernel's 64-B table gathers: raw count (calibration note in the round-1 traffic file)
                         rd = e["read_bytes"] if want_kernel == "k_expr_vm2" else e["read_bytes_raw"]
-                        traffic = rd + e["write_bytes"]
-                        traffic_src = os.path.relpath(tj, ROOT) + (" (real circuit, one batch of 16 in flight)" if tag == "r02" else " (round-1 synthetic circuit: stale for the real one)")
+                        tot += (rd + e["write_bytes"]) * e.get("launches", 1)   # the file holds one entry per grid size:
+                        launches += e.get("launches", 1)                       # mean over the launches, like `achieved`
+                if launches:
+                    traffic = tot / launches
+                    traffic_src = os.path.relpath(tj, ROOT) + (" (real circuit, one batch of 16 in flight; mean over %d launches)" % launches
+                                                               if tag == "r02" else " (round-1 synthetic circuit: stale for the real one)")
             except Exception:
                 traffic = None
         line = {
