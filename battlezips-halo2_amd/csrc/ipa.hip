@@ -678,6 +678,53 @@ __global__ void __launch_bounds__(256) k_ipa_verify_s(const uint32_t* __restrict
     fe_store(s + (b * (n + 2) + i) * 8, acc);
 }
 
+// One wave per opening: sum_i scal[b][i] * pts[b][i] over nl (~100) ad-hoc points, each term by double-and-add
+// (scalars canonical, points affine Montgomery, (0,0) = identity padding), then an LDS tree over the lanes.
+// Work and workspace are linear in the batch; a shared Pippenger table over batch * nl points was quadratic in it.
+template <class C>
+__global__ void __launch_bounds__(64) k_ipa_small_msm(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ scal, size_t nl,
+                                                        uint32_t* __restrict__ out_xyz) {
+    using P = typename C::Base;
+    __shared__ Xyzz<P> sh[64];
+    const int lane = threadIdx.x;
+    const size_t b = blockIdx.x;
+    Xyzz<P> sum = xyzz_identity<P>();
+    for (size_t i = lane; i < nl; i += 64) {
+        Affine<P> q;
+        q.x = fe_load<P>(pts + (b * nl + i) * 16);
+        q.y = fe_load<P>(pts + (b * nl + i) * 16 + 8);
+        if (aff_is_id(q)) continue;
+        const uint32_t* sc = scal + (b * nl + i) * 8;
+        int top = 255;
+        while (top >= 0 && !((sc[top >> 5] >> (top & 31)) & 1)) top--;
+        if (top < 0) continue;
+        Xyzz<P> acc = xyzz_from_affine(q);
+        for (int bit = top - 1; bit >= 0; bit--) {
+            acc = xyzz_dbl(acc);
+            if ((sc[bit >> 5] >> (bit & 31)) & 1) xyzz_madd(acc, q);
+        }
+        xyzz_add(sum, acc);
+    }
+    sh[lane] = sum;
+    __syncthreads();
+    for (int d = 32; d >= 1; d >>= 1) {
+        if (lane < d) {
+            Xyzz<P> o = sh[lane + d];
+            xyzz_add(sum, o);
+            sh[lane] = sum;
+        }
+        __syncthreads();
+    }
+    if (lane == 0) {
+        Fe<P> X, Y, Z;
+        xyzz_to_jacobian(sum, X, Y, Z);
+        uint32_t* o = out_xyz + b * 24;
+        fe_store(o, X);
+        fe_store(o + 8, Y);
+        fe_store(o + 16, Z);
+    }
+}
+
 // For every opening b:  sum_i lc_scal[b][i] * lc_pts[b][i]  ==  <c_b * s(u_b), G>  ?   (the IPA verification equation with
 // everything but the n-term G'_0 moved to the left: L_j, R_j, S, the opened commitment expanded into the proof's own
 // commitments, G_0, U, W).  lc_pts: batch x nl affine canonical points ((0,0) = identity padding), lc_scal: canonical.
@@ -691,15 +738,15 @@ static int ipa_check_batch_t(bzh_ctx* ctx, const bzh_bases* bases, size_t batch,
     while (((size_t)1 << k) < n) k++;
     if (((size_t)1 << k) != n || !B || !nl) return BZH_E_ARG;
     hipStream_t st = ctx->stream;
-    const size_t na = B * nl;  // ad-hoc table: every opening's points side by side, vector b is non-zero on its own segment
-    const size_t words = B * (n + 2) * 8 + B * (k + 1) * 8 + na * 16 + B * na * 8 + 2 * B * 24 + 256;
+    const size_t na = B * nl;  // every opening's own nl points and scalars, side by side
+    const size_t words = B * (n + 2) * 8 + B * (k + 1) * 8 + na * 16 + na * 8 + 2 * B * 24 + 256;
     void* arena = nullptr;
     IPA_TRY(ws_ensure(ctx, 4, words * 4, &arena));
     uint32_t* d_s = (uint32_t*)arena;
     uint32_t* d_cu = d_s + B * (n + 2) * 8;
     uint32_t* d_pts = d_cu + B * (k + 1) * 8;
     uint32_t* d_scal = d_pts + na * 16;
-    uint32_t* d_out = d_scal + B * na * 8;
+    uint32_t* d_out = d_scal + na * 8;
     // right side
     std::vector<Fe<SF>> cum(B * (k + 1));
     for (size_t i = 0; i < cum.size(); i++) cum[i] = fe_to_mont(h_load<SF>(cu + 4 * i));
@@ -707,25 +754,17 @@ static int ipa_check_batch_t(bzh_ctx* ctx, const bzh_bases* bases, size_t batch,
     hipLaunchKernelGGL((k_ipa_verify_s<SF>), dim3((unsigned)((n + 2 + 255) / 256), (unsigned)B), dim3(256), 0, st, d_cu, n, k, d_s);
     BZH_HIP_TRY(ctx, hipGetLastError());
     IPA_TRY(msm_run(ctx, bases, d_s, n + 2, B, BZH_FORM_MONTGOMERY, d_out));
-    // left side
+    // left side: B independent nl-term sums
     IPA_TRY(h2d_small(ctx, d_pts, lc_pts, na * 64));
     IPA_TRY(bases_to_montgomery(ctx, C::id, d_pts, na));
-    BZH_HIP_TRY(ctx, hipMemsetAsync(d_scal, 0, B * na * 32, st));
-    for (size_t b = 0; b < B; b++) IPA_TRY(h2d_small(ctx, d_scal + (b * na + b * nl) * 8, lc_scal + b * nl * 4, nl * 32));
-    bzh_bases tmp;
-    tmp.curve = C::id;
-    tmp.n = na;
-    tmp.d_xy = d_pts;
-    tmp.device = ctx->device;
-    IPA_TRY(msm_run(ctx, &tmp, d_scal, na, B, BZH_FORM_CANONICAL, d_out + B * 24));
+    IPA_TRY(h2d_small(ctx, d_scal, lc_scal, na * 32));
+    hipLaunchKernelGGL((k_ipa_small_msm<C>), dim3((unsigned)B), dim3(64), 0, st, d_pts, d_scal, nl, d_out + B * 24);
+    BZH_HIP_TRY(ctx, hipGetLastError());
     std::vector<uint64_t> jac(2 * B * 12), lhs(B * 8), rhs(B * 8);
     IPA_TRY(d2h_async(ctx, jac.data(), d_out, 2 * B * 96));
     IPA_TRY(d2h_finish(ctx));
     h_jac_batch_to_affine_canonical<PB>(jac.data(), B, rhs.data());
-    // the ad-hoc MSM ran in canonical form: its output limbs are canonical, convert for the helper
-    std::vector<uint64_t> jm(B * 12);
-    for (size_t i = 0; i < B * 3; i++) h_store<PB>(&jm[4 * i], fe_to_mont(h_load<PB>(&jac[B * 12 + 4 * i])));
-    h_jac_batch_to_affine_canonical<PB>(jm.data(), B, lhs.data());
+    h_jac_batch_to_affine_canonical<PB>(jac.data() + B * 12, B, lhs.data());
     for (size_t b = 0; b < B; b++) ok[b] = memcmp(&lhs[b * 8], &rhs[b * 8], 64) == 0;
     return BZH_OK;
 }

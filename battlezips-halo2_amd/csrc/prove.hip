@@ -715,6 +715,7 @@ struct bzh_pk {
     size_t usable = 0;
     uint64_t vk_repr[4] = {0};
     const bzh_bases* srs = nullptr;
+    std::vector<uint64_t> srs_g0_u_w;           // G_0, U, W of `srs`, canonical affine, read back once (bzh_verify_batch checks its argument against these)
     const bzh_bases* srs_lagrange = nullptr;   // (g_lagrange | u | w): Params::commit_lagrange for the columns upstream commits in that basis
     std::vector<bzh::CNode> cx;
     std::vector<int> gates;
@@ -2794,6 +2795,25 @@ int bzh_verify_batch(bzh_ctx* ctx, bzh_pk* pk, size_t batch, const uint64_t* ins
     std::lock_guard<std::mutex> lkp(pk->mu);
     std::lock_guard<std::mutex> lk(ctx->mu);
     BZH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // The commitments of the key and G'_0 are computed against pk->srs: the three points the caller passes must be the
+    // same SRS's, or every valid proof would be rejected without an error.  Row 0 of the window table is the raw SRS.
+    if (pk->srs_g0_u_w.empty()) {
+        uint64_t m[3 * 8];
+        const size_t idx[3] = {0, pk->n, pk->n + 1};
+        for (int i = 0; i < 3; i++)
+            BZH_HIP_TRY(ctx, hipMemcpyAsync(&m[i * 8], pk->srs->d_xy + idx[i] * 16, 64, hipMemcpyDeviceToHost, ctx->stream));
+        BZH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        std::vector<uint64_t> canon(24);
+        for (int i = 0; i < 6; i++) {
+            if (pk->curve == BZH_CURVE_VESTA) bzh::h_store<bzh::VestaCurve::Base>(&canon[i * 4], bzh::fe_from_mont(bzh::h_load<bzh::VestaCurve::Base>(&m[i * 4])));
+            else bzh::h_store<bzh::PallasCurve::Base>(&canon[i * 4], bzh::fe_from_mont(bzh::h_load<bzh::PallasCurve::Base>(&m[i * 4])));
+        }
+        pk->srs_g0_u_w = std::move(canon);
+    }
+    if (memcmp(pk->srs_g0_u_w.data(), g0_u_w, 3 * 64) != 0) {
+        ctx->last_error = "bzh_verify_batch: g0_u_w are not G_0, U, W of the SRS this key was built on";
+        return BZH_E_ARG;
+    }
     int rc = BZH_E_ARG;
     switch (pk->curve) {
         case BZH_CURVE_VESTA:

@@ -291,7 +291,8 @@ int bzh_pk_info(const bzh_pk* pk, size_t* rng_bytes_per_proof, size_t* max_proof
                 uint32_t* usable_rows);
 /* bzh_verify_batch  plonk::verify_proof (SingleVerifier; benches/board.rs:80-86) for `batch` proofs of the key's circuit:
  *                  results[b] = 1 if proof b verifies against instances b, else 0 (malformed proofs included).
- *                  g0_u_w: G_0, U, W of the SRS as 3 affine canonical points (the table itself only lives on the device). */
+ *                  g0_u_w: G_0, U, W of the SRS as 3 affine canonical points; they are checked against the SRS the key
+ *                  was built on (BZH_E_ARG if they differ: a stale copy would otherwise reject every valid proof). */
 int bzh_verify_batch(bzh_ctx* ctx, bzh_pk* pk, size_t batch, const uint64_t* instances, size_t instance_rows, const uint8_t* proofs,
                      size_t proof_stride, const size_t* proof_lens, const uint64_t* g0_u_w, int* results);
 int bzh_prove_batch(bzh_ctx* ctx, bzh_pk* pk, size_t batch, const uint64_t* advice, int form, int mem, const uint64_t* instances,

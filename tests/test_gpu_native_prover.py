@@ -150,6 +150,14 @@ def test_native_prove_then_verify_roundtrip_shaped(gpu_ctx, oracle_c):
         assert pk.verify_batch(insts, proofs) == [True, True, True]
         if insts[0] != insts[1]:
             assert pk.verify_batch([insts[1], insts[0], insts[2]], proofs) == [False, False, True]
+        # G_0 / U / W of another SRS are an argument error, not a silent rejection of every proof
+        good = pk._g0_u_w.copy()
+        pk._g0_u_w[1], pk._g0_u_w[2] = good[2].copy(), good[1].copy()
+        with pytest.raises(bzh2.BzhError) as e:
+            pk.verify_batch(insts, proofs)
+        assert e.value.status == bzh2.E_ARG
+        pk._g0_u_w[:] = good
+        assert pk.verify_batch(insts, proofs) == [True, True, True]
     finally:
         pk.close()
 
