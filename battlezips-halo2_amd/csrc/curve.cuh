@@ -73,9 +73,12 @@ BZH_HD Xyzz<P> xyzz_from_affine(const Affine<P>& a) {
 #define BZH_COLD BZH_HD
 #endif
 
-// dbl-2008-s-1 (a = 0): 6M + 3S... written as 7M + 2S with shared products
+// dbl-2008-s-1 (a = 0): 6M + 3S... written as 7M + 2S with shared products.
+// xyzz_dbl is out of line on the device (BZH_COLD); xyzz_dbl_inl is the same code inlined for the kernels whose time IS
+// a chain of such operations (bucket reduction, final sums): a call passes its 32 + 32 limb arguments through scratch
+// memory, ~700 B per lane of private-segment traffic per addition.
 template <class P>
-BZH_COLD Xyzz<P> xyzz_dbl(const Xyzz<P> p) {
+BZH_HD Xyzz<P> xyzz_dbl_inl(const Xyzz<P>& p) {
     if (xyzz_is_id(p)) return p;
     Fe<P> u = fe_dbl(p.y);
     Fe<P> v = fe_sqr(u);
@@ -89,6 +92,10 @@ BZH_COLD Xyzz<P> xyzz_dbl(const Xyzz<P> p) {
     r.zz = fe_mul(v, p.zz);
     r.zzz = fe_mul(w, p.zzz);
     return r;
+}
+template <class P>
+BZH_COLD Xyzz<P> xyzz_dbl(const Xyzz<P> p) {
+    return xyzz_dbl_inl(p);
 }
 // doubling of an affine point into XYZZ (mdbl-2008-s-1)
 template <class P>
@@ -154,7 +161,7 @@ BZH_HD void xyzz_add(Xyzz<P>& acc, const Xyzz<P>& q) {
     acc = xyzz_add_impl(acc, q);
 }
 template <class P>
-BZH_COLD Xyzz<P> xyzz_add_impl(Xyzz<P> acc, const Xyzz<P> q) {
+BZH_HD Xyzz<P> xyzz_add_impl_inl(Xyzz<P> acc, const Xyzz<P>& q) {
     Fe<P> u1 = fe_mul(acc.x, q.zz);
     Fe<P> u2 = fe_mul(q.x, acc.zz);
     Fe<P> s1 = fe_mul(acc.y, q.zzz);
@@ -162,7 +169,7 @@ BZH_COLD Xyzz<P> xyzz_add_impl(Xyzz<P> acc, const Xyzz<P> q) {
     Fe<P> pp_ = fe_sub(u2, u1);
     Fe<P> r = fe_sub(s2, s1);
     if (fe_is_zero(pp_)) {
-        if (fe_is_zero(r)) return xyzz_dbl(acc);
+        if (fe_is_zero(r)) return xyzz_dbl(acc);   // never taken by sums of distinct buckets; stays out of line
         return xyzz_identity<P>();
     }
     Fe<P> pp = fe_sqr(pp_);
@@ -175,6 +182,20 @@ BZH_COLD Xyzz<P> xyzz_add_impl(Xyzz<P> acc, const Xyzz<P> q) {
     acc.zz = fe_mul(fe_mul(acc.zz, q.zz), pp);
     acc.zzz = fe_mul(fe_mul(acc.zzz, q.zzz), ppp);
     return acc;
+}
+template <class P>
+BZH_COLD Xyzz<P> xyzz_add_impl(Xyzz<P> acc, const Xyzz<P> q) {
+    return xyzz_add_impl_inl(acc, q);
+}
+// acc += q, inlined (see xyzz_dbl_inl)
+template <class P>
+BZH_HD void xyzz_add_inl(Xyzz<P>& acc, const Xyzz<P>& q) {
+    if (xyzz_is_id(q)) return;
+    if (xyzz_is_id(acc)) {
+        acc = q;
+        return;
+    }
+    acc = xyzz_add_impl_inl(acc, q);
 }
 
 // XYZZ -> Jacobian (X:Y:Z) with x = X/Z^2, y = Y/Z^3: Z = ZZZ/ZZ would need an

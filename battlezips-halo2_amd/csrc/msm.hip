@@ -420,6 +420,27 @@ __global__ void __launch_bounds__(T) k_msm_accumulate(const uint32_t* __restrict
 // Suffix_t = sum_{u>=t} S_u (Hillis-Steele suffix scan in LDS, tree sums).
 // Dynamic LDS: 2 * T * 128 B.
 // ---------------------------------------------------------------------------
+// result of one reduced segment: the window sum for k_msm_finalize, or (out_xyz != null: the segment IS the result)
+// the Jacobian point in the caller's form
+template <class P>
+__device__ __forceinline__ void reduce_emit(const Xyzz<P>& v, uint4* winsums, size_t nseg, size_t segi, int form, uint32_t* out_xyz) {
+    if (!out_xyz) {
+        planes_put(winsums, nseg, segi, v);
+        return;
+    }
+    Fe<P> X, Y, Z;
+    xyzz_to_jacobian(v, X, Y, Z);
+    if (form == BZH_FORM_CANONICAL) {
+        X = fe_from_mont(X);
+        Y = fe_from_mont(Y);
+        Z = fe_from_mont(Z);
+    }
+    uint32_t* o = out_xyz + segi * 24;
+    fe_store(o, X);
+    fe_store(o + 8, Y);
+    fe_store(o + 16, Z);
+}
+
 template <class P>
 __device__ __forceinline__ Xyzz<P> block_tree_sum(Xyzz<P> v, uint4* buf, int T) {
     const int tid = threadIdx.x;
@@ -429,7 +450,7 @@ __device__ __forceinline__ Xyzz<P> block_tree_sum(Xyzz<P> v, uint4* buf, int T) 
         __syncthreads();
         if (tid < s) {
             Xyzz<P> o = planes_get<P>(buf, (size_t)T, (size_t)(tid + s));
-            xyzz_add(v, o);
+            xyzz_add_inl(v, o);
         }
     }
     return v;  // valid in thread 0
@@ -437,7 +458,8 @@ __device__ __forceinline__ Xyzz<P> block_tree_sum(Xyzz<P> v, uint4* buf, int T) 
 
 template <class C>
 __global__ void __launch_bounds__(256) k_msm_reduce(const uint4* __restrict__ buckets, int M, int nclass, size_t spv,
-                                                      size_t aseg_mult, uint4* __restrict__ winsums) {
+                                                      size_t aseg_mult, uint4* __restrict__ winsums, int form,
+                                                      uint32_t* __restrict__ out_xyz) {
     using P = typename C::Base;
     extern __shared__ __align__(16) uint32_t lds[];
     uint4* bufA = reinterpret_cast<uint4*>(lds);
@@ -453,8 +475,8 @@ __global__ void __launch_bounds__(256) k_msm_reduce(const uint4* __restrict__ bu
     Xyzz<P> S = xyzz_identity<P>(), W = xyzz_identity<P>();
     for (int k = L; k >= 1; k--) {
         Xyzz<P> bkt = planes_get<P>(seg, MS, (size_t)(tid * L + k - 1));
-        xyzz_add(S, bkt);
-        xyzz_add(W, S);
+        xyzz_add_inl(S, bkt);
+        xyzz_add_inl(W, S);
     }
     // suffix scan of S over threads
     Xyzz<P> suf = S;
@@ -465,7 +487,7 @@ __global__ void __launch_bounds__(256) k_msm_reduce(const uint4* __restrict__ bu
         __syncthreads();
         if (tid + d < T) {
             Xyzz<P> o = planes_get<P>(cur, (size_t)T, (size_t)(tid + d));
-            xyzz_add(suf, o);
+            xyzz_add_inl(suf, o);
         }
         uint4* tmp = cur;
         cur = nxt;
@@ -473,11 +495,11 @@ __global__ void __launch_bounds__(256) k_msm_reduce(const uint4* __restrict__ bu
     }
     // V_t = W_t + L * Suf_t for t >= 1 (log2 L doublings per thread), then ONE tree sum
     if (tid >= 1) {
-        for (int k = L; k > 1; k >>= 1) suf = xyzz_dbl(suf);
-        xyzz_add(W, suf);
+        for (int k = L; k > 1; k >>= 1) suf = xyzz_dbl_inl(suf);
+        xyzz_add_inl(W, suf);
     }
     Xyzz<P> lo = block_tree_sum(W, bufA, T);
-    if (tid == 0) planes_put(winsums, (size_t)gridDim.x, segi, lo);
+    if (tid == 0) reduce_emit<P>(lo, winsums, (size_t)gridDim.x, segi, form, out_xyz);
 }
 
 // ---------------------------------------------------------------------------
@@ -501,7 +523,8 @@ __device__ __forceinline__ Xyzz<P> xyzz_shfl_down(const Xyzz<P>& v, int d) {
 
 template <class C>
 __global__ void __launch_bounds__(64) k_msm_reduce_wave(const uint4* __restrict__ buckets, int M, int nclass, size_t spv,
-                                                         size_t aseg_mult, uint4* __restrict__ winsums) {
+                                                         size_t aseg_mult, uint4* __restrict__ winsums, int form,
+                                                         uint32_t* __restrict__ out_xyz) {
     using P = typename C::Base;
     const int lane = threadIdx.x;
     const size_t aseg = blockIdx.x / nclass, cls = blockIdx.x - aseg * nclass, MS = (size_t)M * nclass;
@@ -512,47 +535,72 @@ __global__ void __launch_bounds__(64) k_msm_reduce_wave(const uint4* __restrict_
     Xyzz<P> S = xyzz_identity<P>(), W = xyzz_identity<P>();
     for (int k = L; k >= 1; k--) {
         Xyzz<P> bkt = planes_get<P>(seg, MS, (size_t)(lane * L + k - 1));
-        xyzz_add(S, bkt);
-        xyzz_add(W, S);
+        xyzz_add_inl(S, bkt);
+        xyzz_add_inl(W, S);
     }
     // inclusive suffix sums of S across lanes
     Xyzz<P> suf = S;
 #pragma unroll 1
     for (int d = 1; d < 64; d <<= 1) {
         Xyzz<P> o = xyzz_shfl_down(suf, d);
-        if (lane + d < 64) xyzz_add(suf, o);
+        if (lane + d < 64) xyzz_add_inl(suf, o);
     }
     // V_t = W_t + L * Suf_t (t >= 1), then sum V over lanes
     if (lane >= 1) {
-        for (int k = L; k > 1; k >>= 1) suf = xyzz_dbl(suf);
-        xyzz_add(W, suf);
+        for (int k = L; k > 1; k >>= 1) suf = xyzz_dbl_inl(suf);
+        xyzz_add_inl(W, suf);
     }
 #pragma unroll 1
     for (int d = 32; d >= 1; d >>= 1) {
         Xyzz<P> o = xyzz_shfl_down(W, d);
-        if (lane < d) xyzz_add(W, o);
+        if (lane < d) xyzz_add_inl(W, o);
     }
-    if (lane == 0) planes_put(winsums, (size_t)gridDim.x, segi, W);
+    if (lane == 0) reduce_emit<P>(W, winsums, (size_t)gridDim.x, segi, form, out_xyz);
 }
 
 // ---------------------------------------------------------------------------
-// k_msm_chunksum: bucket-wise sum of a vector's chunk segments into its first segment (grid: buckets x vectors,
-// one thread per bucket).  All lanes do useful additions, unlike the running-sum reduction, whose per-segment
-// cost this removes for every chunk but one: (nchunks - 1) additions per bucket here against 2 per bucket AND
-// per chunk there, plus its scan overhead.
+// k_msm_chunksum: bucket-wise sum of a vector's chunk segments into its first segment.  All lanes do useful
+// additions, unlike the running-sum reduction, whose per-segment cost this removes for every chunk but one:
+// (nchunks - 1) additions per bucket here against 2 per bucket AND per chunk there, plus its scan overhead.
+// Grid: (buckets / 64) x vectors; the four waves of a workgroup share 64 buckets and each sums a quarter of the
+// chunks (next segment's load in flight during the addition), then two LDS combining steps: a dependent chain of
+// nchunks / 4 + 2 additions (~4.5 us each at this occupancy) instead of nchunks - 1.
 // ---------------------------------------------------------------------------
 template <class C>
 __global__ void __launch_bounds__(256) k_msm_chunksum(uint4* __restrict__ buckets, int MS, size_t nchunks) {
     using P = typename C::Base;
-    const size_t m = blockIdx.x * (size_t)blockDim.x + threadIdx.x, v = blockIdx.y;
-    if (m >= (size_t)MS) return;
+    __shared__ __align__(16) uint4 part[3 * 64 * 8];  // partial sums of waves 1..3, plane layout (stride 64)
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const size_t m = blockIdx.x * (size_t)64 + lane, v = blockIdx.y;
+    const bool live = m < (size_t)MS;
     uint4* seg0 = buckets + v * nchunks * (size_t)MS * 8;
-    Xyzz<P> acc = planes_get<P>(seg0, (size_t)MS, m);
-    for (size_t ck = 1; ck < nchunks; ck++) {
-        const Xyzz<P> o = planes_get<P>(seg0 + ck * (size_t)MS * 8, (size_t)MS, m);
-        xyzz_add(acc, o);
+    // wave q sums chunks [c0, c1)
+    const size_t per = (nchunks + 3) / 4, c0 = min((size_t)q * per, nchunks), c1 = min(c0 + per, nchunks);
+    Xyzz<P> acc = xyzz_identity<P>();
+    if (live && c0 < c1) {
+        acc = planes_get<P>(seg0 + c0 * (size_t)MS * 8, (size_t)MS, m);
+        Xyzz<P> nxt = acc;
+        if (c0 + 1 < c1) nxt = planes_get<P>(seg0 + (c0 + 1) * (size_t)MS * 8, (size_t)MS, m);
+        for (size_t ck = c0 + 1; ck < c1; ck++) {
+            const Xyzz<P> o = nxt;
+            if (ck + 1 < c1) nxt = planes_get<P>(seg0 + (ck + 1) * (size_t)MS * 8, (size_t)MS, m);
+            xyzz_add_inl(acc, o);
+        }
     }
-    planes_put(seg0, (size_t)MS, m, acc);
+    if (q) planes_put(part + (size_t)(q - 1) * 64 * 8, (size_t)64, (size_t)lane, acc);
+    __syncthreads();
+    if (q == 0 || q == 2) {  // 0 += 1, 2 += 3
+        const Xyzz<P> o = planes_get<P>(part + (size_t)q * 64 * 8, (size_t)64, (size_t)lane);
+        xyzz_add_inl(acc, o);
+    }
+    __syncthreads();
+    if (q == 2) planes_put(part + (size_t)1 * 64 * 8, (size_t)64, (size_t)lane, acc);
+    __syncthreads();
+    if (q == 0) {
+        const Xyzz<P> o = planes_get<P>(part + (size_t)1 * 64 * 8, (size_t)64, (size_t)lane);
+        xyzz_add_inl(acc, o);
+        if (live) planes_put(seg0, (size_t)MS, m, acc);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -571,7 +619,7 @@ __global__ void __launch_bounds__(64) k_msm_finalize(const uint4* __restrict__ w
         Xyzz<P> acc = xyzz_identity<P>();
         for (size_t ck = lane; ck < nchunks; ck += 64) {
             Xyzz<P> v = planes_get<P>(winsums, nseg, (b * (size_t)nwin + w) * nchunks + ck);
-            xyzz_add(acc, v);
+            xyzz_add_inl(acc, v);
         }
         if (nchunks > 1) acc = block_tree_sum(acc, buf, 64);
         if (lane == 0) planes_put(wbuf, 64, (size_t)w, acc);
@@ -580,9 +628,9 @@ __global__ void __launch_bounds__(64) k_msm_finalize(const uint4* __restrict__ w
     if (lane == 0) {
         Xyzz<P> acc = xyzz_identity<P>();
         for (int w = nwin - 1; w >= 0; w--) {
-            for (int k = 0; k < c; k++) acc = xyzz_dbl(acc);
+            for (int k = 0; k < c; k++) acc = xyzz_dbl_inl(acc);
             Xyzz<P> v = planes_get<P>(wbuf, 64, (size_t)w);
-            xyzz_add(acc, v);
+            xyzz_add_inl(acc, v);
         }
         Fe<P> X, Y, Z;
         xyzz_to_jacobian(acc, X, Y, Z);
@@ -1119,7 +1167,7 @@ static int msm_run_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_sca
 #undef BZH_LAUNCH_ACC
         }
         const size_t nseg = nb * segs_per_vec;
-        bool presum = false;
+        bool presum = false, fused_out = false;
         {
             ScopedTimer t(ctx, BZH_T_MSM_REDUCE);
             // many segments (throughput regime): sum the chunks of every vector bucket-wise first, then run the
@@ -1132,21 +1180,25 @@ static int msm_run_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_sca
                 rspv = 1;
             }
             if (presum) {
-                hipLaunchKernelGGL((k_msm_chunksum<C>), dim3((unsigned)((M_acc + 255) / 256), (unsigned)nb), dim3(256), 0, ctx->stream,
+                hipLaunchKernelGGL((k_msm_chunksum<C>), dim3((unsigned)((M_acc + 63) / 64), (unsigned)nb), dim3(256), 0, ctx->stream,
                                    (uint4*)d_buckets, M_acc, p.nchunks);
                 rseg = nb;
                 rspv = 1;
                 mult = p.nchunks;
             }
+            // one segment per result (window-table MSM after the chunk pre-sum): the reduction writes the Jacobian result
+            // itself, no k_msm_finalize launch
+            fused_out = acc_nwin == 1 && rspv == 1;
+            uint32_t* fout = fused_out ? d_out + b0 * nclass * 24 : (uint32_t*)nullptr;
             if (p.M >= 64 && rseg * nclass >= 256) {
                 hipLaunchKernelGGL((k_msm_reduce_wave<C>), dim3((unsigned)(rseg * nclass)), dim3(64), 0, ctx->stream,
-                                   (const uint4*)d_buckets, p.M, nclass, rspv, mult, (uint4*)d_winsums);
+                                   (const uint4*)d_buckets, p.M, nclass, rspv, mult, (uint4*)d_winsums, form, fout);
             } else {
                 hipLaunchKernelGGL((k_msm_reduce<C>), dim3((unsigned)(rseg * nclass)), dim3(red_threads), red_lds, ctx->stream,
-                                   (const uint4*)d_buckets, p.M, nclass, rspv, mult, (uint4*)d_winsums);
+                                   (const uint4*)d_buckets, p.M, nclass, rspv, mult, (uint4*)d_winsums, form, fout);
             }
         }
-        {
+        if (!fused_out) {
             ScopedTimer t(ctx, BZH_T_MSM_FINALIZE);
             const size_t fchunks = (presum || use_gs) ? 1 : p.nchunks, fseg = (presum || use_gs) ? nb : nseg;
             hipLaunchKernelGGL((k_msm_finalize<C>), dim3((unsigned)(nb * nclass)), dim3(64), 0, ctx->stream,
