@@ -678,18 +678,22 @@ __global__ void __launch_bounds__(256) k_ipa_verify_s(const uint32_t* __restrict
     fe_store(s + (b * (n + 2) + i) * 8, acc);
 }
 
-// One wave per opening: sum_i scal[b][i] * pts[b][i] over nl (~100) ad-hoc points, each term by double-and-add
-// (scalars canonical, points affine Montgomery, (0,0) = identity padding), then an LDS tree over the lanes.
-// Work and workspace are linear in the batch; a shared Pippenger table over batch * nl points was quadratic in it.
+// One workgroup per opening: sum_i scal[b][i] * pts[b][i] over nl (~100) ad-hoc points, one term per lane by
+// double-and-add (scalars canonical, points affine Montgomery, (0,0) = identity padding), then an LDS tree over the
+// lanes.  The 255 dependent doublings of a fresh point (~5 us each on a SIMD of its own) are the floor of any schedule
+// for this sum, ~1.5 ms; work and workspace are linear in the batch (a shared Pippenger table over batch * nl points
+// was quadratic in it).
+static constexpr int kSmallMsmThreads = 128;
 template <class C>
-__global__ void __launch_bounds__(64) k_ipa_small_msm(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ scal, size_t nl,
-                                                        uint32_t* __restrict__ out_xyz) {
+__global__ void __launch_bounds__(kSmallMsmThreads) k_ipa_small_msm(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ scal,
+                                                                     size_t nl, uint32_t* __restrict__ out_xyz) {
     using P = typename C::Base;
-    __shared__ Xyzz<P> sh[64];
+    constexpr int T = kSmallMsmThreads;
+    __shared__ Xyzz<P> sh[T];
     const int lane = threadIdx.x;
     const size_t b = blockIdx.x;
     Xyzz<P> sum = xyzz_identity<P>();
-    for (size_t i = lane; i < nl; i += 64) {
+    for (size_t i = lane; i < nl; i += T) {
         Affine<P> q;
         q.x = fe_load<P>(pts + (b * nl + i) * 16);
         q.y = fe_load<P>(pts + (b * nl + i) * 16 + 8);
@@ -700,14 +704,14 @@ __global__ void __launch_bounds__(64) k_ipa_small_msm(const uint32_t* __restrict
         if (top < 0) continue;
         Xyzz<P> acc = xyzz_from_affine(q);
         for (int bit = top - 1; bit >= 0; bit--) {
-            acc = xyzz_dbl(acc);
+            acc = xyzz_dbl_inl(acc);
             if ((sc[bit >> 5] >> (bit & 31)) & 1) xyzz_madd(acc, q);
         }
         xyzz_add(sum, acc);
     }
     sh[lane] = sum;
     __syncthreads();
-    for (int d = 32; d >= 1; d >>= 1) {
+    for (int d = T >> 1; d >= 1; d >>= 1) {
         if (lane < d) {
             Xyzz<P> o = sh[lane + d];
             xyzz_add(sum, o);
@@ -758,7 +762,7 @@ static int ipa_check_batch_t(bzh_ctx* ctx, const bzh_bases* bases, size_t batch,
     IPA_TRY(h2d_small(ctx, d_pts, lc_pts, na * 64));
     IPA_TRY(bases_to_montgomery(ctx, C::id, d_pts, na));
     IPA_TRY(h2d_small(ctx, d_scal, lc_scal, na * 32));
-    hipLaunchKernelGGL((k_ipa_small_msm<C>), dim3((unsigned)B), dim3(64), 0, st, d_pts, d_scal, nl, d_out + B * 24);
+    hipLaunchKernelGGL((k_ipa_small_msm<C>), dim3((unsigned)B), dim3(kSmallMsmThreads), 0, st, d_pts, d_scal, nl, d_out + B * 24);
     BZH_HIP_TRY(ctx, hipGetLastError());
     std::vector<uint64_t> jac(2 * B * 12), lhs(B * 8), rhs(B * 8);
     IPA_TRY(d2h_async(ctx, jac.data(), d_out, 2 * B * 96));
