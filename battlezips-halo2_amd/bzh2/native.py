@@ -8,7 +8,7 @@ import ctypes
 
 import numpy as np
 
-from . import CURVE_SCALAR_FIELD, FORM_CANONICAL, FORM_MONTGOMERY, MEM_DEVICE, MEM_HOST, Bases, Context, int_to_limbs, load
+from . import CURVE_SCALAR_FIELD, FORM_CANONICAL, FORM_MONTGOMERY, MEM_DEVICE, MEM_HOST, Bases, BzhError, Context, int_to_limbs, load
 from .circuit_data import MODULI, Circuit, serialize_circuit
 
 _VP = ctypes.c_void_p
@@ -27,8 +27,21 @@ def _bind():
                                    ctypes.POINTER(ctypes.c_int)]
     L.bzh_prove_batch.argtypes = [_VP, _VP, ctypes.c_size_t, _VP, ctypes.c_int, ctypes.c_int, _VP, ctypes.c_size_t, ctypes.c_char_p,
                                   ctypes.c_size_t, _VP, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+    L.bzh_prove_batch_seeded.argtypes = [_VP, _VP, ctypes.c_size_t, _VP, ctypes.c_int, ctypes.c_int, _VP, ctypes.c_size_t, ctypes.c_char_p,
+                                         _VP, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+    L.bzh_rng_expand.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_size_t, _VP]
     L._bzh_native_bound = True
     return L
+
+
+def rng_expand(seed: bytes, first_draw: int, draws: int) -> bytes:
+    """draws [first_draw, first_draw + draws) of the ChaCha20 stream bzh_prove_batch_seeded derives from `seed` (64 bytes each)"""
+    assert len(seed) == 32
+    out = np.zeros(draws * 64, dtype=np.uint8)
+    rc = _bind().bzh_rng_expand(seed, first_draw, draws, _VP(out.ctypes.data))
+    if rc:
+        raise BzhError(rc, "bzh_rng_expand")
+    return out.tobytes()
 
 
 class NativeProvingKey:
@@ -109,13 +122,19 @@ class NativeProvingKey:
         self.ctx._check(rc, "bzh_verify_batch")
         return [bool(v) for v in res]
 
-    def prove_batch(self, advice, instances, rng_list, device_ptr: int | None = None) -> list:
+    def prove_batch(self, advice, instances, rng_list, device_ptr: int | None = None, seeds=None) -> list:
         """advice: (B, num_advice, n, 4) uint64 canonical host array (or, with device_ptr, a device pointer to Montgomery
-        limbs of that shape); instances: B lists of instance columns (equal lengths); rng_list: B byte strings."""
+        limbs of that shape); instances: B lists of instance columns (equal lengths); rng_list: B byte strings of
+        rng_bytes each -- or None with seeds = B 32-byte strings: the library expands each into its proof's stream on the
+        device (bzh_prove_batch_seeded; the same proofs as rng_list = [rng_expand(s, 0, rng_bytes // 64) for s in seeds])."""
         L = _bind()
+        seeded = rng_list is None
+        if seeded:
+            assert seeds is not None and all(len(sd) == 32 for sd in seeds)
+            rng_list = list(seeds)
         B = len(rng_list)
         stride = len(rng_list[0])
-        assert all(len(r) == stride for r in rng_list) and stride >= self.rng_bytes, (stride, self.rng_bytes)
+        assert all(len(r) == stride for r in rng_list) and (seeded or stride >= self.rng_bytes), (stride, self.rng_bytes)
         inst, rows = self._instances(instances)
         proofs = np.zeros((B, self.max_proof_bytes), dtype=np.uint8)
         lens = (ctypes.c_size_t * B)()
@@ -125,7 +144,11 @@ class NativeProvingKey:
             a = np.ascontiguousarray(advice, dtype=np.uint64)
             assert a.shape == (B, self.num_advice, self.n, 4), a.shape
             adv_p, form, mem = _VP(a.ctypes.data), FORM_CANONICAL, MEM_HOST
-        rc = L.bzh_prove_batch(self.ctx.handle, self.handle, B, adv_p, form, mem, _VP(inst.ctypes.data), rows, b"".join(rng_list), stride,
-                               _VP(proofs.ctypes.data), self.max_proof_bytes, lens)
+        if seeded:
+            rc = L.bzh_prove_batch_seeded(self.ctx.handle, self.handle, B, adv_p, form, mem, _VP(inst.ctypes.data), rows,
+                                          b"".join(rng_list), _VP(proofs.ctypes.data), self.max_proof_bytes, lens)
+        else:
+            rc = L.bzh_prove_batch(self.ctx.handle, self.handle, B, adv_p, form, mem, _VP(inst.ctypes.data), rows, b"".join(rng_list), stride,
+                                   _VP(proofs.ctypes.data), self.max_proof_bytes, lens)
         self.ctx._check(rc, "bzh_prove_batch")
         return [bytes(proofs[b, :lens[b]]) for b in range(B)]

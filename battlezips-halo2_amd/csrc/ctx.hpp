@@ -271,7 +271,8 @@ int expr_eval2(bzh_ctx* ctx, int field, const void* d_prog, int nops, const uint
 // ipa.hip
 int random_field(bzh_ctx* ctx, int field, const uint32_t* d_raw, size_t count, uint32_t* d_out);
 int ipa_open(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_polys, size_t batch, const uint64_t* blinds,
-             const uint64_t* x3s, const uint8_t* rng_bytes, size_t rng_stride, bzh_transcript* const* trs, uint64_t* out_v);
+             const uint64_t* x3s, const uint8_t* rng_bytes, size_t rng_stride, bzh_transcript* const* trs, uint64_t* out_v,
+             const uint32_t* d_raw_in = nullptr);  // d_raw_in: the draws already on the device (batch x (n + 1 + 2k) x 64 B) instead of rng_bytes
 int ipa_verify(bzh_ctx* ctx, const bzh_bases* bases, const uint64_t* commitment_xy, const uint64_t* x3, const uint64_t* v,
                const uint8_t* proof, size_t proof_len, bzh_transcript* tr, const uint64_t* g0_u_w_xy);
 int ipa_check_batch(bzh_ctx* ctx, const bzh_bases* bases, size_t batch, size_t nl, const uint64_t* lc_pts, const uint64_t* lc_scal,

@@ -379,7 +379,7 @@ static void h_jac_batch_to_affine_canonical(const uint64_t* xyz, size_t cnt, uin
 template <class C>
 static int ipa_open_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_polys, size_t batch, const uint64_t* blinds,
                       const uint64_t* x3s, const uint8_t* rng_bytes, size_t rng_stride, bzh_transcript* const* trs,
-                      uint64_t* out_v) {
+                      uint64_t* out_v, const uint32_t* d_raw_in) {
     using SF = typename CurveMeta<C>::SF;
     using PB = typename C::Base;
     const int field = CurveMeta<C>::scalar_field;
@@ -424,8 +424,12 @@ static int ipa_open_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_po
     if (B > 65535) return BZH_E_ARG;
 
     // randomness: upstream draw order = n coefficients of s(X), s_blind, then (l_j, r_j) per round
-    for (size_t b = 0; b < B; b++)
-        IPA_TRY(h2d_small(ctx, d_raw + b * nrand * 16, rng_bytes + b * rng_stride, nrand * 64));
+    if (d_raw_in) {  // the 64-byte draws are already on the device (batch x nrand, proof-major)
+        BZH_HIP_TRY(ctx, hipMemcpyAsync(d_raw, d_raw_in, B * nrand * 64, hipMemcpyDeviceToDevice, st));
+    } else {
+        for (size_t b = 0; b < B; b++)
+            IPA_TRY(h2d_small(ctx, d_raw + b * nrand * 16, rng_bytes + b * rng_stride, nrand * 64));
+    }
     hipLaunchKernelGGL((k_reduce_wide<SF>), dim3((unsigned)((B * nrand + g256 - 1) / g256)), dim3(g256), 0, st, d_raw, B * nrand,
                        d_rand);
     BZH_HIP_TRY(ctx, hipMemcpy2DAsync(d_spoly, n * 32, d_rand, nrand * 32, n * 32, B, hipMemcpyDeviceToDevice, st));
@@ -808,11 +812,12 @@ int random_field(bzh_ctx* ctx, int field, const uint32_t* d_raw, size_t count, u
 }
 
 int ipa_open(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_polys, size_t batch, const uint64_t* blinds,
-             const uint64_t* x3s, const uint8_t* rng_bytes, size_t rng_stride, bzh_transcript* const* trs, uint64_t* out_v) {
+             const uint64_t* x3s, const uint8_t* rng_bytes, size_t rng_stride, bzh_transcript* const* trs, uint64_t* out_v,
+             const uint32_t* d_raw_in) {
     switch (bases->curve) {
-        case BZH_CURVE_VESTA: return ipa_open_t<VestaCurve>(ctx, bases, d_polys, batch, blinds, x3s, rng_bytes, rng_stride, trs, out_v);
-        case BZH_CURVE_PALLAS: return ipa_open_t<PallasCurve>(ctx, bases, d_polys, batch, blinds, x3s, rng_bytes, rng_stride, trs, out_v);
-        case BZH_CURVE_BN254: return ipa_open_t<Bn254Curve>(ctx, bases, d_polys, batch, blinds, x3s, rng_bytes, rng_stride, trs, out_v);
+        case BZH_CURVE_VESTA: return ipa_open_t<VestaCurve>(ctx, bases, d_polys, batch, blinds, x3s, rng_bytes, rng_stride, trs, out_v, d_raw_in);
+        case BZH_CURVE_PALLAS: return ipa_open_t<PallasCurve>(ctx, bases, d_polys, batch, blinds, x3s, rng_bytes, rng_stride, trs, out_v, d_raw_in);
+        case BZH_CURVE_BN254: return ipa_open_t<Bn254Curve>(ctx, bases, d_polys, batch, blinds, x3s, rng_bytes, rng_stride, trs, out_v, d_raw_in);
     }
     return BZH_E_ARG;
 }

@@ -35,6 +35,7 @@
 #include <thread>
 #include <vector>
 
+#include "chacha.hpp"
 #include "ctx.hpp"
 #include "curve.cuh"
 
@@ -68,6 +69,18 @@ __global__ void __launch_bounds__(256) k_gather_rows(uint4* __restrict__ dst, co
     const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x, j = blockIdx.y, b = blockIdx.z;
     if (i >= 2 * n) return;
     dst[((b * J + j) * n) * 2 + i] = srcs[j][b * strides[j] * 2 + i];
+}
+
+// rows of 64-byte draws for every proof of a batch: raw[(b * count + i) * 16 ..] = ChaCha20(key_b, counter0 + i)
+__global__ void __launch_bounds__(256) k_chacha20_rows(const uint32_t* __restrict__ keys, uint64_t counter0, size_t count,
+                                                        uint32_t* __restrict__ raw) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (i >= count) return;
+    uint32_t key[8], out[16];
+    for (int k = 0; k < 8; k++) key[k] = keys[b * 8 + k];
+    chacha20_block(key, counter0 + i, out);
+    uint4* o = reinterpret_cast<uint4*>(raw + (b * count + i) * 16);
+    for (int k = 0; k < 4; k++) o[k] = make_uint4(out[4 * k], out[4 * k + 1], out[4 * k + 2], out[4 * k + 3]);
 }
 
 // ---------------------------------------------------------------------------
@@ -1239,6 +1252,13 @@ struct Prover {
     const int field;
     std::vector<bzh_transcript*> T;
     std::vector<const uint8_t*> rng;  // per-proof cursor into the caller's randomness
+    // seeded mode (bzh_prove_batch_seeded): the stream of proof b is ChaCha20(seed_b), addressed by 64-byte block; every
+    // proof of a batch draws in lockstep, so one counter serves the batch
+    bool seeded = false;
+    std::vector<uint32_t> seed_keys;   // B x 8 words
+    uint32_t* d_seed_keys = nullptr;
+    uint64_t seed_ctr = 0;
+    std::vector<uint64_t> host_ctr;    // draws taken on the host per proof since the last row draw (must stay in lockstep)
     std::vector<std::map<int, Fe<SF>>> env;
 
     Prover(bzh_ctx* c, bzh_pk& p, size_t batch)
@@ -1275,15 +1295,40 @@ struct Prover {
     int upload(uint32_t* dst, const Fe<SF>* src, size_t elems) { return h2d_small(ctx, dst, src, elems * 32); }
 
     Fe<SF> draw(size_t b) {
+        if (seeded) {
+            uint32_t blk[16];
+            chacha20_block(&seed_keys[b * 8], seed_ctr + host_ctr[b]++, blk);
+            return h_from_u512<SF>(reinterpret_cast<const uint8_t*>(blk));
+        }
         const Fe<SF> v = h_from_u512<SF>(rng[b]);
         rng[b] += 64;
         return v;
+    }
+    // seeded mode: fold the host-side draws into the batch counter (every proof must have taken the same number)
+    int seed_sync() {
+        for (size_t b = 1; b < B; b++)
+            if (host_ctr[b] != host_ctr[0]) return BZH_E_ARG;
+        seed_ctr += host_ctr[0];
+        std::fill(host_ctr.begin(), host_ctr.end(), 0);
+        return BZH_OK;
+    }
+    // seeded mode: the next `count` 64-byte draws of every proof, generated on the device (B x count x 16 words)
+    int seed_rows(size_t count, uint32_t* raw) {
+        PV_TRY(seed_sync());
+        hipLaunchKernelGGL(k_chacha20_rows, dim3((unsigned)((count + 255) / 256), (unsigned)B), dim3(256), 0, st, d_seed_keys, seed_ctr, count, raw);
+        BZH_HIP_TRY(ctx, hipGetLastError());
+        seed_ctr += count;
+        return BZH_OK;
     }
     // the next `count` draws of every proof, reduced on the device into dst (B x count, proof-major)
     int draw_rows(size_t count, uint32_t* dst) {
         if (!count) return BZH_OK;
         uint32_t* raw = (uint32_t*)pk.arena.alloc(B * count * 64);
         if (!raw) return BZH_E_OOM;
+        if (seeded) {
+            PV_TRY(seed_rows(count, raw));
+            return random_field(ctx, field, raw, B * count, dst);
+        }
         char* stage = nullptr;  // one upload for the whole batch, assembled in pinned memory
         PV_TRY(h2d_stage(ctx, B * count * 64, &stage));
         for (size_t b = 0; b < B; b++) {
@@ -1496,6 +1541,17 @@ struct Prover {
                 for (auto& o : cc.prog.ops) muls += ((o.code >> 4) < 3 && ((o.code >> 2) & 3) == V2_MUL);
                 fprintf(stderr, "[bzh_prove_batch] quotient program (VM v2): %zu terms, %zu ops, %zu multiplications, %d LDS slots, %zu constants, %zu hoisted columns%s\n",
                         terms.size(), cc.prog.ops.size(), muls, cc.prog.nlds, cc.prog.consts.size(), pk.hoist_cols, cc.prog.ok ? "" : " -- NOT usable");
+                // instruction mix: form (SS/SL/LL/UN) x operation, and the kinds of the memory operands
+                size_t hist[4][4] = {{0}}, kinds[4] = {0};
+                for (auto& o : cc.prog.ops) {
+                    const int form = o.code >> 4, oo = (o.code >> 2) & 3;
+                    hist[form & 3][oo]++;
+                    if (form == V2_SL || form == V2_LL) kinds[o.b_kind & 3]++;
+                    if (form == V2_LL || (form == V2_UN && oo != V2_NEG)) kinds[o.a_kind & 3]++;
+                }
+                fprintf(stderr, "[bzh_prove_batch]   mix  SS add/sub/mul/rsub %zu/%zu/%zu/%zu  SL %zu/%zu/%zu/%zu  LL %zu/%zu/%zu/%zu  UN neg/load/store %zu/%zu/%zu ; operands column/const/lds %zu/%zu/%zu\n",
+                        hist[0][0], hist[0][1], hist[0][2], hist[0][3], hist[1][0], hist[1][1], hist[1][2], hist[1][3], hist[2][0], hist[2][1],
+                        hist[2][2], hist[2][3], hist[3][0], hist[3][1], hist[3][2], kinds[BZH_EXPR_COLUMN], kinds[BZH_EXPR_CONST], kinds[BZH_EXPR_LDS]);
             }
             it = pk.progs2.insert({pkey, std::move(cc.prog)}).first;
         }
@@ -2225,9 +2281,16 @@ int Prover<C>::prove(const uint32_t* d_advice_in, const uint64_t* instances, siz
         // the opening draws from each proof's own cursor: a zero stride is not possible, so pass proof 0's cursor and the
         // common distance between the per-proof streams
         const size_t need = 64 * (n + 1 + 2 * (size_t)pk.k);
-        std::vector<uint8_t> ipa_rng(B * need);
-        for (size_t b = 0; b < B; b++) memcpy(&ipa_rng[b * need], rng[b], need);
-        PV_TRY(ipa_open(ctx, pk.srs, p_poly, B, p_blinds.data(), x3c.data(), ipa_rng.data(), need, T.data(), out_v.data()));
+        if (seeded) {
+            uint32_t* raw = (uint32_t*)pk.arena.alloc(B * need);
+            if (!raw) return BZH_E_OOM;
+            PV_TRY(seed_rows(need / 64, raw));
+            PV_TRY(ipa_open(ctx, pk.srs, p_poly, B, p_blinds.data(), x3c.data(), nullptr, need, T.data(), out_v.data(), raw));
+        } else {
+            std::vector<uint8_t> ipa_rng(B * need);
+            for (size_t b = 0; b < B; b++) memcpy(&ipa_rng[b * need], rng[b], need);
+            PV_TRY(ipa_open(ctx, pk.srs, p_poly, B, p_blinds.data(), x3c.data(), ipa_rng.data(), need, T.data(), out_v.data()));
+        }
     }
     mark("ipa");
     for (size_t b = 0; b < B; b++) {
@@ -2246,7 +2309,18 @@ static int prove_batch_t(bzh_ctx* ctx, bzh_pk* pk, size_t batch, const uint32_t*
                          const uint8_t* rng, size_t rng_stride, uint8_t* proofs, size_t proof_stride, size_t* proof_lens) {
     pk->arena.reset();
     Prover<C> pv(ctx, *pk, batch);
-    for (size_t b = 0; b < batch; b++) pv.rng[b] = rng + b * rng_stride;
+    if (rng_stride == 0) {  // seeded: rng holds batch x 32 bytes
+        pv.seeded = true;
+        pv.seed_keys.resize(batch * 8);
+        memcpy(pv.seed_keys.data(), rng, batch * 32);
+        pv.host_ctr.assign(batch, 0);
+        pv.d_seed_keys = (uint32_t*)pk->arena.alloc(batch * 32);
+        if (!pv.d_seed_keys) return BZH_E_OOM;
+        int rcu = h2d_small(ctx, pv.d_seed_keys, pv.seed_keys.data(), batch * 32);
+        if (rcu) return rcu;
+    } else {
+        for (size_t b = 0; b < batch; b++) pv.rng[b] = rng + b * rng_stride;
+    }
     const int rc = pv.prove(d_advice, instances, inst_rows, proofs, proof_stride, proof_lens);
     (void)hipStreamSynchronize(ctx->stream);
     return rc;
@@ -2827,12 +2901,14 @@ int bzh_verify_batch(bzh_ctx* ctx, bzh_pk* pk, size_t batch, const uint64_t* ins
     return rc;
 }
 
-int bzh_prove_batch(bzh_ctx* ctx, bzh_pk* pk, size_t batch, const uint64_t* advice, int form, int mem, const uint64_t* instances,
-                    size_t instance_rows, const uint8_t* rng, size_t rng_stride, uint8_t* proofs, size_t proof_stride,
-                    size_t* proof_lens) {
+// rng_stride == 0: `rng` holds batch x 32-byte seeds (bzh_prove_batch_seeded)
+static int prove_batch_entry(bzh_ctx* ctx, bzh_pk* pk, size_t batch, const uint64_t* advice, int form, int mem, const uint64_t* instances,
+                             size_t instance_rows, const uint8_t* rng, size_t rng_stride, uint8_t* proofs, size_t proof_stride,
+                             size_t* proof_lens) {
     if (!ctx || !pk || !batch || batch > 4096 || !advice || !rng || !proofs || !proof_lens) return BZH_E_ARG;
     if ((form != BZH_FORM_CANONICAL && form != BZH_FORM_MONTGOMERY) || (mem != BZH_MEM_HOST && mem != BZH_MEM_DEVICE)) return BZH_E_ARG;
-    if (pk->device != ctx->device || rng_stride < pk->rng_bytes || (pk->ni && instance_rows && !instances) || instance_rows > pk->usable)
+    if (pk->device != ctx->device || (rng_stride != 0 && rng_stride < pk->rng_bytes) || (pk->ni && instance_rows && !instances) ||
+        instance_rows > pk->usable)
         return BZH_E_ARG;
     if (mem == BZH_MEM_DEVICE && form != BZH_FORM_MONTGOMERY) return BZH_E_ARG;
     std::lock_guard<std::mutex> lkp(pk->mu);
@@ -2857,6 +2933,29 @@ int bzh_prove_batch(bzh_ctx* ctx, bzh_pk* pk, size_t batch, const uint64_t* advi
                                                         proof_lens);
     }
     return BZH_E_ARG;
+}
+
+int bzh_prove_batch(bzh_ctx* ctx, bzh_pk* pk, size_t batch, const uint64_t* advice, int form, int mem, const uint64_t* instances,
+                    size_t instance_rows, const uint8_t* rng, size_t rng_stride, uint8_t* proofs, size_t proof_stride,
+                    size_t* proof_lens) {
+    if (rng_stride == 0) return BZH_E_ARG;
+    return prove_batch_entry(ctx, pk, batch, advice, form, mem, instances, instance_rows, rng, rng_stride, proofs, proof_stride, proof_lens);
+}
+
+int bzh_prove_batch_seeded(bzh_ctx* ctx, bzh_pk* pk, size_t batch, const uint64_t* advice, int form, int mem, const uint64_t* instances,
+                           size_t instance_rows, const uint8_t* seeds, uint8_t* proofs, size_t proof_stride, size_t* proof_lens) {
+    return prove_batch_entry(ctx, pk, batch, advice, form, mem, instances, instance_rows, seeds, 0, proofs, proof_stride, proof_lens);
+}
+
+int bzh_rng_expand(const uint8_t* seed, uint64_t first_draw, size_t draws, uint8_t* out) {
+    if (!seed || (!out && draws)) return BZH_E_ARG;
+    uint32_t key[8], blk[16];
+    memcpy(key, seed, 32);
+    for (size_t i = 0; i < draws; i++) {
+        bzh::chacha20_block(key, first_draw + i, blk);
+        memcpy(out + i * 64, blk, 64);
+    }
+    return BZH_OK;
 }
 
 }  // extern "C"

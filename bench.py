@@ -103,14 +103,17 @@ def parse():
                     help="gloo + several ranks on one GPU rehearses the multi-rank path on a single-GPU box (ranks share device "
                          "local_rank %% device_count); the driver's multi-GPU runs use nccl (RCCL)")
     ap.add_argument("--no-precompute", action="store_true", help="plain bases: no fixed-base window table for the SRS")
-    ap.add_argument("--batch", type=int, default=16,
+    ap.add_argument("--batch", type=int, default=32,
                     help="proof_k* workloads: witnesses synthesised and proved in lockstep per bzh_prove_batch call; "
                          "1 = the single-proof latency path")
     ap.add_argument("--circuit", default="auto", choices=["auto", "shot", "board"],
                     help="proof_k* workloads: which of the reference's circuits (auto: ShotCircuit at k = 11, BoardCircuit otherwise)")
     ap.add_argument("--mix-divisor", type=int, default=1, help="mixed_board_shot: divide the fixed batch (256 Board + 2560 Shot) by this")
     ap.add_argument("--window-bits", type=int, default=0, help="SRS window-table width (0: 8 for --batch 1, else the planner's)")
-    ap.add_argument("--concurrency", type=int, default=8,
+    ap.add_argument("--explicit-rng", action="store_true",
+                    help="proof_k* workloads: generate every proof's random stream on the host (numpy) and pass it to bzh_prove_batch "
+                         "instead of a 32-byte seed per proof expanded on the device (bzh_prove_batch_seeded)")
+    ap.add_argument("--concurrency", type=int, default=4,
                     help="proof_k* workloads: independent proofs in flight per GPU (host threads, one ctx + stream each)")
     return ap.parse_args()
 
@@ -167,6 +170,7 @@ def random_fleet(rng):
 
 
 class ProofRunner:
+    EXPLICIT_RNG = False   # --explicit-rng
     """`workers` host threads, each with its own ctx + stream + proving key + advice tensor in HBM, proving slices of
     `batch` witnesses of one real circuit: bzh_synthesize_{shot,board} (device output) then bzh_prove_batch."""
 
@@ -177,6 +181,7 @@ class ProofRunner:
         from bzh2 import circuits as Cm, native as N
         from bzh2.game import BinaryValue
         self.kind, self.k, self.batch, self.device = kind, k, batch, device
+        self.explicit_rng = ProofRunner.EXPLICIT_RNG
         self.Cm = Cm
         self.layout = Cm.CircuitLayout(Cm.SHOT if kind == "shot" else Cm.BOARD, k)
         blob = self.layout.blob()
@@ -234,9 +239,14 @@ class ProofRunner:
     def _prove_slice(self, wi, lo, count):
         circuits = self._circuits(lo, count)
         _, insts = self.layout.synthesize(circuits, ctx=self.ctxs[wi], device_ptr=self.adv[wi].data_ptr(), threads=4)
-        blob = self.np_rng[wi].bytes(self.rng_bytes * count)
-        rbs = [blob[i * self.rng_bytes:(i + 1) * self.rng_bytes] for i in range(count)]
-        proofs = self.pks[wi].prove_batch(None, insts, rbs, device_ptr=self.adv[wi].data_ptr())
+        if self.explicit_rng:   # the caller supplies every random byte (2 MB per proof at k = 14): the parity tests' mode
+            blob = self.np_rng[wi].bytes(self.rng_bytes * count)
+            rbs = [blob[i * self.rng_bytes:(i + 1) * self.rng_bytes] for i in range(count)]
+            proofs = self.pks[wi].prove_batch(None, insts, rbs, device_ptr=self.adv[wi].data_ptr())
+        else:                   # a 32-byte seed per proof, expanded on the device (bzh_prove_batch_seeded) -- create_proof's OsRng
+            blob = self.np_rng[wi].bytes(32 * count)
+            proofs = self.pks[wi].prove_batch(None, insts, None, device_ptr=self.adv[wi].data_ptr(),
+                                              seeds=[blob[32 * i:32 * i + 32] for i in range(count)])
         self.last_batch[wi], self.last_insts[wi] = proofs, insts
         self.step_batches[wi].append(proofs)
 
@@ -393,7 +403,10 @@ class Workload:
             self.verify_last = self.runner.verify_last
             self.alg_bytes_msm_launch = 0
             self.alg_bytes_step = 0
-            self.desc = {"k": k, "circuit": self.runner.circuit_desc, "proof_bytes": None, "driver": "native (bzh_synthesize_* + bzh_prove_batch)"}
+            self.desc = {"k": k, "circuit": self.runner.circuit_desc, "proof_bytes": None,
+                         "driver": "native (bzh_synthesize_* + %s)" % ("bzh_prove_batch" if ProofRunner.EXPLICIT_RNG else "bzh_prove_batch_seeded"),
+                         "randomness": ("every draw generated on the host and passed in (%d bytes per proof)" % self.runner.rng_bytes) if ProofRunner.EXPLICIT_RNG
+                         else "a fresh 32-byte seed per proof, expanded on the device (ChaCha20) -- the reference draws OsRng inside create_proof"}
             self.result = torch.zeros((1, 12), dtype=torch.int64, device=device)
         elif name in ("msm24", "msm20"):
             # config 5: one 2^k-point MSM.  With several ranks the POINTS are split (shard_range: N / world per GPU, no
@@ -580,6 +593,7 @@ def ubench_peaks():
 
 def main():
     args = parse()
+    ProofRunner.EXPLICIT_RNG = args.explicit_rng
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -712,7 +726,7 @@ def main():
                         launches += e.get("launches", 1)                       # mean over the launches, like `achieved`
                 if launches:
                     traffic = tot / launches
-                    traffic_src = os.path.relpath(tj, ROOT) + (" (real circuit, one batch of 16 in flight; mean over %d launches)" % launches
+                    traffic_src = os.path.relpath(tj, ROOT) + (" (real circuit, one default-size batch in flight; mean over %d launches)" % launches
                                                                if tag == "r02" else " (round-1 synthetic circuit: stale for the real one)")
             except Exception:
                 traffic = None

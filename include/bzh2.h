@@ -299,6 +299,15 @@ int bzh_prove_batch(bzh_ctx* ctx, bzh_pk* pk, size_t batch, const uint64_t* advi
                     size_t instance_rows, const uint8_t* rng, size_t rng_stride, uint8_t* proofs, size_t proof_stride,
                     size_t* proof_lens);
 
+/* create_proof with the randomness drawn inside the library, as the reference does from OsRng (benches/shot.rs:68): proof b's
+ * stream is ChaCha20 keyed by seeds[b] (32 bytes; 64-bit block counter from 0, zero nonce), block i being the i-th 64-byte draw
+ * (ff::Field::random), expanded on the device -- no rng_bytes_per_proof (2 MB at k = 14) to generate and upload per proof.
+ * The proofs are exactly those of bzh_prove_batch fed with bzh_rng_expand(seeds[b], 0, rng_bytes_per_proof / 64, ..). */
+int bzh_prove_batch_seeded(bzh_ctx* ctx, bzh_pk* pk, size_t batch, const uint64_t* advice, int form, int mem, const uint64_t* instances,
+                           size_t instance_rows, const uint8_t* seeds, uint8_t* proofs, size_t proof_stride, size_t* proof_lens);
+/* host: draws [first_draw, first_draw + draws) of the stream of `seed`, 64 bytes each, into out */
+int bzh_rng_expand(const uint8_t* seed, uint64_t first_draw, size_t draws, uint8_t* out);
+
 /* ---- Params::new (halo2_proofs poly::commitment::Params; benches/shot.rs:58, benches/board.rs:51, and on every call of
  * the wasm exports, src/wasm/circuit_wasm.rs:57,97,145,180) -------------------------------------------------------
  * A pure function of k: g[i] = hash_to_curve("Halo2-Parameters")(0u8 || i as u32 LE), g_lagrange = inverse group FFT of

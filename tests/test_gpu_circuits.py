@@ -144,6 +144,33 @@ def test_shot_witness_from_the_device_path_gives_the_same_proofs(gpu_ctx, shot_s
     assert pk.prove_batch(None, insts, rbs, device_ptr=dev.data_ptr()) == want
 
 
+def test_seeded_randomness_gives_the_proofs_of_the_expanded_streams(gpu_ctx, shot_setup, board_setup):
+    """bzh_prove_batch_seeded draws each proof's randomness on the device from ChaCha20(seed) (the reference draws from OsRng
+    inside create_proof); the proofs are those of bzh_prove_batch fed with the same streams expanded by bzh_rng_expand
+    (checked against a Python ChaCha20 in tests/test_rng_cpu.py) -- host single draws, device row draws and the opening's
+    rows all address the stream by position."""
+    from bzh2 import circuits as Cm, native as N
+    rng = random.Random(14)
+    lay, blob, pk, _ = shot_setup
+    circuits = _shot_circuits(Cm, rng, 3)
+    adv, insts = lay.synthesize(circuits)
+    seeds = [bytes(rng.getrandbits(8) for _ in range(32)) for _ in circuits]
+    assert pk.rng_bytes % 64 == 0
+    streams = [N.rng_expand(sd, 0, pk.rng_bytes // 64) for sd in seeds]
+    want = pk.prove_batch(adv, insts, streams)
+    got = pk.prove_batch(adv, insts, None, seeds=seeds)
+    assert got == want and len(set(got)) == 3
+    assert pk.verify_batch(insts, got) == [True] * 3
+    # BoardCircuit (lookup argument, more host-side draws), one proof
+    layb, _, pkb, _ = board_setup
+    deck, _ = _random_deck(rng)
+    ships, state = Cm.board_witness(deck, None)
+    cb = [Cm.BoardCircuit(ships, state, rng.randrange(FQ))]
+    advb, instb = layb.synthesize(cb)
+    sd = bytes(rng.getrandbits(8) for _ in range(32))
+    assert pkb.prove_batch(advb, instb, None, seeds=[sd]) == pkb.prove_batch(advb, instb, [N.rng_expand(sd, 0, pkb.rng_bytes // 64)])
+
+
 def test_shot_unsatisfied_witnesses_are_refused_or_rejected(gpu_ctx, shot_setup):
     """A wrong hit assertion, a non-boolean hit, two shots, no shot (src/circuits/shot.rs:261-640): bzh_prove_batch
     returns BZH_E_RANGE, or the proof is rejected by bzh_verify_batch."""

@@ -8,8 +8,8 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $O/proof_k14_default_bench.json 2> $O/proof_k14_default_bench.err && echo default done
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_default -o d -- python3 $R/bench.py --no-cpu-baseline > $O/proof_k14_default_bench_under_rocprof.json 2> $O/prof_default.err && echo prof default done
-python3 $R/bench.py --no-cpu-baseline --concurrency 1 --steps 5 --warmup 2 > $O/proof_k14_b16c1_bench.json 2> /dev/null && echo b16c1 done
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_b16c1 -o d -- python3 $R/bench.py --no-cpu-baseline --concurrency 1 --steps 5 --warmup 2 > $O/proof_k14_b16c1_bench_under_rocprof.json 2> $O/prof_b16c1.err && echo prof b16c1 done
+python3 $R/bench.py --no-cpu-baseline --concurrency 1 --steps 5 --warmup 2 > $O/proof_k14_b32c1_bench.json 2> /dev/null && echo b32c1 done
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_b32c1 -o d -- python3 $R/bench.py --no-cpu-baseline --concurrency 1 --steps 5 --warmup 2 > $O/proof_k14_b32c1_bench_under_rocprof.json 2> $O/prof_b32c1.err && echo prof b32c1 done
 python3 $R/bench.py --no-cpu-baseline --batch 1 --concurrency 1 --steps 10 --warmup 3 > $O/proof_k14_b1c1_bench.json 2> /dev/null && echo b1 done
 python3 $R/bench.py --no-cpu-baseline --workload proof_k11 --batch 1 --concurrency 1 --steps 10 --warmup 3 > $O/proof_k11_b1c1_bench.json 2> /dev/null && echo k11 b1 done
 python3 $R/bench.py --no-cpu-baseline --workload proof_k11 --batch 128 --concurrency 4 --steps 10 --warmup 2 > $O/proof_k11_b128c4_bench.json 2> /dev/null && echo k11 done
@@ -18,4 +18,8 @@ python3 $R/bench.py --no-cpu-baseline --workload proof_k12 --batch 1 --concurren
 python3 $R/bench.py --no-cpu-baseline --workload verify_k14 --batch 64 --steps 5 --warmup 2 > $O/verify_k14_b64_bench.json 2> /dev/null && echo verify done
 python3 $R/bench.py --no-cpu-baseline --workload ntt22 --steps 10 --warmup 2 > $O/ntt22_bench.json 2> /dev/null && echo ntt22 done
 python3 $R/bench.py --no-cpu-baseline --workload msm24 --steps 5 --warmup 2 > $O/msm24_bench.json 2> /dev/null && echo msm24 done
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python3 $R/bench.py --no-cpu-baseline --concurrency 1 --steps 3 --warmup 1 > $O/pmc_fetch.log 2>&1 && echo pmc fetch done
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python3 $R/bench.py --no-cpu-baseline --concurrency 1 --steps 3 --warmup 1 > $O/pmc_write.log 2>&1 && echo pmc write done
+python3 $R/tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write > $O/proof_k14_pmc_traffic.json && rm -rf $O/pmc_fetch $O/pmc_write && echo pmc merged
+(cd $R && bash examples/run_example.sh > $O/example_cpp_client.txt 2>&1; tail -1 $O/example_cpp_client.txt)
 ls $O
