@@ -2160,16 +2160,43 @@ int Prover<C>::prove(const uint32_t* d_advice_in, const uint64_t* instances, siz
         size_t maxpts = 1;
         for (auto& rs : pk.rot_sets) maxpts = std::max(maxpts, rs.size());
         std::vector<Fe<SF>> r_small(B * nq * maxpts, fe_zero<SF>());
+        // Lagrange interpolation through (points, evals) per proof and point set: the denominators prod_(m != j) (x_j - x_m) of
+        // the whole batch are inverted together (one field inversion per batch instead of one per point: ~12 us each on the host)
+        std::vector<Fe<SF>> dinv(B * J2);
         for (size_t b = 0; b < B; b++) {
             size_t o2 = 0;
             for (size_t si = 0; si < nq; si++) {
                 const size_t np = pk.rot_sets[si].size();
-                // Lagrange interpolation through (points, evals): coefficient vector of length np
-                std::vector<Fe<SF>> res(np, fe_zero<SF>());
+                for (size_t j = 0; j < np; j++) {
+                    Fe<SF> dn = fe_one<SF>();
+                    for (size_t mm = 0; mm < np; mm++)
+                        if (mm != j) dn = fe_mul(dn, fe_sub(pts[b * J2 + o2 + j], pts[b * J2 + o2 + mm]));
+                    dinv[b * J2 + o2 + j] = dn;
+                }
+                o2 += np;
+            }
+        }
+        {
+            std::vector<Fe<SF>> pre(dinv.size() + 1);
+            pre[0] = fe_one<SF>();
+            for (size_t i = 0; i < dinv.size(); i++) {
+                if (fe_is_zero(dinv[i])) return BZH_E_ARG;   // two opening points of one set coincide: not a valid domain
+                pre[i + 1] = fe_mul(pre[i], dinv[i]);
+            }
+            Fe<SF> inv = fe_inv(pre[dinv.size()]);
+            for (size_t i = dinv.size(); i-- > 0;) {
+                const Fe<SF> d = dinv[i];
+                dinv[i] = fe_mul(inv, pre[i]);
+                inv = fe_mul(inv, d);
+            }
+        }
+        for (size_t b = 0; b < B; b++) {
+            size_t o2 = 0;
+            for (size_t si = 0; si < nq; si++) {
+                const size_t np = pk.rot_sets[si].size();
+                std::vector<Fe<SF>> res(np, fe_zero<SF>());   // coefficient vector of length np
                 for (size_t j = 0; j < np; j++) {
                     std::vector<Fe<SF>> num{fe_one<SF>()};
-                    Fe<SF> dn = fe_one<SF>();
-                    const Fe<SF> xj = pts[b * J2 + o2 + j];
                     for (size_t mm = 0; mm < np; mm++) {
                         if (mm == j) continue;
                         const Fe<SF> xm = pts[b * J2 + o2 + mm];
@@ -2178,9 +2205,8 @@ int Prover<C>::prove(const uint32_t* d_advice_in, const uint64_t* instances, siz
                         for (size_t i = 1; i < num.size(); i++) nx[i] = fe_sub(num[i - 1], fe_mul(xm, num[i]));
                         nx[num.size()] = num.back();
                         num.swap(nx);
-                        dn = fe_mul(dn, fe_sub(xj, xm));
                     }
-                    const Fe<SF> cf = fe_mul(ev[b * J2 + o2 + j], fe_inv(dn));
+                    const Fe<SF> cf = fe_mul(ev[b * J2 + o2 + j], dinv[b * J2 + o2 + j]);
                     for (size_t i = 0; i < num.size(); i++) res[i] = fe_add(res[i], fe_mul(cf, num[i]));
                 }
                 for (size_t i = 0; i < np; i++) r_small[(b * nq + si) * maxpts + i] = res[i];
