@@ -1069,7 +1069,11 @@ static int msm_run_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_sca
         const char* e = getenv("BZH_ACC_THREADS");
         return e ? atoi(e) : 0;
     }();
-    const int acc_threads = acc_threads_env == 256 || acc_threads_env == 512 ? acc_threads_env : (p.chunk >= 8192 ? 512 : 256);
+    // 256 threads per chunk (128-item slices at the full chunk size) measured better than 512 wherever several launches share the
+    // GPU and also with one batch in flight (k = 14 default 453 vs 440 proofs/s, 366 vs 356 single stream; k = 11 3 683 vs 3 555):
+    // fewer, longer slices mean fewer buckets cut by slice boundaries to stitch, and the LDS-bound two workgroups per CU leave
+    // more room for the other streams' kernels
+    const int acc_threads = acc_threads_env == 128 || acc_threads_env == 256 || acc_threads_env == 512 ? acc_threads_env : 256;
     const size_t part_bytes = (size_t)2 * acc_threads * 128;  // per segment: two stitch buffers
     int rc;
     if ((rc = ws_ensure(ctx, 0, slice * (size_t)p.nwin * n * sizeof(uint16_t), &d_digits))) return rc;
@@ -1107,7 +1111,7 @@ static int msm_run_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_sca
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         BZH_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msm_accumulate<C, 512>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        BZH_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msm_accumulate<C, 1024>),
+        BZH_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msm_accumulate<C, 128>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         BZH_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msm_reduce<C>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
@@ -1161,7 +1165,7 @@ static int msm_run_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_sca
     hipLaunchKernelGGL((k_msm_accumulate<C, TT>), grid, dim3(TT), acc_lds, ctx->stream, bases->d_xy,                      \
                        (const uint16_t*)d_digits, n_eff, acc_nwin, M_acc, p.chunk, (uint4*)d_buckets, d_partials, row_len, \
                        row_stride, pair_in ? n - 2 : (size_t)0, ctx->profiling ? ctx->d_add_counter : nullptr)
-            if (acc_threads == 1024) BZH_LAUNCH_ACC(1024);
+            if (acc_threads == 128) BZH_LAUNCH_ACC(128);
             else if (acc_threads == 512) BZH_LAUNCH_ACC(512);
             else BZH_LAUNCH_ACC(256);
 #undef BZH_LAUNCH_ACC
