@@ -103,7 +103,7 @@ def parse():
                     help="gloo + several ranks on one GPU rehearses the multi-rank path on a single-GPU box (ranks share device "
                          "local_rank %% device_count); the driver's multi-GPU runs use nccl (RCCL)")
     ap.add_argument("--no-precompute", action="store_true", help="plain bases: no fixed-base window table for the SRS")
-    ap.add_argument("--batch", type=int, default=32,
+    ap.add_argument("--batch", type=int, default=64,
                     help="proof_k* workloads: witnesses synthesised and proved in lockstep per bzh_prove_batch call; "
                          "1 = the single-proof latency path")
     ap.add_argument("--circuit", default="auto", choices=["auto", "shot", "board"],
@@ -386,6 +386,8 @@ class Workload:
             k = int(name[len("proof_k"):])
             self.k = k
             kind = circuit if circuit != "auto" else ("shot" if k == 11 else "board")
+            if k >= 16:
+                batch = min(batch, 8)   # 2^17-row tables: 8 proofs per batch already fill the GPU (and 21 GB of cosets per worker)
             wb = window_bits or (8 if batch == 1 else 0)
             self.window_bits = wb
             self.runner = ProofRunner(kind, k, ctx, device, seed, batch=batch, workers=concurrency, window_bits=wb, first_ctx=ctx)
@@ -399,6 +401,7 @@ class Workload:
             self.calls = [("bzh_synthesize_%s + bzh_prove_batch" % kind, prove)]
             self.solo_step = lambda: self.runner.plan(0, batch)[0]()
             self.units_per_step = batch * concurrency
+            self.batch = batch
             self.records = self.runner.proof_records
             self.verify_last = self.runner.verify_last
             self.alg_bytes_msm_launch = 0
@@ -817,9 +820,9 @@ def main():
             line["config"]["srs"] = "Params::new(%d): hash_to_curve generators + g_lagrange (csrc/params.hip); witness / lookup / grand-product columns committed in the Lagrange basis" % wl.k
             line["config"]["proof_bytes"] = len(wl.runner.last_batch[0][0])
             line["config"]["last_batches_verified"] = verified
-            line["config"]["proofs_in_flight_per_gpu"] = args.concurrency * args.batch
+            line["config"]["proofs_in_flight_per_gpu"] = args.concurrency * getattr(wl, "batch", args.batch)
             line["config"]["concurrent_batches"] = args.concurrency
-            line["config"]["batch"] = args.batch
+            line["config"]["batch"] = getattr(wl, "batch", args.batch)
             line["config"]["srs_window_bits"] = wl.window_bits or "planner"
             line["config"]["distinct_proofs_in_last_batch"] = len(set(wl.runner.last_batch[0]))
         if world == 1 and not args.no_cpu_baseline:

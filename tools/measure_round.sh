@@ -8,12 +8,12 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $O/proof_k14_default_bench.json 2> $O/proof_k14_default_bench.err && echo default done
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_default -o d -- python3 $R/bench.py --no-cpu-baseline > $O/proof_k14_default_bench_under_rocprof.json 2> $O/prof_default.err && echo prof default done
-python3 $R/bench.py --no-cpu-baseline --concurrency 1 --steps 5 --warmup 2 > $O/proof_k14_b32c1_bench.json 2> /dev/null && echo b32c1 done
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_b32c1 -o d -- python3 $R/bench.py --no-cpu-baseline --concurrency 1 --steps 5 --warmup 2 > $O/proof_k14_b32c1_bench_under_rocprof.json 2> $O/prof_b32c1.err && echo prof b32c1 done
+python3 $R/bench.py --no-cpu-baseline --concurrency 1 --steps 5 --warmup 2 > $O/proof_k14_b64c1_bench.json 2> /dev/null && echo b64c1 done
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_b64c1 -o d -- python3 $R/bench.py --no-cpu-baseline --concurrency 1 --steps 5 --warmup 2 > $O/proof_k14_b64c1_bench_under_rocprof.json 2> $O/prof_b64c1.err && echo prof b64c1 done
 python3 $R/bench.py --no-cpu-baseline --batch 1 --concurrency 1 --steps 10 --warmup 3 > $O/proof_k14_b1c1_bench.json 2> /dev/null && echo b1 done
 python3 $R/bench.py --no-cpu-baseline --workload proof_k11 --batch 1 --concurrency 1 --steps 10 --warmup 3 > $O/proof_k11_b1c1_bench.json 2> /dev/null && echo k11 b1 done
-python3 $R/bench.py --no-cpu-baseline --workload proof_k11 --batch 128 --concurrency 4 --steps 10 --warmup 2 > $O/proof_k11_b128c4_bench.json 2> /dev/null && echo k11 done
-python3 $R/bench.py --no-cpu-baseline --workload proof_k12 --batch 32 --concurrency 4 --steps 10 --warmup 2 > $O/proof_k12_b32c4_bench.json 2> /dev/null && echo k12 done
+python3 $R/bench.py --no-cpu-baseline --workload proof_k11 --batch 128 --concurrency 8 --steps 8 --warmup 2 > $O/proof_k11_b128c8_bench.json 2> /dev/null && echo k11 done
+python3 $R/bench.py --no-cpu-baseline --workload proof_k12 --batch 64 --concurrency 4 --steps 8 --warmup 2 > $O/proof_k12_b64c4_bench.json 2> /dev/null && echo k12 done
 python3 $R/bench.py --no-cpu-baseline --workload proof_k12 --batch 1 --concurrency 1 --steps 10 --warmup 3 > $O/proof_k12_b1c1_bench.json 2> /dev/null && echo k12 b1 done
 python3 $R/bench.py --no-cpu-baseline --workload verify_k14 --batch 64 --steps 5 --warmup 2 > $O/verify_k14_b64_bench.json 2> /dev/null && echo verify done
 python3 $R/bench.py --no-cpu-baseline --workload ntt22 --steps 10 --warmup 2 > $O/ntt22_bench.json 2> /dev/null && echo ntt22 done
