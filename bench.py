@@ -721,7 +721,7 @@ def main():
             try:
                 tot, launches = 0.0, 0
                 for e in json.load(open(tj))["kernels"]:
-                    if want_kernel in e["kernel"] and (want_kernel != "k_msm_accumulate" or "512" in e["kernel"] or e.get("workgroup", 0) >= 512):
+                    if want_kernel in e["kernel"]:
                         # coalesced 16-B-per-lane streams (the evaluator's column reads): FETCH_SIZE doubled as the guide prescribes;
                         # the accumulate kernel's 64-B table gathers: raw count (calibration note in the round-1 traffic file)
                         rd = e["read_bytes"] if want_kernel == "k_expr_vm2" else e["read_bytes_raw"]
