@@ -120,7 +120,7 @@ def test_plain_inverse_all_pass_counts(gpu_ctx, oracle_c, k):
     assert (gpu_ctx.ntt(1, a, omega=w, inverse=True) == C.ntt(1, a, w, inverse=True, threads=8)).all()
 
 
-@pytest.mark.parametrize("k,ext", [(3, 3), (5, 2), (8, 3), (9, 3), (11, 3), (11, 2), (12, 1), (14, 3), (10, 4)])
+@pytest.mark.parametrize("k,ext", [(3, 3), (5, 2), (8, 3), (9, 3), (11, 3), (11, 2), (12, 1), (14, 3), (10, 4), (6, 0), (12, 0), (4, 8), (3, 10)])
 @pytest.mark.parametrize("shift", ["zeta", "generator", None])
 def test_coeff_to_extended_matches_padded_oracle_ntt(gpu_ctx, oracle_c, k, ext, shift):
     """bzh_coeff_to_extended reads only the 2^k coefficients; the result is the coset NTT of the zero-padded vector
