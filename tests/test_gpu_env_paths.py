@@ -1,0 +1,46 @@
+"""The library's tuning knobs and fallback paths (environment variables read once per process) must not change a single
+bit: the global-sort MSM path, other accumulate workgroup / chunk sizes, the quotient VM v1 fallback, no hoisted
+columns, other shared-subexpression slot counts.  Each setting runs tests/helpers/env_case.py in its own process; all digests
+(MSM results + the bytes of two real ShotCircuit proofs under fixed seeds) must equal the default's."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CASE = os.path.join(ROOT, "tests", "helpers", "env_case.py")
+
+SETTINGS = [
+    {"BZH_MSM_GS": "1"},
+    {"BZH_ACC_THREADS": "128"},
+    {"BZH_ACC_THREADS": "512", "BZH_ACC_CHUNK": "4096"},
+    {"BZH_QUOTIENT_V1": "1"},
+    {"BZH_NO_HOIST": "1"},
+    {"BZH_VM2_CSE": "0"},
+    {"BZH_VM2_CSE": "6"},
+]
+
+
+def _digest(extra):
+    env = dict(os.environ)
+    for k in ("BZH_MSM_GS", "BZH_ACC_THREADS", "BZH_ACC_CHUNK", "BZH_QUOTIENT_V1", "BZH_NO_HOIST", "BZH_VM2_CSE"):
+        env.pop(k, None)
+    env.update(extra)
+    out = subprocess.run([sys.executable, CASE], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("DIGEST ")]
+    assert len(lines) == 1, out.stdout[-500:]
+    return lines[0].split()[1]
+
+
+@pytest.fixture(scope="module")
+def default_digest():
+    return _digest({})
+
+
+@pytest.mark.parametrize("setting", SETTINGS, ids=lambda s: ",".join("%s=%s" % kv for kv in s.items()))
+def test_env_setting_changes_no_bit(default_digest, setting):
+    assert _digest(setting) == default_digest
