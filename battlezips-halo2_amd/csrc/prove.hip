@@ -1720,7 +1720,8 @@ int Prover<C>::prove(const uint32_t* d_advice_in, const uint64_t* instances, siz
         uint64_t* as = (uint64_t*)as_c;
         for (size_t v = 0; v < 2 * B; v++) memset(as + (v * n + usable) * 4, 0, (n - usable) * 32);
         {  // one sort per proof on host threads
-            const size_t nthreads = std::min<size_t>(B, std::max(1u, std::thread::hardware_concurrency()));
+            // short-lived pool, capped: several provers (threads, ranks) run this at once on the same host
+            const size_t nthreads = std::min<size_t>({B, (size_t)std::max(1u, std::thread::hardware_concurrency()), (size_t)8});
             std::vector<int> rcs(B, BZH_OK);
             std::vector<std::thread> th;
             for (size_t t = 0; t < nthreads; t++)
@@ -2786,7 +2787,7 @@ static int verify_batch_t(bzh_ctx* ctx, bzh_pk* pk, size_t batch, const uint64_t
     const size_t nl_cap = ncommit + 2 * (size_t)pk->k + 1 + 3 + 4;
     std::vector<ProofView<C>> views(B);
     {
-        const size_t nthreads = std::min<size_t>(B, std::max(1u, std::thread::hardware_concurrency()));
+        const size_t nthreads = std::min<size_t>({B, (size_t)std::max(1u, std::thread::hardware_concurrency()), (size_t)32});
         std::vector<std::thread> th;
         for (size_t t = 0; t < nthreads; t++)
             th.emplace_back([&, t]() {

@@ -596,6 +596,7 @@ def ubench_peaks():
 
 def main():
     args = parse()
+    torch.set_num_threads(2)   # torch is plumbing here (device tensors, streams, the final gather): no CPU op pools per rank
     ProofRunner.EXPLICIT_RNG = args.explicit_rng
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
