@@ -149,7 +149,6 @@ static void init_fields(void) {
 typedef struct { fe x, y, z; } jac;   /* z == 0 <=> identity */
 typedef struct { fe x, y; } aff;      /* (0,0) <=> identity */
 static const int CURVE_BASE[3] = {1, 0, 3};
-static const int CURVE_SCALAR[3] = {0, 1, 2};
 
 static inline int aff_is_id(const aff *a) { return f_is_zero(&a->x) && f_is_zero(&a->y); }
 static inline void jac_set_id(jac *o) { memset(o, 0, sizeof(*o)); }
