@@ -97,7 +97,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="proof_k14",
                     choices=["board_k14", "board_k12", "shot_k11", "board_k17", "shot_k11_batch", "msm24", "msm20", "ntt22",
-                             "proof_k11", "proof_k12", "proof_k14", "proof_k8", "proof_k17", "verify_k11", "verify_k14", "mixed_board_shot"])
+                             "proof_k11", "proof_k12", "proof_k14", "proof_k17", "verify_k11", "verify_k14", "mixed_board_shot"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + several ranks on one GPU rehearses the multi-rank path on a single-GPU box (ranks share device "
