@@ -262,7 +262,8 @@ int bzh_ipa_verify(bzh_ctx* ctx, const bzh_bases* bases, const uint64_t* commitm
 /* ---- whole proofs (halo2_proofs plonk::{keygen_pk, create_proof}; reference call sites benches/shot.rs:58-71,
  * benches/board.rs:51-71, src/circuits/shot.rs:915-930, src/circuits/board.rs:907-922) ----------------------
  * bzh_pk_create    keygen_pk for a circuit given as data (serialised constraint system + fixed assignment; the
- *                  format is documented at the top of csrc/prove.hip and produced by bzh2.prover.Circuit.serialize()):
+ *                  format is documented at the top of csrc/prove.hip; produced by bzh_circuit_blob for the reference's circuits and by
+ *                  bzh2.circuit_data.serialize_circuit for test circuits):
  *                  fixed / permutation polynomials in Lagrange, coefficient and extended-coset form, l_0 / l_last /
  *                  l_blind, resident on the device.  `srs`: n + 2 points G_0..G_(n-1), U, W with a window table
  *                  (bzh_bases_precompute); it must outlive the key.
