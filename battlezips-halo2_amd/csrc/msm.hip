@@ -9,13 +9,14 @@
 //
 // Pipeline (all on the ctx's stream):
 //   k_msm_digits      scalars -> signed c-bit digits, u16 [vector][window][point]
-//   k_msm_accumulate  one workgroup per (chunk, window, vector): LDS histogram ->
-//                     LDS scan -> LDS scatter (bucket-sorted point list, u16) ->
-//                     thread-per-bucket XYZZ mixed additions, points gathered
-//                     from the HBM/L2-resident base table (64 B per point)
-//   k_msm_reduce      per segment: sum_m m*B_m via sliced running sums, an LDS
-//                     suffix scan and LDS tree sums
-//   k_msm_finalize    per vector: sum chunks per window, Horner over windows
+//   k_msm_accumulate  one workgroup (256 threads) per (chunk, window, vector): LDS histogram ->
+//                     LDS scan -> LDS scatter (bucket-sorted point list, u16) -> equal slices of that
+//                     list per thread, XYZZ mixed additions, points gathered from the HBM/L2-resident
+//                     base table (64 B per point), buckets cut by slice boundaries stitched
+//   k_msm_chunksum    window-table MSMs with enough vectors: bucket-wise sum of a vector's chunks
+//   k_msm_reduce      per segment: sum_m m*B_m via sliced running sums, an LDS suffix scan and LDS
+//                     tree sums; writes the Jacobian result itself when the segment is the result
+//   k_msm_finalize    otherwise, per vector: sum chunks per window, Horner over windows
 // Modular-integer work (v_mad_u64_u32), no MFMA.
 #include "ctx.hpp"
 #include "curve.cuh"
