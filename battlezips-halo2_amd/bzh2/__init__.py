@@ -478,7 +478,7 @@ class Transcript:
 
 # ---- IPA opening --------------------------------------------------------------------------------
 EXPORTS += ["bzh_ipa_open", "bzh_ipa_open_batch", "bzh_ipa_verify"]
-EXPORTS += ["bzh_pk_create", "bzh_pk_free", "bzh_pk_set_lagrange", "bzh_pk_quotient_stats", "bzh_pk_info", "bzh_prove_batch", "bzh_prove_batch_seeded", "bzh_rng_expand", "bzh_verify_batch"]
+EXPORTS += ["bzh_pk_create", "bzh_pk_free", "bzh_pk_set_lagrange", "bzh_pk_quotient_stats", "bzh_pk_quotient_source", "bzh_pk_set_quotient_module", "bzh_pk_info", "bzh_prove_batch", "bzh_prove_batch_seeded", "bzh_rng_expand", "bzh_verify_batch"]
 # Params::new (bzh2/params.py)
 EXPORTS += ["bzh_hash_to_curve", "bzh_params_generators", "bzh_group_ifft", "bzh_params_create", "bzh_params_free", "bzh_params_bases",
             "bzh_params_points"]

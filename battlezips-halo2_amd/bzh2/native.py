@@ -44,6 +44,47 @@ def rng_expand(seed: bytes, first_draw: int, draws: int) -> bytes:
     return out.tobytes()
 
 
+_QUOTIENT_CODE = {}   # source hash -> code object (several keys of one circuit in a process share one compilation)
+
+
+def compile_quotient_source(src: str, cache_dir: str | None = None) -> bytes | None:
+    """hipcc --genco of a bzh_pk_quotient_source text against csrc/field.cuh; the code object, or None."""
+    import hashlib
+    import os
+    import shutil
+    import subprocess
+    import tempfile
+    key = hashlib.sha256(src.encode()).hexdigest()[:24]
+    if key in _QUOTIENT_CODE:
+        return _QUOTIENT_CODE[key]
+    pkg = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cache_dir = cache_dir or os.environ.get("BZH_CACHE_DIR") or os.path.join(os.path.dirname(pkg), ".bzh2_cache")
+    path = os.path.join(cache_dir, "quotient_%s_gfx950.hsaco" % key)
+    if os.path.exists(path):
+        _QUOTIENT_CODE[key] = open(path, "rb").read()
+        return _QUOTIENT_CODE[key]
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        return None
+    with tempfile.TemporaryDirectory() as td:
+        srcp, outp = os.path.join(td, "quotient.hip"), os.path.join(td, "quotient.hsaco")
+        open(srcp, "w").write(src)
+        r = subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "--genco", "-I", os.path.join(pkg, "csrc"), srcp, "-o", outp],
+                           capture_output=True, text=True)
+        if r.returncode != 0 or not os.path.exists(outp):
+            return None
+        code = open(outp, "rb").read()
+    try:
+        os.makedirs(cache_dir, exist_ok=True)
+        tmp = "%s.tmp%d" % (path, os.getpid())
+        open(tmp, "wb").write(code)
+        os.replace(tmp, path)
+    except OSError:
+        pass
+    _QUOTIENT_CODE[key] = code
+    return code
+
+
 class NativeProvingKey:
     """keygen_pk on the device.  g: the n SRS points, w / u: Params.w / Params.u (affine canonical int pairs)."""
 
@@ -83,6 +124,32 @@ class NativeProvingKey:
         v = [ctypes.c_uint32() for _ in range(4)]
         self.ctx._check(L.bzh_pk_quotient_stats(self.handle, *[ctypes.byref(x) for x in v]), "bzh_pk_quotient_stats")
         return {"ops": v[0].value, "multiplications_per_row": v[1].value, "lds_slots": v[2].value, "hoisted_columns": v[3].value}
+
+    # ---- the quotient evaluator as compiled code -------------------------------------------------------------
+    def quotient_source(self) -> str:
+        """the evaluator program as straight-line HIP source (BzhError E_RANGE before the key's first proof)"""
+        L = _bind()
+        L.bzh_pk_quotient_source.argtypes = [_VP, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+        n = ctypes.c_size_t()
+        self.ctx._check(L.bzh_pk_quotient_source(self.handle, None, 0, ctypes.byref(n)), "bzh_pk_quotient_source")
+        buf = ctypes.create_string_buffer(n.value + 1)
+        self.ctx._check(L.bzh_pk_quotient_source(self.handle, buf, n.value + 1, ctypes.byref(n)), "bzh_pk_quotient_source")
+        return buf.value.decode()
+
+    def set_quotient_module(self, code_object: bytes | None):
+        L = _bind()
+        L.bzh_pk_set_quotient_module.argtypes = [_VP, _VP, ctypes.c_char_p, ctypes.c_size_t]
+        self.ctx._check(L.bzh_pk_set_quotient_module(self.ctx.handle, self.handle, code_object, len(code_object) if code_object else 0),
+                        "bzh_pk_set_quotient_module")
+
+    def compile_quotient(self, cache_dir: str | None = None) -> bool:
+        """Compile quotient_source() with hipcc (a child process; ~5 s, cached on disk by the hash of the source) and install
+        it.  False (the interpreter stays) when there is no hipcc or the compilation fails."""
+        code = compile_quotient_source(self.quotient_source(), cache_dir)
+        if code is None:
+            return False
+        self.set_quotient_module(code)
+        return True
 
     def set_lagrange(self, bases_lagrange):
         """Params::commit_lagrange for the columns upstream commits in the Lagrange basis (None: back to coefficients)."""

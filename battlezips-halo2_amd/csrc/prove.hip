@@ -32,6 +32,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -369,6 +370,103 @@ struct Program2 {
     bool ok = true;
     int nlds = 2;
 };
+
+// FNV-1a over the instruction words: ties a compiled quotient module to the program it was generated from
+static uint64_t program2_hash(const Program2& pg, int field) {
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](const void* p, size_t n) {
+        for (size_t i = 0; i < n; i++) h = (h ^ ((const uint8_t*)p)[i]) * 1099511628211ull;
+    };
+    mix(&field, sizeof(field));
+    mix(&pg.nlds, sizeof(pg.nlds));
+    for (const ExprOp2& o : pg.ops) {
+        const int32_t w[7] = {o.code, o.a_kind, o.a_idx, o.a_rot, o.b_kind, o.b_idx, o.b_rot};
+        mix(w, sizeof(w));
+    }
+    return h;
+}
+
+// The VM v2 program as straight-line HIP source (compiled by the caller with hipcc / hiprtc against csrc/field.cuh and handed
+// back through bzh_pk_set_quotient_module).  The evaluation stack r0..r3 and the slot file become local values; every memory
+// operand is loaded one instruction ahead of its use and a scheduling barrier follows every instruction -- without it the
+// compiler hoists all ~750 leaf loads to the top (255 VGPRs and scratch); with it 106 VGPRs, four waves per SIMD.  Measured
+// on the BoardCircuit program (1 361 instructions, 16 x 2^17 rows): 9.0 ms against the interpreter's 12.5 ms, same bits.
+static std::string program2_source(const Program2& pg, int field) {
+    std::string src;
+    char buf[512];
+    auto add = [&](const char* fmt, auto... a) {
+        snprintf(buf, sizeof(buf), fmt, a...);
+        src += buf;
+    };
+    add("// generated by libbzh2 (bzh_pk_quotient_source): quotient evaluator, %zu instructions\n", pg.ops.size());
+    src += "#include \"field.cuh\"\nusing namespace bzh;\n";
+    add("typedef %s P;\n", field == BZH_FIELD_FQ ? "FqParams" : "FpParams");
+    add("extern \"C\" __device__ __attribute__((used)) unsigned long long jit_program_hash = 0x%llxull;\n",
+        (unsigned long long)program2_hash(pg, field));
+    src += "__device__ __noinline__ Fe<P> mulx(const Fe<P> a, const Fe<P> b) { return fe_mul(a, b); }\n";
+    src += "extern \"C\" __global__ void __launch_bounds__(128) jit_quotient(const uint32_t* const* __restrict__ cols, "
+           "const size_t* __restrict__ strides, const uint32_t* __restrict__ consts, size_t const_stride, size_t size, "
+           "uint32_t* __restrict__ out) {\n"
+           "    const size_t r = blockIdx.x * (size_t)128 + threadIdx.x, v = blockIdx.y;\n"
+           "    if (r >= size) return;\n"
+           "    const size_t mask = size - 1;\n"
+           "    const uint32_t* cv = consts + v * const_stride * 8;\n"
+           "    Fe<P> r0 = fe_zero<P>(), r1 = r0, r2 = r0, r3 = r0;\n";
+    for (int i = 0; i < std::max(pg.nlds, 1); i++) add("    Fe<P> s%d = r0;\n", i);
+    const size_t nops = pg.ops.size();
+    auto is_mem = [](int kind) { return kind == BZH_EXPR_COLUMN || kind == BZH_EXPR_CONST; };
+    auto emit_load = [&](const char* name, size_t i, int kind, int idx, int rot) {
+        if (kind == BZH_EXPR_COLUMN)
+            add("    const Fe<P> %s%zu = fe_load<P>(cols[%d] + (v * strides[%d] + ((r + (size_t)(long)(%d)) & mask)) * 8);\n", name, i, idx, idx, rot);
+        else if (kind == BZH_EXPR_CONST)
+            add("    const Fe<P> %s%zu = fe_load<P>(cv + %d * 8);\n", name, i, idx);
+    };
+    auto emit_loads = [&](size_t i) {
+        if (i >= nops) return;
+        const ExprOp2& o = pg.ops[i];
+        const int form = o.code >> 4, op = (o.code >> 2) & 3;
+        if (form == V2_LL || (form == V2_UN && op == V2_LOAD)) emit_load("la", i, o.a_kind, o.a_idx, o.a_rot);
+        if (form == V2_SL || form == V2_LL) emit_load("lb", i, o.b_kind, o.b_idx, o.b_rot);
+    };
+    auto operand = [&](const char* name, size_t i, int kind, int idx) -> std::string {
+        char t[32];
+        if (is_mem(kind)) snprintf(t, sizeof(t), "%s%zu", name, i);
+        else snprintf(t, sizeof(t), "s%d", idx);
+        return t;
+    };
+    auto arith = [&](int op, const std::string& a, const std::string& b) -> std::string {
+        switch (op) {
+            case V2_ADD: return "fe_add(" + a + ", " + b + ")";
+            case V2_SUB: return "fe_sub(" + a + ", " + b + ")";
+            case V2_MUL: return "mulx(" + a + ", " + b + ")";
+            default: return "fe_sub(" + b + ", " + a + ")";   // RSUB: b - a
+        }
+    };
+    static const char* const regs[4] = {"r0", "r1", "r2", "r3"};
+    emit_loads(0);
+    for (size_t i = 0; i < nops; i++) {
+        const ExprOp2& o = pg.ops[i];
+        const int form = o.code >> 4, op = (o.code >> 2) & 3, pos = o.code & 3;
+        emit_loads(i + 1);
+        const std::string ra = regs[pos];
+        if (form == V2_SS) {
+            src += "    " + ra + " = " + arith(op, ra, regs[(pos + 1) & 3]) + ";\n";
+        } else if (form == V2_SL) {
+            src += "    " + ra + " = " + arith(op, ra, operand("lb", i, o.b_kind, o.b_idx)) + ";\n";
+        } else if (form == V2_LL) {
+            src += "    " + ra + " = " + arith(op, operand("la", i, o.a_kind, o.a_idx), operand("lb", i, o.b_kind, o.b_idx)) + ";\n";
+        } else if (op == V2_NEG) {
+            src += "    " + ra + " = fe_neg(" + ra + ");\n";
+        } else if (op == V2_LOAD) {
+            src += "    " + ra + " = " + operand("la", i, o.a_kind, o.a_idx) + ";\n";
+        } else {
+            add("    s%d = %s;\n", o.a_idx, ra.c_str());
+        }
+        src += "    __builtin_amdgcn_sched_barrier(0);\n";
+    }
+    src += "    fe_store(out + (v * size + r) * 8, r0);\n}\n";
+    return src;
+}
 
 struct Compiler2 {
     const EPool& pool;
@@ -743,6 +841,10 @@ struct bzh_pk {
              *sigma_cosets = nullptr, *l0 = nullptr, *l_last = nullptr, *l_blind = nullptr, *x_col = nullptr, *tinv_col = nullptr;
     std::map<uint64_t, bzh::Program> progs;
     std::map<uint64_t, bzh::Program2> progs2;   // VM v2 programs (the quotient)
+    // the quotient program as a compiled code object (bzh_pk_quotient_source / bzh_pk_set_quotient_module): launched instead of
+    // the interpreter when present
+    hipModule_t q_module = nullptr;
+    hipFunction_t q_fn = nullptr;
     // proof-independent subexpressions of the quotient (selector products ...) evaluated once on the extended coset
     uint32_t* hoist = nullptr;
     size_t hoist_cols = 0;
@@ -1590,6 +1692,17 @@ struct Prover {
             double cols_read = 0;   // count per proof, columns of the key once per launch
             for (size_t i = 0; i < reg.stride.size(); i++) cols_read += reg.stride[i] ? (double)B : 1.0;
             ctx->alg_bytes[BZH_T_QUOTIENT] += (cols_read + (double)B) * (double)size * 32.0;
+        }
+        if (pk.q_fn) {   // the same program as compiled code (bzh_pk_set_quotient_module)
+            ScopedTimer t(ctx, BZH_T_QUOTIENT);
+            const uint32_t* const* a_cols = (const uint32_t* const*)d_ptrs;
+            const size_t* a_strides = (const size_t*)d_strides;
+            const uint32_t* a_consts = d_consts;
+            size_t a_nc = nc, a_size = size;
+            uint32_t* a_out = d_out;
+            void* args[] = {&a_cols, &a_strides, &a_consts, &a_nc, &a_size, &a_out};
+            BZH_HIP_TRY(ctx, hipModuleLaunchKernel(pk.q_fn, (unsigned)(size / 128), (unsigned)B, 1, 128, 1, 1, 0, st, args, nullptr));
+            return BZH_OK;
         }
         return expr_eval2(ctx, field, d_prog, (int)pg.ops.size(), (const uint32_t* const*)d_ptrs, (const size_t*)d_strides, d_consts, nc, size, B,
                           pg.nlds, d_out);
@@ -2841,6 +2954,7 @@ int bzh_pk_free(bzh_ctx* ctx, bzh_pk* pk) {
     (void)hipStreamSynchronize(ctx->stream);
     if (pk->dev) (void)hipFree(pk->dev);
     if (pk->hoist) (void)hipFree(pk->hoist);
+    if (pk->q_module) (void)hipModuleUnload(pk->q_module);
     pk->arena.release();
     delete pk;
     return BZH_OK;
@@ -2868,6 +2982,53 @@ int bzh_pk_quotient_stats(bzh_pk* pk, uint32_t* ops, uint32_t* multiplications, 
     if (multiplications) *multiplications = nm;
     if (lds_slots) *lds_slots = nl;
     if (hoisted_columns) *hoisted_columns = (uint32_t)pk->hoist_cols;
+    return BZH_OK;
+}
+
+int bzh_pk_quotient_source(bzh_pk* pk, char* buf, size_t cap, size_t* len) {
+    if (!pk || !len) return BZH_E_ARG;
+    std::lock_guard<std::mutex> lk(pk->mu);
+    if (pk->progs2.empty()) return BZH_E_RANGE;   // compiled at the key's first proof
+    const std::string src = bzh::program2_source(pk->progs2.begin()->second, pk->field);
+    *len = src.size();
+    if (buf && cap) {
+        const size_t n = std::min(cap - 1, src.size());
+        memcpy(buf, src.data(), n);
+        buf[n] = 0;
+    }
+    return BZH_OK;
+}
+
+int bzh_pk_set_quotient_module(bzh_ctx* ctx, bzh_pk* pk, const void* code_object, size_t len) {
+    if (!ctx || !pk || pk->device != ctx->device) return BZH_E_ARG;
+    std::lock_guard<std::mutex> lkp(pk->mu);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    BZH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (pk->q_module) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipModuleUnload(pk->q_module);
+        pk->q_module = nullptr;
+        pk->q_fn = nullptr;
+    }
+    if (!code_object || !len) return BZH_OK;   // back to the interpreter
+    if (pk->progs2.empty()) return BZH_E_RANGE;
+    hipModule_t mod = nullptr;
+    BZH_HIP_TRY(ctx, hipModuleLoadData(&mod, code_object));
+    hipFunction_t fn = nullptr;
+    hipDeviceptr_t hsym = nullptr;
+    size_t hbytes = 0;
+    unsigned long long have = 0;
+    const bool ok = hipModuleGetFunction(&fn, mod, "jit_quotient") == hipSuccess &&
+                    hipModuleGetGlobal(&hsym, &hbytes, mod, "jit_program_hash") == hipSuccess && hbytes == 8 &&
+                    hipMemcpy(&have, hsym, 8, hipMemcpyDeviceToHost) == hipSuccess &&
+                    have == bzh::program2_hash(pk->progs2.begin()->second, pk->field);
+    if (!ok) {
+        (void)hipModuleUnload(mod);
+        ctx->last_error = "bzh_pk_set_quotient_module: not a module generated from this key's quotient program";
+        return BZH_E_ARG;
+    }
+    pk->q_module = mod;
+    pk->q_fn = fn;
     return BZH_OK;
 }
 

@@ -110,6 +110,9 @@ def parse():
                     help="proof_k* workloads: which of the reference's circuits (auto: ShotCircuit at k = 11, BoardCircuit otherwise)")
     ap.add_argument("--mix-divisor", type=int, default=1, help="mixed_board_shot: divide the fixed batch (256 Board + 2560 Shot) by this")
     ap.add_argument("--window-bits", type=int, default=0, help="SRS window-table width (0: 8 for --batch 1, else the planner's)")
+    ap.add_argument("--no-quotient-codegen", action="store_true",
+                    help="proof_k* workloads: keep the interpreted quotient evaluator (default: its program is compiled with hipcc at setup, "
+                         "bzh_pk_quotient_source / bzh_pk_set_quotient_module)")
     ap.add_argument("--explicit-rng", action="store_true",
                     help="proof_k* workloads: generate every proof's random stream on the host (numpy) and pass it to bzh_prove_batch "
                          "instead of a 32-byte seed per proof expanded on the device (bzh_prove_batch_seeded)")
@@ -171,6 +174,7 @@ def random_fleet(rng):
 
 class ProofRunner:
     EXPLICIT_RNG = False   # --explicit-rng
+    QUOTIENT_CODEGEN = True   # --no-quotient-codegen
     """`workers` host threads, each with its own ctx + stream + proving key + advice tensor in HBM, proving slices of
     `batch` witnesses of one real circuit: bzh_synthesize_{shot,board} (device output) then bzh_prove_batch."""
 
@@ -223,6 +227,19 @@ class ProofRunner:
         self.last_insts = [[] for _ in range(workers)]
         self.step_batches = [[] for _ in range(workers)]      # every batch of the current plan (for the record gather)
         self.np_rng = [np.random.default_rng(seed + 1000 + wi) for wi in range(workers)]
+        # The quotient evaluator as compiled code (bzh_pk_quotient_source -> hipcc -> bzh_pk_set_quotient_module): the program exists
+        # after a key's first proof, so every key proves one witness here (setup, like keygen), then gets the module -- one
+        # compilation per circuit and process, cached on disk.
+        self.quotient_codegen = False
+        if ProofRunner.QUOTIENT_CODEGEN:
+            ok = True
+            for wi in range(workers):
+                self._prove_slice(wi, 0, 1)
+                ok = self.pks[wi].compile_quotient() and ok
+            self.quotient_codegen = ok
+            self.last_batch = [[] for _ in range(workers)]
+            self.last_insts = [[] for _ in range(workers)]
+            self.step_batches = [[] for _ in range(workers)]
 
     def worker_ctxs(self):
         return [(st, types.SimpleNamespace(ctx=c)) for st, c in zip(self.streams, self.ctxs)]
@@ -408,6 +425,7 @@ class Workload:
             self.alg_bytes_step = 0
             self.desc = {"k": k, "circuit": self.runner.circuit_desc, "proof_bytes": None,
                          "driver": "native (bzh_synthesize_* + %s)" % ("bzh_prove_batch" if ProofRunner.EXPLICIT_RNG else "bzh_prove_batch_seeded"),
+                         "quotient_evaluator": "compiled from the key's program at setup (hipcc, bzh_pk_set_quotient_module)" if self.runner.quotient_codegen else "interpreted (k_expr_vm2)",
                          "randomness": ("every draw generated on the host and passed in (%d bytes per proof)" % self.runner.rng_bytes) if ProofRunner.EXPLICIT_RNG
                          else "a fresh 32-byte seed per proof, expanded on the device (ChaCha20) -- the reference draws OsRng inside create_proof"}
             self.result = torch.zeros((1, 12), dtype=torch.int64, device=device)
@@ -598,6 +616,7 @@ def main():
     args = parse()
     torch.set_num_threads(2)   # torch is plumbing here (device tensors, streams, the final gather): no CPU op pools per rank
     ProofRunner.EXPLICIT_RNG = args.explicit_rng
+    ProofRunner.QUOTIENT_CODEGEN = not args.no_quotient_codegen
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -689,6 +708,8 @@ def main():
         nt = timings["ntt"]
         qt = timings.get("quotient", {"ms": 0.0, "launches": 0, "algorithmic_bytes": 0.0})
         peaks = ubench_peaks()
+        # the quotient kernel's name in the profiles: the interpreter, or the key's program as compiled code
+        qname = "jit_quotient" if getattr(getattr(wl, "runner", None), "quotient_codegen", False) else "k_expr_vm2"
         if args.workload == "ntt22":
             dom_ms = nt["ms"] / max(nt["launches"], 1) * (nt["launches"] / max(args.steps, 1))  # all passes of one NTT
             alg = wl.alg_bytes_step
@@ -697,7 +718,7 @@ def main():
             # the gate evaluation over the extended coset is the largest kernel class of this run
             dom_ms = qt["ms"] / max(qt["launches"], 1)
             alg = qt["algorithmic_bytes"] / max(qt["launches"], 1)
-            dom_name = "k_expr_vm2 (quotient gate evaluation, one launch per batch)"
+            dom_name = "%s (quotient gate evaluation, one launch per batch)" % qname
             wl.alg_bytes_step = (acc["algorithmic_bytes"] + nt["algorithmic_bytes"] + qt["algorithmic_bytes"]) / max(args.steps, 1)
         elif is_full or is_verify or is_mixed:
             # MSM launches of a proof differ in size (28 column commits batched by phase, then the IPA rounds): average the
@@ -714,7 +735,7 @@ def main():
         # HBM-side traffic of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
         # separate runs of this same command), if one exists for this workload and kernel
         traffic, traffic_src = None, None
-        want_kernel = "k_expr_vm2" if dom_name.startswith("k_expr_vm2") else "k_msm_accumulate"
+        want_kernel = qname if dom_name.startswith(qname) else "k_msm_accumulate"
         for tag in ("r02", "r01_h", "r01_e"):
             tj = os.path.join(ROOT, "profiles", "%s_%s_pmc_traffic.json" % (tag, args.workload))
             if traffic is not None or not os.path.exists(tj) or args.workload == "ntt22":
@@ -725,7 +746,7 @@ def main():
                     if want_kernel in e["kernel"]:
                         # coalesced 16-B-per-lane streams (the evaluator's column reads): FETCH_SIZE doubled as the guide prescribes;
                         # the accumulate kernel's 64-B table gathers: raw count (calibration note in the round-1 traffic file)
-                        rd = e["read_bytes"] if want_kernel == "k_expr_vm2" else e["read_bytes_raw"]
+                        rd = e["read_bytes"] if want_kernel == qname else e["read_bytes_raw"]
                         tot += (rd + e["write_bytes"]) * e.get("launches", 1)   # the file holds one entry per grid size:
                         launches += e.get("launches", 1)                       # mean over the launches, like `achieved`
                 if launches:
@@ -779,7 +800,7 @@ def main():
                 "k_msm_accumulate": {"avg_launch_ms": acc["ms"] / max(acc["launches"], 1),
                                      "achieved_GBps": acc["algorithmic_bytes"] / max(acc["ms"], 1e-9) / 1e6,
                                      "frac": acc["algorithmic_bytes"] / max(acc["ms"], 1e-9) / 1e6 / HBM_PEAK_GBS},
-                "k_expr_vm2": {"avg_launch_ms": qt["ms"] / max(qt["launches"], 1),
+                qname: {"avg_launch_ms": qt["ms"] / max(qt["launches"], 1),
                                "achieved_GBps": qt["algorithmic_bytes"] / max(qt["ms"], 1e-9) / 1e6,
                                "frac": qt["algorithmic_bytes"] / max(qt["ms"], 1e-9) / 1e6 / HBM_PEAK_GBS} if qt["ms"] else None,
                 "k_ntt_pass": {"achieved_GBps": nt["algorithmic_bytes"] / max(nt["ms"], 1e-9) / 1e6,
@@ -798,7 +819,7 @@ def main():
                     st = wl.runner.pks[0].quotient_stats()
                     rows = (1 << (wl.k + 3)) * wl.runner.batch * 2
                     rate = st["multiplications_per_row"] * rows / (s_q["ms"] * 1e-3) / 1e9
-                    one["k_expr_vm2"] = {"avg_launch_ms": s_q["ms"] / max(s_q["launches"], 1),
+                    one[qname] = {"avg_launch_ms": s_q["ms"] / max(s_q["launches"], 1),
                                          "achieved_GBps": s_q["algorithmic_bytes"] / s_q["ms"] / 1e6,
                                          "frac": s_q["algorithmic_bytes"] / s_q["ms"] / 1e6 / HBM_PEAK_GBS,
                                          "G_field_multiplications_per_s": rate, "frac_of_fe_mul_peak": rate / peaks["fe_mul"] if peaks["fe_mul"] else None}

@@ -288,6 +288,14 @@ int bzh_pk_set_lagrange(bzh_pk* pk, const bzh_bases* g_lagrange);
 /* the quotient's evaluator program (compiled at the key's first proof; zeros before): instructions, field multiplications per
  * extended-domain row, LDS slots, proof-independent subexpressions hoisted into key-owned coset columns */
 int bzh_pk_quotient_stats(bzh_pk* pk, uint32_t* ops, uint32_t* multiplications, uint32_t* lds_slots, uint32_t* hoisted_columns);
+/* The quotient evaluator as compiled code.  bzh_pk_quotient_source returns the key's evaluator program (available after the
+ * key's first proof, BZH_E_RANGE before) as straight-line HIP source: *len = its length, copied NUL-terminated into buf (cap
+ * bytes) when buf != NULL.  Compile it for gfx950 against csrc/field.cuh (`hipcc -O3 -std=c++17 --offload-arch=gfx950 --genco
+ * -I <csrc>`, ~5 s; or hiprtc) and hand the code object to bzh_pk_set_quotient_module: the quotient pass of every later proof
+ * launches it instead of the interpreter (BoardCircuit, 16 x 2^17 rows: 9.0 ms against 12.5 ms; same proof bytes).  A module
+ * generated from another program is refused (BZH_E_ARG: it carries the program's hash); NULL / 0 returns to the interpreter. */
+int bzh_pk_quotient_source(bzh_pk* pk, char* buf, size_t cap, size_t* len);
+int bzh_pk_set_quotient_module(bzh_ctx* ctx, bzh_pk* pk, const void* code_object, size_t len);
 int bzh_pk_info(const bzh_pk* pk, size_t* rng_bytes_per_proof, size_t* max_proof_bytes, uint32_t* num_advice, uint32_t* n_rows,
                 uint32_t* usable_rows);
 /* bzh_verify_batch  plonk::verify_proof (SingleVerifier; benches/board.rs:80-86) for `batch` proofs of the key's circuit:

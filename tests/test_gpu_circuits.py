@@ -171,6 +171,50 @@ def test_seeded_randomness_gives_the_proofs_of_the_expanded_streams(gpu_ctx, sho
     assert pkb.prove_batch(advb, instb, None, seeds=[sd]) == pkb.prove_batch(advb, instb, [N.rng_expand(sd, 0, pkb.rng_bytes // 64)])
 
 
+def test_compiled_quotient_module_gives_the_same_proofs(gpu_ctx, shot_setup, board_setup):
+    """bzh_pk_quotient_source -> hipcc -> bzh_pk_set_quotient_module: the key's evaluator program as straight-line code
+    produces the proofs of the interpreter, bit for bit; a module generated from another circuit's program is refused;
+    NULL returns to the interpreter."""
+    import shutil
+    import bzh2
+    from bzh2 import circuits as Cm, native as N
+    if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc on this box")
+    rng = random.Random(15)
+    lay, blob, pk, _ = shot_setup
+    circuits = _shot_circuits(Cm, rng, 3)
+    adv, insts = lay.synthesize(circuits)
+    seeds = [bytes(rng.getrandbits(8) for _ in range(32)) for _ in circuits]
+    want = pk.prove_batch(adv, insts, None, seeds=seeds)                  # interpreter (and makes the program exist)
+    src = pk.quotient_source()
+    assert "jit_quotient" in src and "jit_program_hash" in src
+    shot_code = N.compile_quotient_source(src)
+    assert shot_code is not None
+    pk.set_quotient_module(shot_code)
+    try:
+        assert pk.prove_batch(adv, insts, None, seeds=seeds) == want
+        # BoardCircuit: its own module works, the Shot module is refused
+        layb, _, pkb, _ = board_setup
+        deck, _ = _random_deck(rng)
+        ships, state = Cm.board_witness(deck, None)
+        cb = [Cm.BoardCircuit(ships, state, rng.randrange(FQ))]
+        advb, instb = layb.synthesize(cb)
+        sd = [bytes(rng.getrandbits(8) for _ in range(32))]
+        wantb = pkb.prove_batch(advb, instb, None, seeds=sd)
+        with pytest.raises(bzh2.BzhError) as e:
+            pkb.set_quotient_module(shot_code)
+        assert e.value.status == bzh2.E_ARG
+        assert pkb.compile_quotient()
+        try:
+            assert pkb.prove_batch(advb, instb, None, seeds=sd) == wantb
+        finally:
+            pkb.set_quotient_module(None)
+        assert pkb.prove_batch(advb, instb, None, seeds=sd) == wantb
+    finally:
+        pk.set_quotient_module(None)
+    assert pk.prove_batch(adv, insts, None, seeds=seeds) == want
+
+
 def test_shot_unsatisfied_witnesses_are_refused_or_rejected(gpu_ctx, shot_setup):
     """A wrong hit assertion, a non-boolean hit, two shots, no shot (src/circuits/shot.rs:261-640): bzh_prove_batch
     returns BZH_E_RANGE, or the proof is rejected by bzh_verify_batch."""
