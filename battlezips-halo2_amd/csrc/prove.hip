@@ -403,6 +403,8 @@ static std::string program2_source(const Program2& pg, int field) {
     add("typedef %s P;\n", field == BZH_FIELD_FQ ? "FqParams" : "FpParams");
     add("extern \"C\" __device__ __attribute__((used)) unsigned long long jit_program_hash = 0x%llxull;\n",
         (unsigned long long)program2_hash(pg, field));
+    // measured alternatives, all slower: the multiplication inlined (492 vs 514 proofs/s), barriers after multiplications only
+    // (498), 0 / 4 / 6 shared-subexpression slots instead of 2 (478 / 503 / 505)
     src += "__device__ __noinline__ Fe<P> mulx(const Fe<P> a, const Fe<P> b) { return fe_mul(a, b); }\n";
     src += "extern \"C\" __global__ void __launch_bounds__(128) jit_quotient(const uint32_t* const* __restrict__ cols, "
            "const size_t* __restrict__ strides, const uint32_t* __restrict__ consts, size_t const_stride, size_t size, "
