@@ -54,10 +54,16 @@ def compile_quotient_source(src: str, cache_dir: str | None = None) -> bytes | N
     import shutil
     import subprocess
     import tempfile
-    key = hashlib.sha256(src.encode()).hexdigest()[:24]
+    pkg = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256(src.encode())
+    for hdr in ("field.cuh", "field_mul_fips.inc"):   # the code object also depends on the arithmetic it is compiled against
+        try:
+            h.update(open(os.path.join(pkg, "csrc", hdr), "rb").read())
+        except OSError:
+            return None
+    key = h.hexdigest()[:24]
     if key in _QUOTIENT_CODE:
         return _QUOTIENT_CODE[key]
-    pkg = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cache_dir = cache_dir or os.environ.get("BZH_CACHE_DIR") or os.path.join(os.path.dirname(pkg), ".bzh2_cache")
     path = os.path.join(cache_dir, "quotient_%s_gfx950.hsaco" % key)
     if os.path.exists(path):
