@@ -47,7 +47,7 @@ def rng_expand(seed: bytes, first_draw: int, draws: int) -> bytes:
 _QUOTIENT_CODE = {}   # source hash -> code object (several keys of one circuit in a process share one compilation)
 
 
-def compile_quotient_source(src: str, cache_dir: str | None = None) -> bytes | None:
+def compile_quotient_source(src: str, cache_dir: str | None = None, use_cache: bool = True) -> bytes | None:
     """hipcc --genco of a bzh_pk_quotient_source text against csrc/field.cuh; the code object, or None."""
     import hashlib
     import os
@@ -62,11 +62,11 @@ def compile_quotient_source(src: str, cache_dir: str | None = None) -> bytes | N
         except OSError:
             return None
     key = h.hexdigest()[:24]
-    if key in _QUOTIENT_CODE:
+    if use_cache and key in _QUOTIENT_CODE:
         return _QUOTIENT_CODE[key]
     cache_dir = cache_dir or os.environ.get("BZH_CACHE_DIR") or os.path.join(os.path.dirname(pkg), ".bzh2_cache")
     path = os.path.join(cache_dir, "quotient_%s_gfx950.hsaco" % key)
-    if os.path.exists(path):
+    if use_cache and os.path.exists(path):
         _QUOTIENT_CODE[key] = open(path, "rb").read()
         return _QUOTIENT_CODE[key]
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
@@ -151,11 +151,17 @@ class NativeProvingKey:
     def compile_quotient(self, cache_dir: str | None = None) -> bool:
         """Compile quotient_source() with hipcc (a child process; ~5 s, cached on disk by the hash of the source) and install
         it.  False (the interpreter stays) when there is no hipcc or the compilation fails."""
-        code = compile_quotient_source(self.quotient_source(), cache_dir)
-        if code is None:
-            return False
-        self.set_quotient_module(code)
-        return True
+        src = self.quotient_source()
+        for attempt in (0, 1):
+            code = compile_quotient_source(src, cache_dir, use_cache=attempt == 0)
+            if code is None:
+                return False
+            try:
+                self.set_quotient_module(code)
+                return True
+            except BzhError:
+                continue   # a stale or damaged cached code object: compile afresh once
+        return False
 
     def set_lagrange(self, bases_lagrange):
         """Params::commit_lagrange for the columns upstream commits in the Lagrange basis (None: back to coefficients)."""
