@@ -330,11 +330,17 @@ __global__ void __launch_bounds__(T) k_msm_accumulate(const uint32_t* __restrict
         }
         uint32_t m = lo, bbeg = cnt[m - 1], bend = cnt[m];
         // software pipeline: the gather of item j+1 is in flight while item j is added
+        // row / column of the chunk's first item, once per thread: an item is then at most chunk / row_len rows further on, found
+        // by subtraction instead of a 64-bit division per item
+        const size_t row0 = remap ? c0 / row_len : 0, col0 = remap ? c0 - row0 * row_len : 0;
         auto point_index = [&](uint32_t e) -> size_t {
             size_t pidx = (size_t)(e & 0x7fffu);
             if (remap) {
-                const size_t g = c0 + pidx, row = g / row_len;
-                size_t col = g - row * row_len;
+                size_t row = row0, col = col0 + pidx;
+                while (col >= row_len) {
+                    col -= row_len;
+                    row++;
+                }
                 if (dup_from && col >= dup_from) col -= 2;  // the last two table columns appear twice (paired vectors)
                 pidx = row * row_stride + col - c0;
             }
