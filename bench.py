@@ -845,6 +845,11 @@ def main():
             line["config"]["proofs_in_flight_per_gpu"] = args.concurrency * getattr(wl, "batch", args.batch)
             line["config"]["concurrent_batches"] = args.concurrency
             line["config"]["batch"] = getattr(wl, "batch", args.batch)
+            try:
+                free_b, total_b = torch.cuda.mem_get_info(device)
+                line["config"]["hbm_in_use_GB"] = round((total_b - free_b) / 1e9, 1)   # this rank's GPU, every tenant of it
+            except Exception:
+                pass
             line["config"]["srs_window_bits"] = wl.window_bits or "planner"
             line["config"]["distinct_proofs_in_last_batch"] = len(set(wl.runner.last_batch[0]))
         if world == 1 and not args.no_cpu_baseline:
