@@ -38,6 +38,51 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "battlezips-halo2_amd"))
 
+
+def launch_ranks():
+    """`bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment (i.e. not under torchrun): start the N rank
+    processes here -- one per GPU, rank r on device r, RCCL rendezvous on 127.0.0.1 -- BEFORE this process imports torch,
+    loads libbzh2.so or touches the GPU in any way (children are fresh interpreters, not forks or execs of a process that
+    has initialised HIP), wait for them and exit with their status.  Rank 0 prints the one JSON line."""
+    ap = argparse.ArgumentParser(add_help=False)
+    ap.add_argument("--gpus", type=int, default=1)
+    known, _ = ap.parse_known_args()
+    if "WORLD_SIZE" in os.environ:
+        if int(os.environ["WORLD_SIZE"]) != known.gpus:
+            raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%s: launch one rank per GPU (python -m torch.distributed.run "
+                             "--nproc-per-node N bench.py --gpus N ..., or plain `python bench.py --gpus N`)" % (known.gpus, os.environ["WORLD_SIZE"]))
+        return
+    if known.gpus <= 1:
+        return
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(known.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(known.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    pending = list(procs)
+    while pending:
+        for pr in list(pending):
+            code = pr.poll()
+            if code is None:
+                continue
+            pending.remove(pr)
+            if code != 0 and rc == 0:
+                rc = code
+                for other in pending:       # a failed rank leaves the others waiting in a collective: stop exactly those children
+                    other.terminate()
+        time.sleep(0.05)
+    sys.exit(rc)
+
+
+if __name__ == "__main__":
+    launch_ranks()
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
@@ -116,6 +161,12 @@ def parse():
     ap.add_argument("--explicit-rng", action="store_true",
                     help="proof_k* workloads: generate every proof's random stream on the host (numpy) and pass it to bzh_prove_batch "
                          "instead of a 32-byte seed per proof expanded on the device (bzh_prove_batch_seeded)")
+    ap.add_argument("--curve", default="vesta", choices=["vesta", "pallas", "bn254"],
+                    help="msm24 / msm20 / ntt22 (BASELINE configs[4]): the curve of the MSM, the NTT runs over its scalar field "
+                         "(vesta: Fp, the reference's commitment curve; pallas: Fq; bn254: G1 / Fr -- no reference, SURVEY F3)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU work: every rank joins the process group, gathers one fixed-stride record per rank and rank 0 prints "
+                         "the line -- checks the --gpus launcher and the rendezvous on a CPU-only machine (tests/test_bench_launcher_cpu.py)")
     ap.add_argument("--concurrency", type=int, default=4,
                     help="proof_k* workloads: independent proofs in flight per GPU (host threads, one ctx + stream each)")
     return ap.parse_args()
@@ -305,12 +356,17 @@ class Workload:
     """Device-resident inputs + the list of library calls that make one step."""
 
     def __init__(self, name, ctx, device, seed, precompute=True, concurrency=1, batch=1, window_bits=0, circuit="auto", rank=0, world=1,
-                 mix_divisor=1, dist=None):
+                 mix_divisor=1, dist=None, curve="vesta"):
         self.name, self.ctx = name, ctx
         gen = torch.Generator(device=device)
         gen.manual_seed(seed)
         self.calls = []
-        self.curve, self.field = bzh2.CURVE_VESTA, bzh2.FIELD_FP
+        self.curve = {"vesta": bzh2.CURVE_VESTA, "pallas": bzh2.CURVE_PALLAS, "bn254": bzh2.CURVE_BN254}[curve]
+        self.field = bzh2.CURVE_SCALAR_FIELD[self.curve]
+        self.curve_desc = {"vesta": "vesta / Fp (IPA over Pasta, the reference's locked build)", "pallas": "pallas / Fq",
+                           "bn254": "bn254 G1 / Fr (no reference: SURVEY F3)"}[curve]
+        if curve != "vesta" and name not in ("msm24", "msm20", "ntt22"):
+            raise SystemExit("--curve applies to the config-5 microbenches (msm24 / msm20 / ntt22); the circuits are Vesta / Fp")
         self.alg_bytes_msm_launch = 0
         self.units_per_step = 1
         self.desc = {}
@@ -453,7 +509,8 @@ class Workload:
                 self.calls.append(("all_gather 96-B partials + local adds", combine))
             self.alg_bytes_msm_launch = nl * 96
             self.alg_bytes_step = n * 96
-            self.desc = {"msm": "1x2^%d vesta%s" % (k, (", points split over %d ranks (%d each)" % (world, nl)) if world > 1 else "")}
+            self.desc = {"msm": "1x2^%d %s%s" % (k, curve, (", points split over %d ranks (%d each)" % (world, nl)) if world > 1 else ""),
+                         "stages": "one 2^%d-point multi-scalar multiplication (digits, bucket accumulation, reduction, final sum)" % k}
             self.result = self.msm_out
         elif name == "ntt22":
             k = 22
@@ -462,7 +519,8 @@ class Workload:
             self.w = bzh2.field_omega(self.field, k, bzh2.FORM_MONTGOMERY)
             self.calls = [("ntt", lambda: ctx.ntt_device(self.field, self.data.data_ptr(), k, 1, self.w, None, False))]
             self.alg_bytes_step = 64 << k
-            self.desc = {"ntt": "1x NTT 2^22 (Fp)"}
+            self.desc = {"ntt": "1x NTT 2^22 over the scalar field of %s" % curve,
+                         "stages": "one forward radix-2 NTT of 2^22 elements, in place (all passes)"}
             self.result = self.data[:, :4].contiguous().view(1, 16)[:, :12].contiguous()
         else:
             raise ValueError(name)
@@ -612,6 +670,25 @@ def ubench_peaks():
     return best
 
 
+def dry_run(args, rank, world):
+    """--dry-run: the launcher / rendezvous / record-gather path without a GPU (gloo)."""
+    import torch.distributed as dist
+    from bzh2.shard import gather_records
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    rec = torch.full((1, 8), rank, dtype=torch.uint8)
+    t0 = time.perf_counter()
+    got = gather_records(rec, [1] * world, dist) if world > 1 else rec
+    elapsed = time.perf_counter() - t0
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (no GPU work)", "value": 0.0, "unit": "proofs/s", "n_gpus": world, "steps": 0, "warmup": 0,
+                          "ms_per_step": elapsed * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none",
+                          "data": "none", "config": {"workload": "dry_run", "ranks_gathered": sorted(int(v) for v in got[:, 0])}}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     torch.set_num_threads(2)   # torch is plumbing here (device tensors, streams, the final gather): no CPU op pools per rank
@@ -620,8 +697,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.dry_run:
+        return dry_run(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if args.dist_backend == "nccl" and local_rank >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d has no GPU (%d visible); one rank per GPU" % (local_rank, torch.cuda.device_count()))
     if args.dist_backend == "gloo":
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
@@ -639,7 +720,8 @@ def main():
     stream = torch.cuda.current_stream(device)
     ctx = bzh2.Context(local_rank, stream=stream.cuda_stream)
     wl = Workload(args.workload, ctx, device, seed=1234 + rank, precompute=not args.no_precompute, concurrency=args.concurrency, batch=args.batch,
-                  window_bits=args.window_bits, circuit=args.circuit, rank=rank, world=world, mix_divisor=args.mix_divisor, dist=dist)
+                  window_bits=args.window_bits, circuit=args.circuit, rank=rank, world=world, mix_divisor=args.mix_divisor, dist=dist,
+                  curve=args.curve)
 
     def barrier():
         torch.cuda.synchronize(device)
@@ -765,7 +847,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if getattr(wl, "fixed_total", False) else "weak", "vs_baseline": None,
             "dtype": "u32x8 (255-bit modular integer, Montgomery)", "data": "synthetic",
-            "config": dict({"workload": args.workload, "curve": "vesta/Fp (IPA over Pasta, the reference's locked build)",
+            "config": dict({"workload": args.workload, "curve": wl.curve_desc,
                             "stages": "MSM commits + NTT/iNTT/coset-NTT of one proof; NOT included: synthesis, quotient, "
                                       "grand products, multiopen/IPA, transcript",
                             "form": "montgomery", "srs_window_table": not args.no_precompute, "parallelism": "independent proofs per GPU (dp%d)" % world,

@@ -248,7 +248,7 @@ def lagrange_interpolate(points, evals, F):
     return res
 
 
-def _constraint_expressions(keys, col_at, z_at, lk_at, sig_at, l0, l_last, l_blind, x_pow, beta, gamma, theta):
+def _constraint_expressions(keys, col_at, z_at, lk_at, sig_at, l0, l_last, l_blind, x_pow, beta, gamma, theta, skip_gates=False):
     """Every quotient-numerator term in protocol order, generic over 'where' it is evaluated:
     col_at(type, col, rot) column value; sig_at(j) permutation polynomial j; z_at(i, rot_key) permutation
     product i at rot in {0, 1, 'last'};
@@ -256,7 +256,7 @@ def _constraint_expressions(keys, col_at, z_at, lk_at, sig_at, l0, l_last, l_bli
     cs, dom = keys.cs, keys.dom
     p = dom.F.p
     out = []
-    for g in cs.gates:
+    for g in ([] if skip_gates else cs.gates):       # skip_gates: the caller has folded the gate terms itself (oracle/accel.py)
         out.append(expr_eval(g, col_at, p))
     nsets = (len(cs.perm_columns) + cs.chunk_len - 1) // cs.chunk_len if cs.perm_columns else 0
     active = (1 - (l_last + l_blind)) % p
@@ -293,6 +293,27 @@ def _fold(vals, ch, p):
     for v in vals:
         acc = (acc * ch + v) % p
     return acc
+
+
+def quotient_evals(keys, cosets, perm, lk, beta, gamma, theta, y):
+    """h(X) = (sum of the constraint terms folded by y) / (X^n - 1) at every point of the extended coset.
+    cosets: {'advice'|'fixed'|'instance': [column -> extended evaluations]}; perm / lk: the dicts create_proof builds
+    ('coset' of every permutation product; 'a_coset' / 's_coset' / 'z_coset' of every lookup)."""
+    cs, dom = keys.cs, keys.dom
+    F = dom.F
+    p, n, ext, en = F.p, cs.n, dom.ext, dom.en
+    last_rot = -(cs.blinding_factors + 1)
+    h_eval = []
+    for r in range(en):
+        col_at = lambda t, c, rot: cosets[t][c][(r + rot * ext) % en]
+        z_at = lambda i, key: perm[i]['coset'][(r + {0: 0, 1: ext, 'last': last_rot * ext}[key]) % en]
+        lk_at = lambda i, nm, rot: lk[i][nm + '_coset'][(r + rot * ext) % en]
+        sig_at = lambda j: keys.sigma_cosets[j][r]
+        xr = dom.zeta * pow(dom.eomega, r, p) % p
+        terms = _constraint_expressions(keys, col_at, z_at, lk_at, sig_at, keys.l0[r], keys.l_last[r], keys.l_blind[r], xr, beta, gamma, theta)
+        num = _fold(terms, y, p)
+        h_eval.append(num * F.inv((pow(xr, n, p) - 1) % p) % p)
+    return h_eval
 
 
 def create_proof(keys: Keys, advice, instance, rand_scalars, transcript):
@@ -386,19 +407,8 @@ def create_proof(keys: Keys, advice, instance, rand_scalars, transcript):
     T.write_point(cv, keys.commit(random_poly, random_blind))
     y = T.squeeze_challenge()
     # quotient h(X) on the extended coset
-    ext, en = dom.ext, dom.en
     cosets = {'advice': adv_cosets, 'fixed': keys.fixed_cosets, 'instance': inst_cosets}
-    last_rot = -(bf + 1)
-    h_eval = []
-    for r in range(en):
-        col_at = lambda t, c, rot: cosets[t][c][(r + rot * ext) % en]
-        z_at = lambda i, key: perm[i]['coset'][(r + {0: 0, 1: ext, 'last': last_rot * ext}[key]) % en]
-        lk_at = lambda i, nm, rot: lk[i][nm + '_coset'][(r + rot * ext) % en]
-        sig_at = lambda j: keys.sigma_cosets[j][r]
-        xr = dom.zeta * pow(dom.eomega, r, p) % p
-        terms = _constraint_expressions(keys, col_at, z_at, lk_at, sig_at, keys.l0[r], keys.l_last[r], keys.l_blind[r], xr, beta, gamma, theta)
-        num = _fold(terms, y, p)
-        h_eval.append(num * F.inv((pow(xr, n, p) - 1) % p) % p)
+    h_eval = quotient_evals(keys, cosets, perm, lk, beta, gamma, theta, y)
     h_coeffs = dom.extended_to_coeff(h_eval)
     npieces = cs.degree - 1                                # quotient degree / n
     assert all(c == 0 for c in h_coeffs[npieces * n:]), "quotient has higher degree than expected: constraints not satisfied?"
@@ -408,6 +418,7 @@ def create_proof(keys: Keys, advice, instance, rand_scalars, transcript):
         T.write_point(cv, keys.commit(piece, b))
     x = T.squeeze_challenge()
     xn = pow(x, n, p)
+    last_rot = -(bf + 1)
     # evaluations
     ev = lambda poly, rot: O.eval_polynomial(poly, dom.rotate(x, rot), F)
     for c, r in cs.instance_queries:

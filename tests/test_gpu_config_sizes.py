@@ -1,6 +1,6 @@
 """BASELINE.json configs at their OWN sizes, through the C ABI, against the C oracle (oracle/oracle.c):
-  configs[4]  2^24-point MSM on Vesta (plain bases and fixed-base window table) == best_multiexp restatement
-  configs[4]  2^22 NTT over Fp: forward, ZETA-coset and inverse, the full vector bit for bit
+  configs[4]  2^24-point MSM on Vesta, Pallas and BN254 G1 (plain bases and fixed-base window table) == best_multiexp restatement
+  configs[4]  2^22 NTT over Fp, Fq and BN254 Fr: forward, ZETA-coset and inverse, the full vector bit for bit
 Reference seams: halo2_proofs `best_multiexp` / `best_fft` as reached from create_proof (benches/shot.rs:68,
 benches/board.rs:61-68).  Scalars / elements are uniform below the modulus (tests/randutil.py)."""
 import os
@@ -18,13 +18,16 @@ pytestmark = pytest.mark.gpu
 THREADS = max(1, min(32, os.cpu_count() or 1))
 
 
-def test_msm_2_24_vesta_matches_oracle_plain_and_window_table(gpu_ctx, oracle_c):
+@pytest.mark.parametrize("cid", [0, 1, 2], ids=["vesta", "pallas", "bn254_g1"])
+def test_msm_2_24_matches_oracle_plain_and_window_table(gpu_ctx, oracle_c, cid):
+    """configs[4] names Pallas + BN256; SURVEY section 8d lists Vesta/Fp (the reference's commitment curve), Pallas/Fq and
+    BN254 G1/Fr (no reference, SURVEY F3: checked against the C oracle's own best_multiexp restatement)."""
     import bzh2
-    cid, n = 0, 1 << 24
-    cv = O.VESTA
-    g = cv.random_point(random.Random(2024))
+    n = 1 << 24
+    cv = O.CURVE_BY_ID[cid]
+    g = cv.random_point(random.Random(2024 + cid))
     bases = C.point_walk(cid, C.points_to_array([g])[0], n)         # G_i = [i+1]G, affine, from the C oracle
-    rng = np.random.default_rng(24)
+    rng = np.random.default_rng(24 + cid)
     sc = uniform_below(rng, n, SCALAR_MODULUS[cid])
     sc[7] = 0
     sc[8] = C.int_to_limbs(SCALAR_MODULUS[cid] - 1)
@@ -43,22 +46,23 @@ def test_msm_2_24_vesta_matches_oracle_plain_and_window_table(gpu_ctx, oracle_c)
         hb.free()
 
 
-def test_ntt_2_22_full_vector_matches_oracle(gpu_ctx, oracle_c):
-    F = O.FP
+@pytest.mark.parametrize("fid", [0, 1, 2], ids=["fp", "fq", "bn254_fr"])
+def test_ntt_2_22_full_vector_matches_oracle(gpu_ctx, oracle_c, fid):
+    F = O.FIELD_BY_ID[fid]
     k = 22
     n = 1 << k
-    rng = np.random.default_rng(2222)
-    a = uniform_below(rng, n, FIELD_MODULUS[0])
+    rng = np.random.default_rng(2222 + fid)
+    a = uniform_below(rng, n, FIELD_MODULUS[fid])
     w = F.omega(k)
     zeta = pow(F.g, (F.p - 1) // 3, F.p)
-    fwd = gpu_ctx.ntt(0, a, omega=w)
-    assert (fwd == C.ntt(0, a, w, threads=THREADS)).all()
-    cos = gpu_ctx.ntt(0, a, omega=w, coset_shift=zeta)
-    assert (cos == C.ntt(0, a, w, coset_shift=zeta, threads=THREADS)).all()
-    inv = gpu_ctx.ntt(0, a, omega=w, inverse=True)
-    assert (inv == C.ntt(0, a, w, inverse=True, threads=THREADS)).all()
-    cinv = gpu_ctx.ntt(0, a, omega=w, inverse=True, coset_shift=F.g)
-    assert (cinv == C.ntt(0, a, w, inverse=True, coset_shift=F.g, threads=THREADS)).all()
+    fwd = gpu_ctx.ntt(fid, a, omega=w)
+    assert (fwd == C.ntt(fid, a, w, threads=THREADS)).all()
+    cos = gpu_ctx.ntt(fid, a, omega=w, coset_shift=zeta)
+    assert (cos == C.ntt(fid, a, w, coset_shift=zeta, threads=THREADS)).all()
+    inv = gpu_ctx.ntt(fid, a, omega=w, inverse=True)
+    assert (inv == C.ntt(fid, a, w, inverse=True, threads=THREADS)).all()
+    cinv = gpu_ctx.ntt(fid, a, omega=w, inverse=True, coset_shift=F.g)
+    assert (cinv == C.ntt(fid, a, w, inverse=True, coset_shift=F.g, threads=THREADS)).all()
 
 
 def test_k17_native_proof_passes_the_oracle_verifier(gpu_ctx, oracle_c, monkeypatch):

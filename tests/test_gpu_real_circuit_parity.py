@@ -1,0 +1,111 @@
+"""Byte parity of the reference's REAL circuits at their real sizes with the ORACLE PROVER (not only its verifier):
+ShotCircuit at k = 11 (benches/shot.rs:22,68; src/circuits/shot.rs:880-941), BoardCircuit at k = 12
+(benches/board.rs:22,61-68; src/circuits/board.rs:879-933) and at k = 14 -- the headline bench workload -- run live
+against oracle/halo2_oracle.create_proof (bulk arithmetic through the C oracle, oracle/accel.py, whose equivalence to
+the big-int prover tests/test_oracle_accel_cpu.py shows), and at k = 17 against tests/golden/real_proofs.json (the same
+oracle prover, run ahead of time by tests/golden/make_real_proof_golden.py: ~10 min of CPU).
+
+Every case: the Params::new(k) SRS (bzh_params_create; Lagrange-basis commitments as upstream makes them), witnesses from
+bzh_synthesize_*, one shared randomness stream per proof (bzh_prove_batch's explicit-rng form), and the proof bytes
+compared with BOTH quotient evaluators of the product -- the interpreter (k_expr_vm2) and the compiled per-circuit
+kernel.  This covers Compiler2's hash-consing / y-folding / hoisting / CSE slots on the real 81- and 140-polynomial
+constraint systems against an independent evaluator (orc_gate_eval walks the plain expression trees)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import accel as A
+import halo2_oracle as H
+import pasta as O
+from helpers import real_parity as R
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "real_proofs.json")
+
+
+def _setup(ctx, kind, k):
+    import bzh2
+    from bzh2 import circuits as Cm, native as N, params as Pm
+    lay = Cm.CircuitLayout(Cm.SHOT if kind == "shot" else Cm.BOARD, k)
+    prm = Pm.Params(ctx, k)
+    pk = N.NativeProvingKey(ctx, lay.blob(), bzh2.CURVE_VESTA, params=prm)
+    return lay, prm, pk
+
+
+def _both_evaluators(pk, adv, insts, streams):
+    """the proofs of the interpreter and of the compiled quotient kernel for the same inputs"""
+    pk.set_quotient_module(None)
+    interp = pk.prove_batch(adv, insts, streams)
+    assert pk.compile_quotient(), "no compiled quotient kernel for this circuit"
+    try:
+        compiled = pk.prove_batch(adv, insts, streams)
+    finally:
+        pk.set_quotient_module(None)
+    return interp, compiled
+
+
+@pytest.mark.parametrize("kind,k,count", [("shot", 11, 2), ("board", 12, 2), ("board", 14, 1)])
+def test_real_circuit_proofs_are_the_oracle_provers_bytes(gpu_ctx, oracle_c, kind, k, count):
+    from bzh2 import circuits as Cm
+    lay, prm, pk = _setup(gpu_ctx, kind, k)
+    try:
+        circuits = (R.shot_circuits if kind == "shot" else R.board_circuits)(Cm, 100 * k + 7, count)
+        adv, insts = lay.synthesize(circuits)
+        streams = [R.rng_stream("parity-%s-%d-%d" % (kind, k, b), pk.rng_bytes) for b in range(count)]
+        interp, compiled = _both_evaluators(pk, adv, insts, streams)
+        g_arr, _, w, u, _ = prm.points(want_lagrange=False)
+        with A.accelerated(R.THREADS):
+            keys = R.oracle_keys(lay.blob(), R.points_of(g_arr), w, u)
+            for b in range(count):
+                want = R.oracle_prove(keys, adv[b], insts[b], streams[b])
+                assert interp[b] == want, "interpreter quotient: proof %d differs from the oracle prover's" % b
+                assert compiled[b] == want, "compiled quotient: proof %d differs from the oracle prover's" % b
+            assert H.verify_proof(keys, insts[0], interp[0], O.Blake2bTranscript(O.FP))
+        assert len(set(interp)) == count
+        assert pk.verify_batch(insts, interp) == [True] * count
+    finally:
+        pk.close()
+        prm.close()
+        lay.close()
+
+
+@pytest.mark.parametrize("k,batch", [(14, 6), (17, 2)])
+def test_real_board_circuit_production_at_bench_sizes(gpu_ctx, oracle_c, k, batch):
+    """src/circuits/board.rs:879-933 (`production`: keygen -> create_proof -> verify_proof of the real BoardCircuit) at the
+    metric's larger sizes: a batch of distinct fleets proved with per-proof seeds (the bench's path), every proof accepted by
+    the native verifier, one by the oracle verifier, a tampered copy and a swapped instance rejected by both; at k = 17 the
+    first proof is additionally the golden oracle-prover proof byte for byte."""
+    from bzh2 import circuits as Cm
+    lay, prm, pk = _setup(gpu_ctx, "board", k)
+    try:
+        assert pk.compile_quotient()
+        circuits = R.board_circuits(Cm, 1700 + k, batch)
+        adv, insts = lay.synthesize(circuits)
+        seeds = [R.rng_stream("production-%d-%d" % (k, b), 32) for b in range(batch)]
+        proofs = pk.prove_batch(adv, insts, None, seeds=seeds)
+        assert len(set(proofs)) == batch
+        assert pk.verify_batch(insts, proofs) == [True] * batch
+        bad = proofs[1][:1200] + bytes([proofs[1][1200] ^ 4]) + proofs[1][1201:]
+        assert pk.verify_batch([insts[1], insts[0]], [bad, proofs[1]]) == [False, False]
+        g_arr, _, w, u, _ = prm.points(want_lagrange=False)
+        with A.accelerated(R.THREADS):
+            keys = R.oracle_keys(lay.blob(), R.points_of(g_arr), w, u, verifier_only=True)
+            assert H.verify_proof(keys, insts[1], proofs[1], O.Blake2bTranscript(O.FP))
+            assert not H.verify_proof(keys, insts[1], bad, O.Blake2bTranscript(O.FP))
+            assert not H.verify_proof(keys, insts[0], proofs[1], O.Blake2bTranscript(O.FP))
+        gold = [e for e in json.load(open(GOLDEN)) if e["kind"] == "board" and e["k"] == k]
+        if k == 17:
+            assert gold, "tests/golden/real_proofs.json has no k = 17 entry"
+        for e in gold:
+            assert e["seed"] == 1700 + k
+            stream = R.rng_stream(e["tag"], pk.rng_bytes)
+            interp, compiled = _both_evaluators(pk, adv[:1], insts[:1], [stream])
+            assert interp[0].hex() == e["proof_hex"], "interpreter quotient: differs from the golden oracle-prover proof"
+            assert compiled[0].hex() == e["proof_hex"], "compiled quotient: differs from the golden oracle-prover proof"
+    finally:
+        pk.close()
+        prm.close()
+        lay.close()
