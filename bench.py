@@ -164,6 +164,8 @@ def parse():
     ap.add_argument("--curve", default="vesta", choices=["vesta", "pallas", "bn254"],
                     help="msm24 / msm20 / ntt22 (BASELINE configs[4]): the curve of the MSM, the NTT runs over its scalar field "
                          "(vesta: Fp, the reference's commitment curve; pallas: Fq; bn254: G1 / Fr -- no reference, SURVEY F3)")
+    ap.add_argument("--records-out", default=None,
+                    help="rank 0 writes the gathered proof records of the last step (uint8 array, numpy .npy) here")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU work: every rank joins the process group, gathers one fixed-stride record per rank and rank 0 prints "
                          "the line -- checks the --gpus launcher and the rendezvous on a CPU-only machine (tests/test_bench_launcher_cpu.py)")
@@ -278,6 +280,7 @@ class ProofRunner:
         self.last_insts = [[] for _ in range(workers)]
         self.step_batches = [[] for _ in range(workers)]      # every batch of the current plan (for the record gather)
         self.np_rng = [np.random.default_rng(seed + 1000 + wi) for wi in range(workers)]
+        self.kind_id = 1 if kind == "shot" else 0           # bzh2.wire.KIND_SHOT / KIND_BOARD
         # The quotient evaluator as compiled code (bzh_pk_quotient_source -> hipcc -> bzh_pk_set_quotient_module): the program exists
         # after a key's first proof, so every key proves one witness here (setup, like keygen), then gets the module -- one
         # compilation per circuit and process, cached on disk.
@@ -311,12 +314,15 @@ class ProofRunner:
             blob = self.np_rng[wi].bytes(self.rng_bytes * count)
             rbs = [blob[i * self.rng_bytes:(i + 1) * self.rng_bytes] for i in range(count)]
             proofs = self.pks[wi].prove_batch(None, insts, rbs, device_ptr=self.adv[wi].data_ptr())
-        else:                   # a 32-byte seed per proof, expanded on the device (bzh_prove_batch_seeded) -- create_proof's OsRng
-            blob = self.np_rng[wi].bytes(32 * count)
-            proofs = self.pks[wi].prove_batch(None, insts, None, device_ptr=self.adv[wi].data_ptr(),
-                                              seeds=[blob[32 * i:32 * i + 32] for i in range(count)])
+        else:                   # a 32-byte seed per proof, expanded on the device (bzh_prove_batch_seeded) -- create_proof's OsRng.
+            # BENCHMARK seeds: a function of (run seed, circuit, proof index) so that a sharded run makes the proofs of the unsharded
+            # one (tests/test_gpu_bench_ranks.py); a real caller draws them from the OS (include/bzh2.h)
+            import hashlib
+            seeds = [hashlib.blake2b(b"bzh2-bench-seed %d %s %d" % (self.rng_seed, self.kind.encode(), i), digest_size=32).digest()
+                     for i in range(lo, lo + count)]
+            proofs = self.pks[wi].prove_batch(None, insts, None, device_ptr=self.adv[wi].data_ptr(), seeds=seeds)
         self.last_batch[wi], self.last_insts[wi] = proofs, insts
-        self.step_batches[wi].append(proofs)
+        self.step_batches[wi].append((lo, insts, proofs))
 
     def plan(self, lo, count):
         """jobs (one per worker) that together prove witnesses [lo, lo + count) in slices of `batch`"""
@@ -335,13 +341,16 @@ class ProofRunner:
         return any(self.step_batches)
 
     def proof_records(self):
-        """the last step's proofs of this rank as fixed-stride records {u32 length, bytes}: what the final gather carries"""
-        recs = bytearray()
+        """the last step's proofs of this rank as fixed-stride BattleZipsWASM records (bzh_record_encode: public inputs +
+        proof bytes, tagged with circuit kind and proof index), in index order: what the final gather carries"""
+        from bzh2.wire import BattleZipsRecord
+        items = []
         for batches in self.step_batches:
-            for proofs in batches:
-                for pr in proofs:
-                    recs += len(pr).to_bytes(4, "little") + pr + bytes(self.proof_stride - len(pr))
-        a = np.frombuffer(bytes(recs), dtype=np.uint8).reshape(-1, 4 + self.proof_stride)
+            for lo, insts, proofs in batches:
+                for j, pr in enumerate(proofs):
+                    items.append((lo + j, BattleZipsRecord([int(v) for v in insts[j][0]], pr, self.kind_id, lo + j).to_fixed(self.proof_stride)))
+        items.sort()
+        a = np.frombuffer(b"".join(r for _, r in items), dtype=np.uint8).reshape(len(items), -1)
         return torch.from_numpy(a.copy()).to(self.device)
 
     def verify_last(self):
@@ -409,8 +418,9 @@ class Workload:
             self.k = 14
             nb, ns = max(256 // mix_divisor, 1), max(2560 // mix_divisor, 1)
             mine_b, mine_s = shard_range(nb, rank, world), shard_range(ns, rank, world)
-            self.provers = [ProofRunner("board", 14, ctx, device, seed, batch=max(batch // 2, 1), workers=2, window_bits=window_bits, first_ctx=ctx),
-                            ProofRunner("shot", 11, ctx, device, seed + 7, batch=max(batch // 2, 1) * 8, workers=2, window_bits=window_bits)]
+            fixed_seed = seed - rank           # the fixed batch is the same set of proofs whatever the world size
+            self.provers = [ProofRunner("board", 14, ctx, device, fixed_seed, batch=max(batch // 2, 1), workers=2, window_bits=window_bits, first_ctx=ctx),
+                            ProofRunner("shot", 11, ctx, device, fixed_seed + 7, batch=max(batch // 2, 1) * 8, workers=2, window_bits=window_bits)]
             self.shares = [(mine_b.start, len(mine_b)), (mine_s.start, len(mine_s))]
             self.workers = [w for p in self.provers for w in p.worker_ctxs()]
 
@@ -749,6 +759,14 @@ def main():
             wl.combine(gathered)
     barrier()
     elapsed = time.perf_counter() - t0
+    if rank == 0 and hasattr(wl, "records"):   # untimed: every gathered record decodes (bzh_record_decode: canonical public inputs)
+        from bzh2.wire import BattleZipsRecord
+        recs = (gathered if dist is not None else wl.records()).cpu().numpy()
+        decoded = [BattleZipsRecord.from_fixed(recs[i].tobytes()) for i in range(recs.shape[0])]
+        if getattr(wl, "fixed_total", False) or world == 1:
+            assert len({(r.kind, r.index) for r in decoded}) == len(decoded), "duplicate (kind, index) among the gathered records"
+        if args.records_out:
+            np.save(args.records_out, recs)
     timings = ctx.timings()
     msm_adds = sum(c.msm_additions() for c in all_ctx)     # bucket additions actually made in the timed region (all contexts)
     for c in all_ctx[1:]:  # proofs in flight on their own ctx + stream: sum their kernel classes into the report

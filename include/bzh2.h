@@ -409,6 +409,35 @@ int bzh_affine_compress(int curve, const uint64_t* xy, size_t n, int form, uint8
  * (ROOT_OF_UNITY^(2^(S-log_n))); out: 4 limbs in `form`. */
 int bzh_field_omega(int field, unsigned log_n, int form, uint64_t* out);
 
+/* ---- proof / IO record (host) ---------------------------------------------
+ * The record the reference's wasm frontend hands to JavaScript, src/wasm/circuit_wasm.rs:27-31:
+ *     struct BattleZipsWASM { commitment: Vec<[u8; 32]>, proof: Vec<u8> }
+ * commitment = the public inputs (Board: commit.x, commit.y; Shot: commit.x, commit.y, shot, hit) as
+ * BinaryValue::from_fp(fp).to_repr() (:75-83, :164-167), proof = Blake2bWrite::finalize().  Two forms:
+ *   - the serde JSON text {"commitment":[[32 numbers],...],"proof":[numbers]} (bzh_record_to_json / _from_json), and
+ *   - a fixed-stride binary record: what the multi-GPU gather carries (equal-sized records, one all_gather) and what
+ *     a batch client stores per proof:
+ *         u32 proof_len | u8 n_inputs | u8 kind | u16 0 | u32 index | u32 0 | u8 inputs[4][32] | u8 proof[proof_stride]
+ *     `kind` / `index` are the caller's tags (e.g. 0 = Board, 1 = Shot; position in the batch); they are not part of the
+ *     JSON form.
+ * Reading back (verify_board / verify_shot, :86-116) goes through BinaryValue::from_repr(bin).to_fp(): a public input
+ * that is not a canonical Fp element is refused -- BZH_E_RANGE here, from encode, decode and from_json alike.
+ * Malformed JSON is BZH_E_ARG; a proof longer than the record's stride, more than 4 inputs, or a corrupt header is
+ * BZH_E_RANGE. */
+#define BZH_RECORD_HEADER_BYTES 144
+#define BZH_RECORD_MAX_INPUTS 4
+/* bytes per record for proofs of up to proof_stride bytes (bzh_pk_info's max_proof_bytes) */
+size_t bzh_record_stride(size_t proof_stride);
+/* public_inputs: n_inputs x 4 canonical limbs */
+int bzh_record_encode(const uint64_t* public_inputs, size_t n_inputs, const uint8_t* proof, size_t proof_len, uint32_t kind, uint32_t index,
+                      uint8_t* record, size_t record_stride);
+/* any out pointer may be NULL; *proof points into `record` */
+int bzh_record_decode(const uint8_t* record, size_t record_stride, uint64_t* public_inputs, size_t* n_inputs, const uint8_t** proof,
+                      size_t* proof_len, uint32_t* kind, uint32_t* index);
+/* out == NULL: size query (*len = strlen of the text); otherwise cap must hold *len + 1 */
+int bzh_record_to_json(const uint8_t* record, size_t record_stride, char* out, size_t cap, size_t* len);
+int bzh_record_from_json(const char* text, size_t text_len, uint32_t kind, uint32_t index, uint8_t* record, size_t record_stride);
+
 #ifdef __cplusplus
 }
 #endif

@@ -69,20 +69,45 @@ def test_binary_value_basics():
 
 
 def test_wasm_record_round_trip_and_canonical_check():
-    """src/wasm/circuit_wasm.rs:27-31,75-83: {commitment: Vec<[u8;32]>, proof: Vec<u8>} as serde writes it."""
+    """src/wasm/circuit_wasm.rs:27-31,75-83: {commitment: Vec<[u8;32]>, proof: Vec<u8>} as serde writes it, through the
+    C ABI (bzh_record_*); reading back refuses non-canonical public inputs as BinaryValue::from_repr(..).to_fp() does (:86-116)."""
     import json
-    from bzh2.wire import BattleZipsRecord
+    from bzh2.wire import BattleZipsRecord, KIND_SHOT, record_stride
     from bzh2.game import FP_MODULUS
-    rec = BattleZipsRecord([5, FP_MODULUS - 1], bytes(range(200)))
+    rec = BattleZipsRecord([5, FP_MODULUS - 1, 1 << 53, 1], bytes(range(200)), KIND_SHOT, 77)
     text = rec.to_json()
     d = json.loads(text)
-    assert [len(c) for c in d["commitment"]] == [32, 32] and d["commitment"][0][:2] == [5, 0] and d["proof"][:3] == [0, 1, 2]
-    back = BattleZipsRecord.from_json(text)
-    assert back.commitment == rec.commitment and back.proof == rec.proof
-    d["commitment"][1] = list(FP_MODULUS.to_bytes(32, "little"))            # p itself is not a canonical Fp
+    assert set(d) == {"commitment", "proof"}
+    assert [len(c) for c in d["commitment"]] == [32] * 4 and d["commitment"][0][:2] == [5, 0] and d["proof"] == list(range(200))
+    assert d["commitment"][1] == list((FP_MODULUS - 1).to_bytes(32, "little"))
+    back = BattleZipsRecord.from_json(text, KIND_SHOT, 77)
+    assert back == rec
+    # serde's own spelling with whitespace parses too; fields in either order
+    assert BattleZipsRecord.from_json(json.dumps({"proof": d["proof"], "commitment": d["commitment"]}, indent=1), KIND_SHOT, 77) == rec
+    d2 = json.loads(text)
+    d2["commitment"][1] = list(FP_MODULUS.to_bytes(32, "little"))            # p itself is not a canonical Fp
     with pytest.raises(ValueError):
-        BattleZipsRecord.from_json(json.dumps(d))
+        BattleZipsRecord.from_json(json.dumps(d2))
+    for bad in ('{"commitment":[[1,2,3]],"proof":[]}', '{"commitment":[],"proof":[256]}', '{"commitment":[],"proof":[1.5]}',
+                '{"commitment":[]}', '{"commitment":[],"proof":[],"x":1}', '{"commitment":[],"proof":[1,]}', text + "x", ""):
+        with pytest.raises(ValueError):
+            BattleZipsRecord.from_json(bad)
+    with pytest.raises(ValueError):                                         # five public inputs: no circuit of the reference has them
+        BattleZipsRecord.from_json(json.dumps({"commitment": [[0] * 32] * 5, "proof": []}))
+    assert BattleZipsRecord.from_json('{"commitment":[],"proof":[]}') == BattleZipsRecord([], b"")
+    # fixed-stride form: what the multi-GPU gather carries
     fixed = rec.to_fixed(256)
-    assert len(fixed) == 260 and BattleZipsRecord.proof_from_fixed(fixed) == rec.proof
+    assert len(fixed) == record_stride(256) == 144 + 256
+    assert BattleZipsRecord.from_fixed(fixed) == rec and BattleZipsRecord.proof_from_fixed(fixed) == rec.proof
     with pytest.raises(ValueError):
-        rec.to_fixed(100)
+        rec.to_fixed(100)                                                   # proof longer than the stride
+    with pytest.raises(ValueError):
+        BattleZipsRecord([FP_MODULUS], b"").to_fixed(8)                     # non-canonical input refused on encode
+    corrupt = bytearray(fixed)
+    corrupt[0:4] = (257).to_bytes(4, "little")                              # length beyond the stride
+    with pytest.raises(ValueError):
+        BattleZipsRecord.from_fixed(bytes(corrupt))
+    corrupt = bytearray(fixed)
+    corrupt[16 + 32:16 + 64] = FP_MODULUS.to_bytes(32, "little")            # a gathered record with a non-canonical input
+    with pytest.raises(ValueError):
+        BattleZipsRecord.from_fixed(bytes(corrupt))
