@@ -185,9 +185,11 @@ class NativeProvingKey:
                     inst[b, i, r] = int_to_limbs(int(v) % self.p)
         return inst, rows
 
-    def verify_batch(self, instances, proofs) -> list:
-        """plonk::verify_proof for each (instances[b], proofs[b]); returns a list of bools."""
+    def verify_batch(self, instances, proofs, ctx: Context | None = None) -> list:
+        """plonk::verify_proof for each (instances[b], proofs[b]); returns a list of bools.  ctx: the context (stream) to run on --
+        the key is shared, read-only state; every ctx that uses it gets its own workspace inside the library."""
         L = _bind()
+        ctx = ctx or self.ctx
         B = len(proofs)
         inst, rows = self._instances(instances)
         stride = max(max(len(pr) for pr in proofs), 1)
@@ -196,17 +198,20 @@ class NativeProvingKey:
         for b, pr in enumerate(proofs):
             buf[b, :len(pr)] = np.frombuffer(pr, dtype=np.uint8)
         res = (ctypes.c_int * B)()
-        rc = L.bzh_verify_batch(self.ctx.handle, self.handle, B, _VP(inst.ctypes.data), rows, _VP(buf.ctypes.data), stride, lens,
+        rc = L.bzh_verify_batch(ctx.handle, self.handle, B, _VP(inst.ctypes.data), rows, _VP(buf.ctypes.data), stride, lens,
                                 _VP(self._g0_u_w.ctypes.data), res)
-        self.ctx._check(rc, "bzh_verify_batch")
+        ctx._check(rc, "bzh_verify_batch")
         return [bool(v) for v in res]
 
-    def prove_batch(self, advice, instances, rng_list, device_ptr: int | None = None, seeds=None) -> list:
+    def prove_batch(self, advice, instances, rng_list, device_ptr: int | None = None, seeds=None, ctx: Context | None = None) -> list:
         """advice: (B, num_advice, n, 4) uint64 canonical host array (or, with device_ptr, a device pointer to Montgomery
         limbs of that shape); instances: B lists of instance columns (equal lengths); rng_list: B byte strings of
         rng_bytes each -- or None with seeds = B 32-byte strings: the library expands each into its proof's stream on the
-        device (bzh_prove_batch_seeded; the same proofs as rng_list = [rng_expand(s, 0, rng_bytes // 64) for s in seeds])."""
+        device (bzh_prove_batch_seeded; the same proofs as rng_list = [rng_expand(s, 0, rng_bytes // 64) for s in seeds]).
+        ctx: the context (device stream) to prove on, default the one the key was created through; several host threads may
+        prove on ONE key concurrently, each through its own ctx."""
         L = _bind()
+        ctx = ctx or self.ctx
         seeded = rng_list is None
         if seeded:
             assert seeds is not None and all(len(sd) == 32 for sd in seeds)
@@ -224,10 +229,10 @@ class NativeProvingKey:
             assert a.shape == (B, self.num_advice, self.n, 4), a.shape
             adv_p, form, mem = _VP(a.ctypes.data), FORM_CANONICAL, MEM_HOST
         if seeded:
-            rc = L.bzh_prove_batch_seeded(self.ctx.handle, self.handle, B, adv_p, form, mem, _VP(inst.ctypes.data), rows,
+            rc = L.bzh_prove_batch_seeded(ctx.handle, self.handle, B, adv_p, form, mem, _VP(inst.ctypes.data), rows,
                                           b"".join(rng_list), _VP(proofs.ctypes.data), self.max_proof_bytes, lens)
         else:
-            rc = L.bzh_prove_batch(self.ctx.handle, self.handle, B, adv_p, form, mem, _VP(inst.ctypes.data), rows, b"".join(rng_list), stride,
+            rc = L.bzh_prove_batch(ctx.handle, self.handle, B, adv_p, form, mem, _VP(inst.ctypes.data), rows, b"".join(rng_list), stride,
                                    _VP(proofs.ctypes.data), self.max_proof_bytes, lens)
-        self.ctx._check(rc, "bzh_prove_batch")
+        ctx._check(rc, "bzh_prove_batch")
         return [bytes(proofs[b, :lens[b]]) for b in range(B)]

@@ -853,12 +853,25 @@ struct bzh_pk {
     // multiopen structure: rotation sets and the commitments grouped under each
     std::vector<std::vector<int>> rot_sets;
     std::vector<std::vector<uint64_t>> groups;
-    bzh::Arena arena;
+    // per-call workspaces: one grow-only arena per ctx that has used the key (several worker streams share ONE key)
+    std::map<const bzh_ctx*, std::unique_ptr<bzh::Arena>> arenas;
     size_t rng_bytes = 0;
     // verifying key: commitments to the fixed and permutation polynomials (computed at the first verification)
     bool vk_ready = false;
     std::vector<uint64_t> fixed_commitments, sigma_commitments;  // affine canonical x || y
-    std::mutex mu;  // the arena and the program cache serve one call at a time, whichever ctx it comes through
+    // The key is immutable after bzh_pk_create except for caches filled on first use (programs, hoisted columns, the vk
+    // commitments, G_0/U/W, the quotient module, the arena map): `mu` guards those in short sections.  Calls through different
+    // ctxs run concurrently on one key; a call holds its ctx's mutex throughout (lock order: ctx->mu, then pk->mu).
+    std::mutex mu;
+    bzh::Arena& arena_for(const bzh_ctx* ctx, int dev) {
+        std::lock_guard<std::mutex> lk(mu);
+        auto& a = arenas[ctx];
+        if (!a) {
+            a.reset(new bzh::Arena());
+            a->device = dev;
+        }
+        return *a;
+    }
 };
 
 namespace bzh {
@@ -1335,7 +1348,6 @@ static int pk_create_t(bzh_ctx* ctx, const bzh_bases* srs, const uint8_t* blob, 
         draws += n + 1 + 2 * (size_t)pk.k;
         pk.rng_bytes = draws * 64;
     }
-    pk.arena.device = ctx->device;
     BZH_HIP_TRY(ctx, hipStreamSynchronize(st));
     *out = pkp.release();
     return BZH_OK;
@@ -1364,10 +1376,11 @@ struct Prover {
     uint64_t seed_ctr = 0;
     std::vector<uint64_t> host_ctr;    // draws taken on the host per proof since the last row draw (must stay in lockstep)
     std::vector<std::map<int, Fe<SF>>> env;
+    Arena& arena;   // this ctx's workspace of the (shared) key
 
-    Prover(bzh_ctx* c, bzh_pk& p, size_t batch)
+    Prover(bzh_ctx* c, bzh_pk& p, size_t batch, Arena& ar)
         : ctx(c), pk(p), B(batch), st(c->stream), n(p.n), en(p.en), usable(p.usable), field(p.field), T(batch, nullptr), rng(batch),
-          env(batch) {}
+          env(batch), arena(ar) {}
     ~Prover() {
         for (auto t : T)
             if (t) bzh_transcript_free(t);
@@ -1384,7 +1397,7 @@ struct Prover {
         t_last = now;
     }
 
-    uint32_t* dalloc(size_t elems) { return (uint32_t*)pk.arena.alloc(elems * 32); }
+    uint32_t* dalloc(size_t elems) { return (uint32_t*)arena.alloc(elems * 32); }
     int zero(uint32_t* p, size_t elems) {
         BZH_HIP_TRY(ctx, hipMemsetAsync(p, 0, elems * 32, st));
         return BZH_OK;
@@ -1427,7 +1440,7 @@ struct Prover {
     // the next `count` draws of every proof, reduced on the device into dst (B x count, proof-major)
     int draw_rows(size_t count, uint32_t* dst) {
         if (!count) return BZH_OK;
-        uint32_t* raw = (uint32_t*)pk.arena.alloc(B * count * 64);
+        uint32_t* raw = (uint32_t*)arena.alloc(B * count * 64);
         if (!raw) return BZH_E_OOM;
         if (seeded) {
             PV_TRY(seed_rows(count, raw));
@@ -1519,16 +1532,21 @@ struct Prover {
     // ---- compiled programs -------------------------------------------------------------------------
     template <class Build>
     int run(uint64_t pkey, Build build, const Cols& reg, size_t size, uint32_t* d_out) {
-        auto it = pk.progs.find(pkey);
-        if (it == pk.progs.end()) {
-            EPool ep;
-            const int root = build(ep);
-            Compiler cc(ep);
-            cc.prog.result_slot = cc.emit(root);
-            if (cc.overflow) return BZH_E_RANGE;
-            it = pk.progs.insert({pkey, std::move(cc.prog)}).first;
+        const Program* pgp = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(pk.mu);   // map nodes are stable: the program outlives the lock
+            auto it = pk.progs.find(pkey);
+            if (it == pk.progs.end()) {
+                EPool ep;
+                const int root = build(ep);
+                Compiler cc(ep);
+                cc.prog.result_slot = cc.emit(root);
+                if (cc.overflow) return BZH_E_RANGE;
+                it = pk.progs.insert({pkey, std::move(cc.prog)}).first;
+            }
+            pgp = &it->second;
         }
-        const Program& pg = it->second;
+        const Program& pg = *pgp;
         const size_t nc = pg.consts.size(), ncols = reg.ptr.size();
         bool per_proof = false;
         for (auto& c : pg.consts) per_proof |= c.sym >= 0;
@@ -1545,7 +1563,7 @@ struct Prover {
                     memcpy(&cv[(b * nc + i) * 8], c.val, 32);
                 }
             }
-        char* stage = (char*)pk.arena.alloc(cv.size() * 4 + pg.ops.size() * sizeof(bzh_expr_op) + ncols * 16 + 1024);
+        char* stage = (char*)arena.alloc(cv.size() * 4 + pg.ops.size() * sizeof(bzh_expr_op) + ncols * 16 + 1024);
         if (!stage) return BZH_E_OOM;
         uint32_t* d_consts = (uint32_t*)stage;
         char* d_prog = stage + ((cv.size() * 4 + 255) & ~(size_t)255);
@@ -1566,8 +1584,16 @@ struct Prover {
     template <class BuildTerms>
     int run2(uint64_t pkey, BuildTerms build, const Cols& reg, size_t size, uint32_t* d_out) {
         if (size % 128) return BZH_E_RANGE;   // VM v2 runs whole 128-row workgroups (tiny test domains take the plain fold)
+        const Program2* pgp = nullptr;
+        hipFunction_t q_fn = nullptr;
+        {
+        // first use on this key: compile the program and evaluate the hoisted columns, all under the key's lock (other ctxs
+        // sharing the key wait here once); the hoisted columns are written on THIS ctx's stream, so it is drained before the
+        // lock is released and every other stream may read them
+        std::lock_guard<std::mutex> lk(pk.mu);
         auto it = pk.progs2.find(pkey);
         if (it == pk.progs2.end()) {
+            const bool built_hoist_before = pk.hoist != nullptr;
             EPool ep;
             int tinv = -1;
             const std::vector<int> terms = build(ep, &tinv);
@@ -1619,7 +1645,7 @@ struct Prover {
                             const Program& pg = c1.prog;
                             std::vector<uint32_t> cv(std::max<size_t>(pg.consts.size(), 1) * 8);
                             for (size_t i = 0; i < pg.consts.size(); i++) memcpy(&cv[i * 8], pg.consts[i].val, 32);
-                            char* stage = (char*)pk.arena.alloc(cv.size() * 4 + pg.ops.size() * sizeof(bzh_expr_op) + ncols * 16 + 1024);
+                            char* stage = (char*)arena.alloc(cv.size() * 4 + pg.ops.size() * sizeof(bzh_expr_op) + ncols * 16 + 1024);
                             if (!stage) return BZH_E_OOM;
                             uint32_t* d_consts = (uint32_t*)stage;
                             char* d_prog = stage + ((cv.size() * 4 + 255) & ~(size_t)255);
@@ -1657,9 +1683,13 @@ struct Prover {
                         hist[0][0], hist[0][1], hist[0][2], hist[0][3], hist[1][0], hist[1][1], hist[1][2], hist[1][3], hist[2][0], hist[2][1],
                         hist[2][2], hist[2][3], hist[3][0], hist[3][1], hist[3][2], kinds[BZH_EXPR_COLUMN], kinds[BZH_EXPR_CONST], kinds[BZH_EXPR_LDS]);
             }
+            if (pk.hoist && !built_hoist_before) BZH_HIP_TRY(ctx, hipStreamSynchronize(st));
             it = pk.progs2.insert({pkey, std::move(cc.prog)}).first;
         }
-        const Program2& pg = it->second;
+        pgp = &it->second;
+        q_fn = pk.q_fn;
+        }
+        const Program2& pg = *pgp;
         if (!pg.ok) return BZH_E_RANGE;
         const size_t nc = pg.consts.size(), ncols = reg.ptr.size() + pk.hoist_cols;
         std::vector<const uint32_t*> ptrs(reg.ptr);
@@ -1680,7 +1710,7 @@ struct Prover {
                     memcpy(&cv[(b * nc + i) * 8], c.val, 32);
                 }
             }
-        char* stage = (char*)pk.arena.alloc(cv.size() * 4 + pg.ops.size() * sizeof(ExprOp2) + ncols * 16 + 1024);
+        char* stage = (char*)arena.alloc(cv.size() * 4 + pg.ops.size() * sizeof(ExprOp2) + ncols * 16 + 1024);
         if (!stage) return BZH_E_OOM;
         uint32_t* d_consts = (uint32_t*)stage;
         char* d_prog = stage + ((cv.size() * 4 + 255) & ~(size_t)255);
@@ -1695,7 +1725,7 @@ struct Prover {
             for (size_t i = 0; i < reg.stride.size(); i++) cols_read += reg.stride[i] ? (double)B : 1.0;
             ctx->alg_bytes[BZH_T_QUOTIENT] += (cols_read + (double)B) * (double)size * 32.0;
         }
-        if (pk.q_fn) {   // the same program as compiled code (bzh_pk_set_quotient_module)
+        if (q_fn) {   // the same program as compiled code (bzh_pk_set_quotient_module)
             ScopedTimer t(ctx, BZH_T_QUOTIENT);
             const uint32_t* const* a_cols = (const uint32_t* const*)d_ptrs;
             const size_t* a_strides = (const size_t*)d_strides;
@@ -1703,7 +1733,7 @@ struct Prover {
             size_t a_nc = nc, a_size = size;
             uint32_t* a_out = d_out;
             void* args[] = {&a_cols, &a_strides, &a_consts, &a_nc, &a_size, &a_out};
-            BZH_HIP_TRY(ctx, hipModuleLaunchKernel(pk.q_fn, (unsigned)(size / 128), (unsigned)B, 1, 128, 1, 1, 0, st, args, nullptr));
+            BZH_HIP_TRY(ctx, hipModuleLaunchKernel(q_fn, (unsigned)(size / 128), (unsigned)B, 1, 128, 1, 1, 0, st, args, nullptr));
             return BZH_OK;
         }
         return expr_eval2(ctx, field, d_prog, (int)pg.ops.size(), (const uint32_t* const*)d_ptrs, (const size_t*)d_strides, d_consts, nc, size, B,
@@ -2075,7 +2105,7 @@ int Prover<C>::prove(const uint32_t* d_advice_in, const uint64_t* instances, siz
         PV_TRY(qrc);
     }
     PV_TRY(ntt_run(ctx, field, h, pk.ek, B, pk.eomega, pk.zeta, 1, BZH_FORM_MONTGOMERY));
-    uint32_t* d_flag = (uint32_t*)pk.arena.alloc(256);
+    uint32_t* d_flag = (uint32_t*)arena.alloc(256);
     if (!d_flag) return BZH_E_OOM;
     uint32_t h_flag = 0;
     if ((size_t)npieces * n < en) {
@@ -2142,7 +2172,7 @@ int Prover<C>::prove(const uint32_t* d_advice_in, const uint64_t* instances, siz
             ps[j] = srcs[j].first;
             ss[j] = srcs[j].second;
         }
-        char* stage = (char*)pk.arena.alloc(J * 16 + 512);
+        char* stage = (char*)arena.alloc(J * 16 + 512);
         if (!stage) return BZH_E_OOM;
         char* d_ss = stage + ((J * 8 + 255) & ~(size_t)255);
         PV_TRY(h2d_small(ctx, stage, ps.data(), J * 8));
@@ -2424,7 +2454,7 @@ int Prover<C>::prove(const uint32_t* d_advice_in, const uint64_t* instances, siz
         // common distance between the per-proof streams
         const size_t need = 64 * (n + 1 + 2 * (size_t)pk.k);
         if (seeded) {
-            uint32_t* raw = (uint32_t*)pk.arena.alloc(B * need);
+            uint32_t* raw = (uint32_t*)arena.alloc(B * need);
             if (!raw) return BZH_E_OOM;
             PV_TRY(seed_rows(need / 64, raw));
             PV_TRY(ipa_open(ctx, pk.srs, p_poly, B, p_blinds.data(), x3c.data(), nullptr, need, T.data(), out_v.data(), raw));
@@ -2449,14 +2479,15 @@ int Prover<C>::prove(const uint32_t* d_advice_in, const uint64_t* instances, siz
 template <class C>
 static int prove_batch_t(bzh_ctx* ctx, bzh_pk* pk, size_t batch, const uint32_t* d_advice, const uint64_t* instances, size_t inst_rows,
                          const uint8_t* rng, size_t rng_stride, uint8_t* proofs, size_t proof_stride, size_t* proof_lens) {
-    pk->arena.reset();
-    Prover<C> pv(ctx, *pk, batch);
+    Arena& arena = pk->arena_for(ctx, ctx->device);
+    arena.reset();
+    Prover<C> pv(ctx, *pk, batch, arena);
     if (rng_stride == 0) {  // seeded: rng holds batch x 32 bytes
         pv.seeded = true;
         pv.seed_keys.resize(batch * 8);
         memcpy(pv.seed_keys.data(), rng, batch * 32);
         pv.host_ctr.assign(batch, 0);
-        pv.d_seed_keys = (uint32_t*)pk->arena.alloc(batch * 32);
+        pv.d_seed_keys = (uint32_t*)arena.alloc(batch * 32);
         if (!pv.d_seed_keys) return BZH_E_OOM;
         int rcu = h2d_small(ctx, pv.d_seed_keys, pv.seed_keys.data(), batch * 32);
         if (rcu) return rcu;
@@ -2864,19 +2895,23 @@ template <class C>
 static int verify_batch_t(bzh_ctx* ctx, bzh_pk* pk, size_t batch, const uint64_t* instances, size_t inst_rows, const uint8_t* proofs,
                           size_t proof_stride, const size_t* proof_lens, const uint64_t* g0_u_w, int* results) {
     using SF = typename CurveScalar<C>::SF;
-    pk->arena.reset();
-    Prover<C> pv(ctx, *pk, batch);
+    Arena& arena = pk->arena_for(ctx, ctx->device);
+    arena.reset();
+    Prover<C> pv(ctx, *pk, batch, arena);
     const size_t n = pk->n, B = batch;
     const int ni = pk->ni;
     std::vector<uint64_t> xy;
     std::vector<Fe<SF>> blinds;
-    if (!pk->vk_ready) {  // verifying key: commitments to the fixed and permutation polynomials, blind 1
-        const size_t nf = pk->nf, m = pk->perm_columns.size();
-        blinds.assign(nf, fe_one<SF>());
-        PV_TRY(pv.commit(pk->fixed_polys, n, nf, blinds, pk->fixed_commitments));
-        blinds.assign(m, fe_one<SF>());
-        PV_TRY(pv.commit(pk->sigma_polys, n, m, blinds, pk->sigma_commitments));
-        pk->vk_ready = true;
+    {
+        std::lock_guard<std::mutex> lkv(pk->mu);
+        if (!pk->vk_ready) {  // verifying key: commitments to the fixed and permutation polynomials, blind 1
+            const size_t nf = pk->nf, m = pk->perm_columns.size();
+            blinds.assign(nf, fe_one<SF>());
+            PV_TRY(pv.commit(pk->fixed_polys, n, nf, blinds, pk->fixed_commitments));
+            blinds.assign(m, fe_one<SF>());
+            PV_TRY(pv.commit(pk->sigma_polys, n, m, blinds, pk->sigma_commitments));
+            pk->vk_ready = true;
+        }
     }
     // instance commitments of the whole batch (the verifier recomputes them, as upstream does for IPA)
     std::vector<uint64_t> inst_xy(B * std::max(ni, 1) * 8, 0);
@@ -2957,7 +2992,7 @@ int bzh_pk_free(bzh_ctx* ctx, bzh_pk* pk) {
     if (pk->dev) (void)hipFree(pk->dev);
     if (pk->hoist) (void)hipFree(pk->hoist);
     if (pk->q_module) (void)hipModuleUnload(pk->q_module);
-    pk->arena.release();
+    for (auto& kv : pk->arenas) kv.second->release();
     delete pk;
     return BZH_OK;
 }
@@ -3003,8 +3038,8 @@ int bzh_pk_quotient_source(bzh_pk* pk, char* buf, size_t cap, size_t* len) {
 
 int bzh_pk_set_quotient_module(bzh_ctx* ctx, bzh_pk* pk, const void* code_object, size_t len) {
     if (!ctx || !pk || pk->device != ctx->device) return BZH_E_ARG;
-    std::lock_guard<std::mutex> lkp(pk->mu);
     std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::mutex> lkp(pk->mu);
     BZH_HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (pk->q_module) {
         (void)hipStreamSynchronize(ctx->stream);
@@ -3056,11 +3091,11 @@ int bzh_verify_batch(bzh_ctx* ctx, bzh_pk* pk, size_t batch, const uint64_t* ins
     if (pk->device != ctx->device || (pk->ni && instance_rows && !instances) || instance_rows > pk->usable) return BZH_E_ARG;
     for (size_t b = 0; b < batch; b++)
         if (proof_lens[b] > proof_stride) return BZH_E_ARG;
-    std::lock_guard<std::mutex> lkp(pk->mu);
     std::lock_guard<std::mutex> lk(ctx->mu);
     BZH_HIP_TRY(ctx, hipSetDevice(ctx->device));
     // The commitments of the key and G'_0 are computed against pk->srs: the three points the caller passes must be the
     // same SRS's, or every valid proof would be rejected without an error.  Row 0 of the window table is the raw SRS.
+    std::unique_lock<std::mutex> lkp(pk->mu);
     if (pk->srs_g0_u_w.empty()) {
         uint64_t m[3 * 8];
         const size_t idx[3] = {0, pk->n, pk->n + 1};
@@ -3078,6 +3113,7 @@ int bzh_verify_batch(bzh_ctx* ctx, bzh_pk* pk, size_t batch, const uint64_t* ins
         ctx->last_error = "bzh_verify_batch: g0_u_w are not G_0, U, W of the SRS this key was built on";
         return BZH_E_ARG;
     }
+    lkp.unlock();
     int rc = BZH_E_ARG;
     switch (pk->curve) {
         case BZH_CURVE_VESTA:
@@ -3101,7 +3137,6 @@ static int prove_batch_entry(bzh_ctx* ctx, bzh_pk* pk, size_t batch, const uint6
         instance_rows > pk->usable)
         return BZH_E_ARG;
     if (mem == BZH_MEM_DEVICE && form != BZH_FORM_MONTGOMERY) return BZH_E_ARG;
-    std::lock_guard<std::mutex> lkp(pk->mu);
     std::lock_guard<std::mutex> lk(ctx->mu);
     BZH_HIP_TRY(ctx, hipSetDevice(ctx->device));
     const uint32_t* d_adv = (const uint32_t*)advice;

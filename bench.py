@@ -269,9 +269,11 @@ class ProofRunner:
                 wctx = bzh2.Context(device.index or 0, stream=st.cuda_stream)
             self.streams.append(st)
             self.ctxs.append(wctx)
-            self.pks.append(N.NativeProvingKey(wctx, blob, bzh2.CURVE_VESTA, params=self.params))
-            if os.environ.get("BZH_BENCH_COEFF_COMMITS"):   # experiment: coefficient-basis commitments everywhere
-                self.pks[-1].set_lagrange(None)
+            if wi == 0:   # ONE proving key (fixed / sigma / hoisted columns) shared by every worker stream; workspaces are per ctx
+                self.pk = N.NativeProvingKey(wctx, blob, bzh2.CURVE_VESTA, params=self.params)
+                if os.environ.get("BZH_BENCH_COEFF_COMMITS"):   # experiment: coefficient-basis commitments everywhere
+                    self.pk.set_lagrange(None)
+            self.pks.append(self.pk)
             self.adv.append(torch.zeros((batch, self.layout.num_advice, n, 4), dtype=torch.int64, device=device))
         torch.cuda.synchronize(device)
         self.rng_bytes = self.pks[0].rng_bytes
@@ -286,11 +288,8 @@ class ProofRunner:
         # compilation per circuit and process, cached on disk.
         self.quotient_codegen = False
         if ProofRunner.QUOTIENT_CODEGEN:
-            ok = True
-            for wi in range(workers):
-                self._prove_slice(wi, 0, 1)
-                ok = self.pks[wi].compile_quotient() and ok
-            self.quotient_codegen = ok
+            self._prove_slice(0, 0, 1)
+            self.quotient_codegen = self.pk.compile_quotient()
             self.last_batch = [[] for _ in range(workers)]
             self.last_insts = [[] for _ in range(workers)]
             self.step_batches = [[] for _ in range(workers)]
@@ -313,14 +312,14 @@ class ProofRunner:
         if self.explicit_rng:   # the caller supplies every random byte (2 MB per proof at k = 14): the parity tests' mode
             blob = self.np_rng[wi].bytes(self.rng_bytes * count)
             rbs = [blob[i * self.rng_bytes:(i + 1) * self.rng_bytes] for i in range(count)]
-            proofs = self.pks[wi].prove_batch(None, insts, rbs, device_ptr=self.adv[wi].data_ptr())
+            proofs = self.pk.prove_batch(None, insts, rbs, device_ptr=self.adv[wi].data_ptr(), ctx=self.ctxs[wi])
         else:                   # a 32-byte seed per proof, expanded on the device (bzh_prove_batch_seeded) -- create_proof's OsRng.
             # BENCHMARK seeds: a function of (run seed, circuit, proof index) so that a sharded run makes the proofs of the unsharded
             # one (tests/test_gpu_bench_ranks.py); a real caller draws them from the OS (include/bzh2.h)
             import hashlib
             seeds = [hashlib.blake2b(b"bzh2-bench-seed %d %s %d" % (self.rng_seed, self.kind.encode(), i), digest_size=32).digest()
                      for i in range(lo, lo + count)]
-            proofs = self.pks[wi].prove_batch(None, insts, None, device_ptr=self.adv[wi].data_ptr(), seeds=seeds)
+            proofs = self.pk.prove_batch(None, insts, None, device_ptr=self.adv[wi].data_ptr(), seeds=seeds, ctx=self.ctxs[wi])
         self.last_batch[wi], self.last_insts[wi] = proofs, insts
         self.step_batches[wi].append((lo, insts, proofs))
 
@@ -355,9 +354,9 @@ class ProofRunner:
 
     def verify_last(self):
         ok = True
-        for wi, pk in enumerate(self.pks):
+        for wi in range(len(self.ctxs)):
             if self.last_batch[wi]:
-                ok = ok and all(pk.verify_batch(self.last_insts[wi], self.last_batch[wi]))
+                ok = ok and all(self.pk.verify_batch(self.last_insts[wi], self.last_batch[wi], ctx=self.ctxs[wi]))
         return ok
 
 
