@@ -44,6 +44,8 @@ def rng_expand(seed: bytes, first_draw: int, draws: int) -> bytes:
     return out.tobytes()
 
 
+QUOTIENT_INTERPRETER, QUOTIENT_BUILTIN, QUOTIENT_MODULE = 0, 1, 2
+
 _QUOTIENT_CODE = {}   # source hash -> code object (several keys of one circuit in a process share one compilation)
 
 
@@ -75,8 +77,12 @@ def compile_quotient_source(src: str, cache_dir: str | None = None, use_cache: b
     with tempfile.TemporaryDirectory() as td:
         srcp, outp = os.path.join(td, "quotient.hip"), os.path.join(td, "quotient.hsaco")
         open(srcp, "w").write(src)
+        # hipcc is a driver that execs clang through a shell: it must not inherit a profiler's preload (rocprofv3 sets LD_PRELOAD /
+        # tool-library variables; a preloaded tool initialises the GPU in every child and the exec chain is then refused on this pool)
+        env = {k: v for k, v in os.environ.items()
+               if k not in ("LD_PRELOAD", "HSA_TOOLS_LIB", "ROCP_TOOL_LIBRARIES") and not k.startswith(("ROCPROFILER_", "ROCPROF_", "ROCP_"))}
         r = subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "--genco", "-I", os.path.join(pkg, "csrc"), srcp, "-o", outp],
-                           capture_output=True, text=True)
+                           capture_output=True, text=True, env=env)
         if r.returncode != 0 or not os.path.exists(outp):
             return None
         code = open(outp, "rb").read()
@@ -107,6 +113,9 @@ class NativeProvingKey:
             self.bases: Bases = ctx.upload_bases(curve, tbl).precompute(window_bits)
             self._g0_u_w = np.ascontiguousarray(np.stack([tbl[0], tbl[-2], tbl[-1]]))
         else:
+            import weakref
+            self._params = params                      # keep the borrowed tables alive as long as the key
+            params._borrowers.append(weakref.ref(self))
             self.bases = params.bases
             gp, _, wp, up, _ = params.points(want_lagrange=False)
             self._g0_u_w = np.ascontiguousarray(np.stack([gp[0], np.concatenate([int_to_limbs(up[0]), int_to_limbs(up[1])]),
@@ -133,7 +142,7 @@ class NativeProvingKey:
 
     # ---- the quotient evaluator as compiled code -------------------------------------------------------------
     def quotient_source(self) -> str:
-        """the evaluator program as straight-line HIP source (BzhError E_RANGE before the key's first proof)"""
+        """the evaluator program as straight-line HIP source (BzhError E_RANGE if the circuit does not fit the evaluator)"""
         L = _bind()
         L.bzh_pk_quotient_source.argtypes = [_VP, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
         n = ctypes.c_size_t()
@@ -148,10 +157,33 @@ class NativeProvingKey:
         self.ctx._check(L.bzh_pk_set_quotient_module(self.ctx.handle, self.handle, code_object, len(code_object) if code_object else 0),
                         "bzh_pk_set_quotient_module")
 
+    def quotient_selected(self):
+        """(flavour, builtin_available): which quotient evaluator the key runs -- QUOTIENT_INTERPRETER (k_expr_vm2),
+        QUOTIENT_BUILTIN (kernel generated when libbzh2.so was built: the reference's Shot / Board circuits) or
+        QUOTIENT_MODULE (a code object installed with set_quotient_module)"""
+        L = _bind()
+        L.bzh_pk_quotient_selected.argtypes = [_VP, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+        f, b = ctypes.c_int(), ctypes.c_int()
+        self.ctx._check(L.bzh_pk_quotient_selected(self.handle, ctypes.byref(f), ctypes.byref(b)), "bzh_pk_quotient_selected")
+        return f.value, bool(b.value)
+
+    def quotient_select(self, flavour: int):
+        L = _bind()
+        L.bzh_pk_quotient_select.argtypes = [_VP, ctypes.c_int]
+        self.ctx._check(L.bzh_pk_quotient_select(self.handle, flavour), "bzh_pk_quotient_select")
+
     def compile_quotient(self, cache_dir: str | None = None) -> bool:
-        """Compile quotient_source() with hipcc (a child process; ~5 s, cached on disk by the hash of the source) and install
-        it.  False (the interpreter stays) when there is no hipcc or the compilation fails."""
-        src = self.quotient_source()
+        """Make the key run its quotient program as compiled code.  The reference's circuits have a kernel inside libbzh2.so
+        (generated at build time): selected, nothing to compile.  Any other circuit: quotient_source() through hipcc (a child
+        process; ~5 s, cached on disk by the hash of the source), installed with set_quotient_module.  False (the interpreter
+        stays) when there is neither a builtin kernel nor a working hipcc."""
+        if self.quotient_selected()[1]:
+            self.quotient_select(QUOTIENT_BUILTIN)
+            return True
+        try:
+            src = self.quotient_source()
+        except BzhError:
+            return False          # the circuit does not fit the VM v2 evaluator
         for attempt in (0, 1):
             code = compile_quotient_source(src, cache_dir, use_cache=attempt == 0)
             if code is None:

@@ -68,6 +68,7 @@ class Params:
         L.bzh_params_bases(h, ctypes.byref(g), ctypes.byref(gl))
         self.bases = Bases(ctx, g, CURVE_VESTA, self.n + 2)
         self.bases_lagrange = Bases(ctx, gl, CURVE_VESTA, self.n + 2)
+        self._borrowers = []     # weak references to the proving keys built on these tables (they borrow, include/bzh2.h)
 
     def points(self, want_g: bool = True, want_lagrange: bool = True):
         """host copies: (g, g_lagrange, w, u, from_cache) -- arrays of canonical limbs, w / u as (x, y) ints"""
@@ -80,6 +81,12 @@ class Params:
         return g, gl, (limbs_to_int(w[:4]), limbs_to_int(w[4:])), (limbs_to_int(u[:4]), limbs_to_int(u[4:])), bool(fc.value)
 
     def close(self):
+        """bzh_params_free.  Proving keys borrow the tables: closing the Params under a live key would leave it reading freed
+        window tables, so that ordering is refused."""
         if self.handle is not None:
+            if any(r() is not None and r().handle is not None for r in self._borrowers):
+                raise RuntimeError("Params.close(): a NativeProvingKey built on these Params is still open; close the key first")
             _bind().bzh_params_free(self.ctx.handle, self.handle)
             self.handle = None
+            self.bases.handle = None            # the tables went with the params
+            self.bases_lagrange.handle = None

@@ -40,6 +40,9 @@
 #include "ctx.hpp"
 #include "curve.cuh"
 
+// the table of quotient kernels generated at build time (quotient_builtin.hip); absent (null) in the generator's own link
+extern "C" const bzh_builtin_quotient* bzh_builtin_quotients(size_t* count) __attribute__((weak));
+
 namespace bzh {
 
 namespace {
@@ -391,23 +394,31 @@ static uint64_t program2_hash(const Program2& pg, int field) {
 // operand is loaded one instruction ahead of its use and a scheduling barrier follows every instruction -- without it the
 // compiler hoists all ~750 leaf loads to the top (255 VGPRs and scratch); with it 106 VGPRs, four waves per SIMD.  Measured
 // on the BoardCircuit program (1 361 instructions, 16 x 2^17 rows): 9.0 ms against the interpreter's 12.5 ms, same bits.
-static std::string program2_source(const Program2& pg, int field) {
+// builtin != 0: the flavour linked into libbzh2.so at build time (csrc/gen_quotient.cpp -> quotient_builtin.hip): kernel named
+// after the program hash inside its own namespace, a host launcher, no module-level hash symbol.
+static std::string program2_source(const Program2& pg, int field, bool builtin = false) {
     std::string src;
     char buf[512];
     auto add = [&](const char* fmt, auto... a) {
         snprintf(buf, sizeof(buf), fmt, a...);
         src += buf;
     };
-    add("// generated by libbzh2 (bzh_pk_quotient_source): quotient evaluator, %zu instructions\n", pg.ops.size());
-    src += "#include \"field.cuh\"\nusing namespace bzh;\n";
+    const unsigned long long hash = (unsigned long long)program2_hash(pg, field);
+    char kname[64];
+    if (builtin) snprintf(kname, sizeof(kname), "bzh_quotient_%016llx", hash);
+    else snprintf(kname, sizeof(kname), "jit_quotient");
+    add("// generated by libbzh2 (%s): quotient evaluator, %zu instructions\n", builtin ? "bzh_quotient_source_for_circuit" : "bzh_pk_quotient_source",
+        pg.ops.size());
+    if (builtin) add("namespace bzh_q_%016llx {\n", hash);
+    else src += "#include \"field.cuh\"\n";
+    src += "using namespace bzh;\n";
     add("typedef %s P;\n", field == BZH_FIELD_FQ ? "FqParams" : "FpParams");
-    add("extern \"C\" __device__ __attribute__((used)) unsigned long long jit_program_hash = 0x%llxull;\n",
-        (unsigned long long)program2_hash(pg, field));
+    if (!builtin) add("extern \"C\" __device__ __attribute__((used)) unsigned long long jit_program_hash = 0x%llxull;\n", hash);
     // measured alternatives, all slower: the multiplication inlined (492 vs 514 proofs/s), barriers after multiplications only
     // (498), 0 / 4 / 6 shared-subexpression slots instead of 2 (478 / 503 / 505)
     src += "__device__ __noinline__ Fe<P> mulx(const Fe<P> a, const Fe<P> b) { return fe_mul(a, b); }\n";
-    src += "extern \"C\" __global__ void __launch_bounds__(128) jit_quotient(const uint32_t* const* __restrict__ cols, "
-           "const size_t* __restrict__ strides, const uint32_t* __restrict__ consts, size_t const_stride, size_t size, "
+    add("extern \"C\" __global__ void __launch_bounds__(128) %s(const uint32_t* const* __restrict__ cols, ", kname);
+    src += "const size_t* __restrict__ strides, const uint32_t* __restrict__ consts, size_t const_stride, size_t size, "
            "uint32_t* __restrict__ out) {\n"
            "    const size_t r = blockIdx.x * (size_t)128 + threadIdx.x, v = blockIdx.y;\n"
            "    if (r >= size) return;\n"
@@ -467,6 +478,11 @@ static std::string program2_source(const Program2& pg, int field) {
         src += "    __builtin_amdgcn_sched_barrier(0);\n";
     }
     src += "    fe_store(out + (v * size + r) * 8, r0);\n}\n";
+    if (builtin) {
+        add("static void launch(unsigned gx, unsigned gy, void* st, const uint32_t* const* cols, const size_t* strides, const uint32_t* consts, "
+            "size_t nc, size_t size, uint32_t* out) {\n    hipLaunchKernelGGL(%s, dim3(gx, gy), dim3(128), 0, (hipStream_t)st, cols, strides, consts, nc, size, out);\n}\n", kname);
+        add("}  // namespace bzh_q_%016llx\n", hash);
+    }
     return src;
 }
 
@@ -842,14 +858,24 @@ struct bzh_pk {
     uint32_t *fixed = nullptr, *fixed_polys = nullptr, *fixed_cosets = nullptr, *sigma = nullptr, *ident = nullptr, *sigma_polys = nullptr,
              *sigma_cosets = nullptr, *l0 = nullptr, *l_last = nullptr, *l_blind = nullptr, *x_col = nullptr, *tinv_col = nullptr;
     std::map<uint64_t, bzh::Program> progs;
-    std::map<uint64_t, bzh::Program2> progs2;   // VM v2 programs (the quotient)
-    // the quotient program as a compiled code object (bzh_pk_quotient_source / bzh_pk_set_quotient_module): launched instead of
-    // the interpreter when present
-    hipModule_t q_module = nullptr;
-    hipFunction_t q_fn = nullptr;
-    // proof-independent subexpressions of the quotient (selector products ...) evaluated once on the extended coset
+    // The quotient's VM v2 program: compiled on the host at bzh_pk_create (it depends on the circuit only, not on k or on
+    // any witness); q_ok = false when the circuit does not fit VM v2 (the prover then folds through VM v1).
+    bzh::Program2 qprog;
+    bool q_ok = false;
+    uint64_t q_hash = 0;
+    // proof-independent subexpressions of the quotient (selector products ...): one VM v1 program each, evaluated once on the
+    // extended coset into `hoist` at bzh_pk_create
+    std::vector<bzh::Program> hoist_progs;
     uint32_t* hoist = nullptr;
     size_t hoist_cols = 0;
+    // The same program as compiled code, launched instead of the interpreter:
+    //   q_builtin: a kernel generated at build time and linked into libbzh2.so (the reference's two circuits), found by q_hash;
+    //   q_module / q_fn: a code object the caller compiled from bzh_pk_quotient_source (any other circuit).
+    // q_select: BZH_QUOTIENT_* -- which of the three runs.
+    bzh_quotient_launch_fn q_builtin = nullptr;
+    hipModule_t q_module = nullptr;
+    hipFunction_t q_fn = nullptr;
+    int q_select = BZH_QUOTIENT_INTERPRETER;
     // multiopen structure: rotation sets and the commitments grouped under each
     std::vector<std::vector<int>> rot_sets;
     std::vector<std::vector<uint64_t>> groups;
@@ -1006,20 +1032,243 @@ struct CurveScalar<PallasCurve> {
 // ---------------------------------------------------------------------------
 // keygen
 // ---------------------------------------------------------------------------
+// ---------------------------------------------------------------------------
+// the quotient program of a key (host): column registry, terms in protocol order, compilation, hoisted columns
+// ---------------------------------------------------------------------------
+// per-proof columns of one prove call; all null when only the program is wanted (compile_quotient, materialize_hoist)
+struct QuotientPtrs {
+    const uint32_t* adv = nullptr;    // na columns of en elements per proof
+    const uint32_t* inst = nullptr;   // ni
+    const uint32_t* z = nullptr;      // nsets + nl grand products
+    std::vector<const uint32_t*> lk;  // per lookup: A' | S'
+};
+// The registry fixes the column INDEX every instruction of the compiled program refers to: it must be built by this one
+// function, for the compile and for every launch.  stride = elements between consecutive proofs, 0 = shared (key-owned).
+static void quotient_registry(const bzh_pk& pk, const QuotientPtrs& q, Cols& reg) {
+    const size_t en = pk.en, m = pk.perm_columns.size();
+    const int na = pk.na, nf = pk.nf, ni = pk.ni, nsets = pk.nsets, nl = pk.nl, nz = pk.nsets + pk.nl;
+    auto at = [](const uint32_t* base, size_t elems) -> const uint32_t* { return base ? base + elems * 8 : nullptr; };
+    for (int i = 0; i < na; i++) reg.add(key(K_ADV, i), at(q.adv, (size_t)i * en), (size_t)na * en);
+    for (int i = 0; i < nf; i++) reg.add(key(K_FIX, i), at(pk.fixed_cosets, (size_t)i * en), 0);
+    for (int i = 0; i < ni; i++) reg.add(key(K_INST, i), at(q.inst, (size_t)i * en), (size_t)ni * en);
+    for (size_t j = 0; j < m; j++) reg.add(key(K_SIGMA, j), at(pk.sigma_cosets, j * en), 0);
+    for (int i = 0; i < nsets; i++) reg.add(key(K_PZ, i), at(q.z, (size_t)i * en), (size_t)nz * en);
+    for (int i = 0; i < nl; i++) {
+        const uint32_t* c = (size_t)i < q.lk.size() ? q.lk[i] : nullptr;
+        reg.add(key(K_LA, i), c, 2 * en);
+        reg.add(key(K_LS, i), at(c, en), 2 * en);
+        reg.add(key(K_LZ, i), at(q.z, (size_t)(nsets + i) * en), (size_t)nz * en);
+    }
+    reg.add(key(K_MISC, M_L0), pk.l0, 0);
+    reg.add(key(K_MISC, M_LLAST), pk.l_last, 0);
+    reg.add(key(K_MISC, M_LBLIND), pk.l_blind, 0);
+    reg.add(key(K_MISC, M_X), pk.x_col, 0);
+    reg.add(key(K_MISC, M_TINV), pk.tinv_col, 0);
+}
+
+// every term of the quotient's numerator in protocol order (gates, permutation argument, lookups); *tinv = the 1 / (X^n - 1) column
+template <class SF>
+static std::vector<int> quotient_terms(const bzh_pk& pk, const Cols& reg, EPool& ep, int* tinv) {
+    const int e = (int)pk.ext, nsets = pk.nsets, nl = pk.nl, last_rot = -(pk.bf + 1);
+    const size_t m = pk.perm_columns.size();
+    auto Q = [&](uint64_t kk, int rot = 0) { return ep.query(reg.at(kk), rot); };
+    auto col_q = [&](std::pair<int, int> col) {
+        return Q(key(col.first == CX_ADVICE ? K_ADV : (col.first == CX_FIXED ? K_FIX : K_INST), col.second));
+    };
+    const Fe<SF> onef = fe_one<SF>();
+    auto one = [&] { return ep.cnst(onef); };
+    auto l0 = [&] { return Q(key(K_MISC, M_L0)); };
+    auto l_last = [&] { return Q(key(K_MISC, M_LLAST)); };
+    auto active = [&] { return ep.sub(one(), ep.add(l_last(), Q(key(K_MISC, M_LBLIND)))); };
+    std::vector<int> terms;
+    for (int g : pk.gates) terms.push_back(lower(pk, g, ep, reg, e));
+    if (nsets) {
+        terms.push_back(ep.mul(l0(), ep.sub(one(), Q(key(K_PZ, 0)))));
+        const uint64_t zl = key(K_PZ, nsets - 1);
+        terms.push_back(ep.mul(l_last(), ep.sub(ep.mul(Q(zl), Q(zl)), Q(zl))));
+        for (int i = 1; i < nsets; i++) terms.push_back(ep.mul(l0(), ep.sub(Q(key(K_PZ, i)), Q(key(K_PZ, i - 1), last_rot * e))));
+        for (int i = 0; i < nsets; i++) {
+            const size_t c0 = (size_t)i * pk.chunk_len, c1 = std::min(m, c0 + pk.chunk_len);
+            int left = Q(key(K_PZ, i), e), right = Q(key(K_PZ, i));
+            for (size_t gj = c0; gj < c1; gj++) {
+                left = ep.mul(left, ep.add(ep.add(col_q(pk.perm_columns[gj]), ep.mul(ep.sym(SY_BETA), Q(key(K_SIGMA, gj)))), ep.sym(SY_GAMMA)));
+                const int cur = ep.mul(ep.sym(SY_BD0 + (int)gj), Q(key(K_MISC, M_X)));
+                right = ep.mul(right, ep.add(ep.add(col_q(pk.perm_columns[gj]), cur), ep.sym(SY_GAMMA)));
+            }
+            terms.push_back(ep.mul(active(), ep.sub(left, right)));
+        }
+    }
+    for (int i = 0; i < nl; i++) {
+        auto z0 = [&] { return Q(key(K_LZ, i)); };
+        auto a_p = [&] { return Q(key(K_LA, i)); };
+        auto s_p = [&] { return Q(key(K_LS, i)); };
+        auto comp = [&](const std::vector<int>& es) {
+            std::vector<int> t;
+            for (int x : es) t.push_back(lower(pk, x, ep, reg, e));
+            return ep.horner(t, ep.sym(SY_THETA));
+        };
+        terms.push_back(ep.mul(l0(), ep.sub(one(), z0())));
+        terms.push_back(ep.mul(l_last(), ep.sub(ep.mul(z0(), z0()), z0())));
+        const int lhs = ep.mul(ep.mul(Q(key(K_LZ, i), e), ep.add(a_p(), ep.sym(SY_BETA))), ep.add(s_p(), ep.sym(SY_GAMMA)));
+        const int rhs = ep.mul(ep.mul(z0(), ep.add(comp(pk.lookups[i].first), ep.sym(SY_BETA))),
+                               ep.add(comp(pk.lookups[i].second), ep.sym(SY_GAMMA)));
+        terms.push_back(ep.mul(active(), ep.sub(lhs, rhs)));
+        terms.push_back(ep.mul(l0(), ep.sub(a_p(), s_p())));
+        terms.push_back(ep.mul(ep.mul(active(), ep.sub(a_p(), s_p())), ep.sub(a_p(), Q(key(K_LA, i), -e))));
+    }
+    *tinv = Q(key(K_MISC, M_TINV));
+    return terms;
+}
+
+// Compile the quotient for VM v2 (host only).  Hoisting: maximal subexpressions over proof-independent columns (stride 0:
+// fixed / permutation / Lagrange columns of the key) and literal constants that contain a multiplication -- the
+// compressed-selector products q prod (j - q) of every gate -- get one VM v1 program each (pk.hoist_progs) and are referred
+// to by the main program as extra registry columns; materialize_hoist evaluates them once on the extended coset.
+template <class SF>
+static void compile_quotient(bzh_pk& pk) {
+    pk.q_ok = false;
+    pk.hoist_progs.clear();
+    pk.hoist_cols = 0;
+    if (pk.en % 128) return;   // VM v2 runs whole 128-row workgroups (tiny test domains take the plain fold)
+    Cols reg;
+    quotient_registry(pk, QuotientPtrs{}, reg);
+    EPool ep;
+    int tinv = -1;
+    const std::vector<int> terms = quotient_terms<SF>(pk, reg, ep, &tinv);
+    Compiler2 cc(ep);
+    if (!getenv("BZH_NO_HOIST")) {
+        const size_t nn = ep.n.size();
+        std::vector<char> indep(nn, 0);
+        std::vector<int> muls(nn, 0);
+        for (size_t i = 0; i < nn; i++) {   // children precede parents in the pool
+            const ENode& e = ep.n[i];
+            if (e.tag == EX_CONST) indep[i] = 1;
+            else if (e.tag == EX_SYMBOL) indep[i] = 0;
+            else if (e.tag == EX_QUERY) indep[i] = reg.stride[e.col] == 0;
+            else if (e.tag == EX_NEG) indep[i] = indep[e.a], muls[i] = muls[e.a];
+            else if (e.tag == EX_SCALE) indep[i] = indep[e.a], muls[i] = muls[e.a] + 1;
+            else indep[i] = indep[e.a] && indep[e.b], muls[i] = muls[e.a] + muls[e.b] + (e.tag == EX_MUL);
+        }
+        std::vector<int> picked;
+        std::vector<char> seen(nn, 0);
+        std::vector<int> stack(terms.begin(), terms.end());
+        while (!stack.empty()) {
+            const int i = stack.back();
+            stack.pop_back();
+            if (seen[i]) continue;
+            seen[i] = 1;
+            const ENode& e = ep.n[i];
+            if (e.tag == EX_CONST || e.tag == EX_SYMBOL || e.tag == EX_QUERY) continue;
+            if (indep[i] && muls[i] >= 1) {
+                picked.push_back(i);
+                continue;
+            }
+            if (e.a >= 0) stack.push_back(e.a);
+            if (e.b >= 0) stack.push_back(e.b);
+        }
+        std::sort(picked.begin(), picked.end());
+        if (!picked.empty() && picked.size() <= 512) {
+            const size_t ncols = reg.ptr.size();
+            for (size_t hi = 0; hi < picked.size(); hi++) {
+                Compiler c1(ep);
+                c1.prog.result_slot = c1.emit(picked[hi]);
+                if (c1.overflow) {
+                    pk.hoist_progs.clear();
+                    return;   // does not fit the evaluators' slot file: the prover folds through VM v1
+                }
+                pk.hoist_progs.push_back(std::move(c1.prog));
+                cc.hoisted[picked[hi]] = (int)(ncols + hi);
+            }
+        }
+    }
+    cc.quotient(terms, tinv);
+    cc.prog.nlds = cc.nlds();
+    if (getenv("BZH_PROVE_TRACE")) {
+        size_t muls = 0;
+        for (auto& o : cc.prog.ops) muls += ((o.code >> 4) < 3 && ((o.code >> 2) & 3) == V2_MUL);
+        fprintf(stderr, "[bzh_pk_create] quotient program (VM v2): %zu terms, %zu ops, %zu multiplications, %d LDS slots, %zu constants, %zu hoisted columns%s\n",
+                terms.size(), cc.prog.ops.size(), muls, cc.prog.nlds, cc.prog.consts.size(), pk.hoist_progs.size(), cc.prog.ok ? "" : " -- NOT usable");
+        // instruction mix: form (SS/SL/LL/UN) x operation, and the kinds of the memory operands
+        size_t hist[4][4] = {{0}}, kinds[4] = {0};
+        for (auto& o : cc.prog.ops) {
+            const int form = o.code >> 4, oo = (o.code >> 2) & 3;
+            hist[form & 3][oo]++;
+            if (form == V2_SL || form == V2_LL) kinds[o.b_kind & 3]++;
+            if (form == V2_LL || (form == V2_UN && oo != V2_NEG)) kinds[o.a_kind & 3]++;
+        }
+        fprintf(stderr, "[bzh_pk_create]   mix  SS add/sub/mul/rsub %zu/%zu/%zu/%zu  SL %zu/%zu/%zu/%zu  LL %zu/%zu/%zu/%zu  UN neg/load/store %zu/%zu/%zu ; operands column/const/lds %zu/%zu/%zu\n",
+                hist[0][0], hist[0][1], hist[0][2], hist[0][3], hist[1][0], hist[1][1], hist[1][2], hist[1][3], hist[2][0], hist[2][1],
+                hist[2][2], hist[2][3], hist[3][0], hist[3][1], hist[3][2], kinds[BZH_EXPR_COLUMN], kinds[BZH_EXPR_CONST], kinds[BZH_EXPR_LDS]);
+    }
+    pk.qprog = std::move(cc.prog);
+    pk.q_ok = pk.qprog.ok;
+    pk.q_hash = program2_hash(pk.qprog, pk.field);
+    pk.hoist_cols = pk.hoist_progs.size();
+    if (!pk.q_ok) {
+        pk.hoist_progs.clear();
+        pk.hoist_cols = 0;
+    }
+}
+
+// evaluate the hoisted columns on the extended coset (device; once per key, at bzh_pk_create)
+template <class SF>
+static int materialize_hoist(bzh_ctx* ctx, bzh_pk& pk) {
+    if (!pk.q_ok || pk.hoist_progs.empty()) return BZH_OK;
+    const size_t size = pk.en;
+    Cols reg;
+    quotient_registry(pk, QuotientPtrs{}, reg);   // hoisted programs read key-owned columns only
+    const size_t ncols = reg.ptr.size();
+    BZH_HIP_TRY(ctx, hipMalloc((void**)&pk.hoist, pk.hoist_cols * size * 32));
+    size_t stage_bytes = 0;
+    for (const Program& pg : pk.hoist_progs)
+        stage_bytes = std::max(stage_bytes, std::max<size_t>(pg.consts.size(), 1) * 32 + pg.ops.size() * sizeof(bzh_expr_op) + ncols * 16 + 1024);
+    char* stage_all = nullptr;
+    BZH_HIP_TRY(ctx, hipMalloc((void**)&stage_all, stage_bytes * pk.hoist_progs.size()));
+    int rc = BZH_OK;
+    for (size_t hi = 0; hi < pk.hoist_progs.size() && !rc; hi++) {
+        const Program& pg = pk.hoist_progs[hi];
+        std::vector<uint32_t> cv(std::max<size_t>(pg.consts.size(), 1) * 8);
+        for (size_t i = 0; i < pg.consts.size(); i++) memcpy(&cv[i * 8], pg.consts[i].val, 32);
+        char* stage = stage_all + hi * stage_bytes;
+        uint32_t* d_consts = (uint32_t*)stage;
+        char* d_prog = stage + ((cv.size() * 4 + 255) & ~(size_t)255);
+        char* d_ptrs = d_prog + ((pg.ops.size() * sizeof(bzh_expr_op) + 255) & ~(size_t)255);
+        char* d_strides = d_ptrs + ((ncols * 8 + 255) & ~(size_t)255);
+        if ((rc = h2d_small(ctx, d_consts, cv.data(), cv.size() * 4))) break;
+        if ((rc = h2d_small(ctx, d_prog, pg.ops.data(), pg.ops.size() * sizeof(bzh_expr_op)))) break;
+        if ((rc = h2d_small(ctx, d_ptrs, reg.ptr.data(), ncols * 8))) break;
+        if ((rc = h2d_small(ctx, d_strides, reg.stride.data(), ncols * 8))) break;
+        int nslots = pg.result_slot + 1;
+        for (auto& o : pg.ops) nslots = std::max(nslots, (int)o.dst + 1);
+        rc = expr_eval(ctx, pk.field, d_prog, (int)pg.ops.size(), (const uint32_t* const*)d_ptrs, (const size_t*)d_strides, d_consts, 0, size,
+                       pg.result_slot, 1, nslots, pk.hoist + hi * size * 8);
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(stage_all);
+    return rc;
+}
+
+// what the host half of keygen hands to the device half
+template <class SF>
+struct ParsedKey {
+    std::vector<Fe<SF>> fixed_h;                 // nf x n fixed assignment, Montgomery
+    std::vector<uint32_t> map_c, map_r;          // permutation: (column, row) -> (column, row)
+    Fe<SF> omega, eomega, delta, zeta;
+};
+
+// keygen, host half: parse the circuit blob, derive the constraint-system shape (queries, degree, blinding factors,
+// extended domain), the permutation cycles and the multiopen structure, and compile the quotient program.  No device work:
+// this is also what the build-time kernel generator runs (bzh_quotient_source_for_circuit).
 template <class C>
-static int pk_create_t(bzh_ctx* ctx, const bzh_bases* srs, const uint8_t* blob, size_t len, bzh_pk** out) {
+static int pk_parse_t(const uint8_t* blob, size_t len, bzh_pk& pk, ParsedKey<typename CurveScalar<C>::SF>& po) {
     using SF = typename CurveScalar<C>::SF;
     using FM = FieldMeta<SF>;
-    std::unique_ptr<bzh_pk> pkp(new bzh_pk());
-    bzh_pk& pk = *pkp;
     Reader r{blob, blob + len};
     const uint32_t magic = r.u32();
     if (magic != 0x31435A42u && magic != 0x32435A42u) return BZH_E_ARG;  // "BZC1" / "BZC2"
     const bool explicit_queries = magic == 0x32435A42u;
     pk.curve = C::id;
     pk.field = FM::id;
-    pk.device = ctx->device;
-    pk.srs = srs;
     pk.k = r.u32();
     pk.na = (int)r.u32();
     pk.nf = (int)r.u32();
@@ -1029,7 +1278,6 @@ static int pk_create_t(bzh_ctx* ctx, const bzh_bases* srs, const uint8_t* blob, 
     if (!r.ok || pk.k < 1 || pk.k > 24 || pk.na > 4096 || pk.nf > 4096 || pk.ni > 4096) return BZH_E_ARG;
     memcpy(pk.vk_repr, vk, 32);
     pk.n = (size_t)1 << pk.k;
-    if (srs->n != pk.n + 2 || srs->curve != C::id) return BZH_E_ARG;
     const uint32_t ngates = r.u32();
     for (uint32_t g = 0; g < ngates && r.ok; g++) pk.gates.push_back(parse_expr<SF>(r, pk));
     const uint32_t nperm = r.u32();
@@ -1060,7 +1308,8 @@ static int pk_create_t(bzh_ctx* ctx, const bzh_bases* srs, const uint8_t* blob, 
     }
     if (!r.ok) return BZH_E_ARG;
     const size_t n = pk.n;
-    std::vector<Fe<SF>> fixed_h((size_t)pk.nf * n, fe_zero<SF>());
+    std::vector<Fe<SF>>& fixed_h = po.fixed_h;
+    fixed_h.assign((size_t)pk.nf * n, fe_zero<SF>());
     for (int f = 0; f < pk.nf; f++) {
         const uint32_t fl = r.u32();
         if (!r.ok || fl > n) return BZH_E_ARG;
@@ -1180,10 +1429,14 @@ static int pk_create_t(bzh_ctx* ctx, const bzh_bases* srs, const uint8_t* blob, 
     h_store<SF>(pk.eomega, eomega);
     h_store<SF>(pk.zeta, zeta);
     memcpy(pk.delta, delta.l, 32);
+    po.omega = omega, po.eomega = eomega, po.delta = delta, po.zeta = zeta;
 
     // permutation cycles (upstream permutation::keygen::Assembly::copy)
     const size_t m = nperm;
-    std::vector<uint32_t> map_c(m * n), map_r(m * n), aux_c(m * n), aux_r(m * n), sizes(m * n, 1);
+    std::vector<uint32_t>& map_c = po.map_c;
+    std::vector<uint32_t>& map_r = po.map_r;
+    map_c.resize(m * n), map_r.resize(m * n);
+    std::vector<uint32_t> aux_c(m * n), aux_r(m * n), sizes(m * n, 1);
     for (size_t c = 0; c < m; c++)
         for (size_t rr = 0; rr < n; rr++) {
             map_c[c * n + rr] = aux_c[c * n + rr] = (uint32_t)c;
@@ -1211,6 +1464,87 @@ static int pk_create_t(bzh_ctx* ctx, const bzh_bases* srs, const uint8_t* blob, 
         std::swap(map_r[li], map_r[ri]);
     }
 
+    // multiopen structure (rotations stand in for the points: distinct rotations <-> distinct points x * omega^r)
+    {
+        struct Q {
+            uint64_t cid;
+            int rot;
+        };
+        std::vector<Q> q;
+        const int last_rot = -(pk.bf + 1);
+        for (auto& a : pk.instance_queries) q.push_back({key(K_INST, a.first), a.second});
+        for (auto& a : pk.advice_queries) q.push_back({key(K_ADV, a.first), a.second});
+        for (int i = 0; i < pk.nsets; i++) {
+            q.push_back({key(K_PZ, i), 0});
+            q.push_back({key(K_PZ, i), 1});
+            if (i != pk.nsets - 1) q.push_back({key(K_PZ, i), last_rot});
+        }
+        for (int i = 0; i < pk.nl; i++) {
+            q.push_back({key(K_LZ, i), 0});
+            q.push_back({key(K_LA, i), 0});
+            q.push_back({key(K_LS, i), 0});
+            q.push_back({key(K_LA, i), -1});
+            q.push_back({key(K_LZ, i), 1});
+        }
+        for (auto& a : pk.fixed_queries) q.push_back({key(K_FIX, a.first), a.second});
+        for (size_t j = 0; j < m; j++) q.push_back({key(K_SIGMA, j), 0});
+        q.push_back({key(K_MISC, M_H0), 0});
+        q.push_back({key(K_MISC, M_F), 0});  // the random polynomial
+        std::vector<uint64_t> order;
+        std::map<uint64_t, std::vector<int>> pts_of;
+        for (auto& e2 : q) {
+            auto it = pts_of.find(e2.cid);
+            if (it == pts_of.end()) {
+                order.push_back(e2.cid);
+                it = pts_of.insert({e2.cid, {}}).first;
+            }
+            if (std::find(it->second.begin(), it->second.end(), e2.rot) == it->second.end()) it->second.push_back(e2.rot);
+        }
+        for (uint64_t cid : order) {
+            std::vector<int> ks = pts_of[cid];
+            std::sort(ks.begin(), ks.end());
+            size_t si = 0;
+            for (; si < pk.rot_sets.size(); si++)
+                if (pk.rot_sets[si] == ks) break;
+            if (si == pk.rot_sets.size()) {
+                pk.rot_sets.push_back(ks);
+                pk.groups.push_back({});
+            }
+            pk.groups[si].push_back(cid);
+        }
+    }
+    // randomness per proof: blinding rows and blinds in create_proof's draw order, then the IPA opening
+    {
+        const size_t bf1 = (size_t)pk.bf + 1;
+        size_t draws = (size_t)pk.na * bf1 + pk.na;
+        draws += (size_t)pk.nl * (2 * bf1 + 2);
+        draws += (size_t)(pk.nsets + pk.nl) * ((size_t)pk.bf + 1);
+        draws += n + 1;                 // random polynomial + its blind
+        draws += (size_t)pk.npieces;    // h pieces
+        draws += 1;                     // f blind
+        draws += n + 1 + 2 * (size_t)pk.k;
+        pk.rng_bytes = draws * 64;
+    }
+    compile_quotient<SF>(pk);
+    return BZH_OK;
+}
+
+// keygen, device half: fixed / permutation / identity polynomials in Lagrange, coefficient and extended-coset form,
+// l_0 / l_last / l_blind, X and 1 / (X^n - 1) on the extended coset, the hoisted columns of the quotient program.
+template <class C>
+static int pk_create_t(bzh_ctx* ctx, const bzh_bases* srs, const uint8_t* blob, size_t len, bzh_pk** out) {
+    using SF = typename CurveScalar<C>::SF;
+    std::unique_ptr<bzh_pk> pkp(new bzh_pk());
+    bzh_pk& pk = *pkp;
+    ParsedKey<SF> po;
+    PV_TRY(pk_parse_t<C>(blob, len, pk, po));
+    pk.device = ctx->device;
+    pk.srs = srs;
+    if (srs->n != pk.n + 2 || srs->curve != C::id) return BZH_E_ARG;
+    const size_t n = pk.n, m = pk.perm_columns.size();
+    const std::vector<Fe<SF>>& fixed_h = po.fixed_h;
+    const std::vector<uint32_t>&map_c = po.map_c, &map_r = po.map_r;
+    const Fe<SF> omega = po.omega, eomega = po.eomega, delta = po.delta, zeta = po.zeta;
     // device allocation: fixed / sigma / ident columns in the three forms, l0 / l_last / l_blind, X and 1/(X^n - 1)
     const size_t en = pk.en, nf = pk.nf;
     const size_t words = (2 * nf * n + nf * en + 3 * m * n + m * en + 3 * en + 2 * en + 3 * n) * 8;
@@ -1287,67 +1621,16 @@ static int pk_create_t(bzh_ctx* ctx, const bzh_bases* srs, const uint8_t* blob, 
         PV_TRY(up(pk.tinv_col, host.data(), en));
     }
 
-    // multiopen structure (rotations stand in for the points: distinct rotations <-> distinct points x * omega^r)
-    {
-        struct Q {
-            uint64_t cid;
-            int rot;
-        };
-        std::vector<Q> q;
-        const int last_rot = -(pk.bf + 1);
-        for (auto& a : pk.instance_queries) q.push_back({key(K_INST, a.first), a.second});
-        for (auto& a : pk.advice_queries) q.push_back({key(K_ADV, a.first), a.second});
-        for (int i = 0; i < pk.nsets; i++) {
-            q.push_back({key(K_PZ, i), 0});
-            q.push_back({key(K_PZ, i), 1});
-            if (i != pk.nsets - 1) q.push_back({key(K_PZ, i), last_rot});
-        }
-        for (int i = 0; i < pk.nl; i++) {
-            q.push_back({key(K_LZ, i), 0});
-            q.push_back({key(K_LA, i), 0});
-            q.push_back({key(K_LS, i), 0});
-            q.push_back({key(K_LA, i), -1});
-            q.push_back({key(K_LZ, i), 1});
-        }
-        for (auto& a : pk.fixed_queries) q.push_back({key(K_FIX, a.first), a.second});
-        for (size_t j = 0; j < m; j++) q.push_back({key(K_SIGMA, j), 0});
-        q.push_back({key(K_MISC, M_H0), 0});
-        q.push_back({key(K_MISC, M_F), 0});  // the random polynomial
-        std::vector<uint64_t> order;
-        std::map<uint64_t, std::vector<int>> pts_of;
-        for (auto& e2 : q) {
-            auto it = pts_of.find(e2.cid);
-            if (it == pts_of.end()) {
-                order.push_back(e2.cid);
-                it = pts_of.insert({e2.cid, {}}).first;
-            }
-            if (std::find(it->second.begin(), it->second.end(), e2.rot) == it->second.end()) it->second.push_back(e2.rot);
-        }
-        for (uint64_t cid : order) {
-            std::vector<int> ks = pts_of[cid];
-            std::sort(ks.begin(), ks.end());
-            size_t si = 0;
-            for (; si < pk.rot_sets.size(); si++)
-                if (pk.rot_sets[si] == ks) break;
-            if (si == pk.rot_sets.size()) {
-                pk.rot_sets.push_back(ks);
-                pk.groups.push_back({});
-            }
-            pk.groups[si].push_back(cid);
-        }
+    PV_TRY(materialize_hoist<SF>(ctx, pk));
+    pk.q_builtin = nullptr;
+    if (pk.q_ok) {
+        size_t nb = 0;
+        const bzh_builtin_quotient* tab = bzh_builtin_quotients ? bzh_builtin_quotients(&nb) : nullptr;
+        for (size_t i = 0; i < nb; i++)
+            if (tab[i].program_hash == pk.q_hash) pk.q_builtin = tab[i].launch;
     }
-    // randomness per proof: blinding rows and blinds in create_proof's draw order, then the IPA opening
-    {
-        const size_t bf1 = (size_t)pk.bf + 1;
-        size_t draws = (size_t)pk.na * bf1 + pk.na;
-        draws += (size_t)pk.nl * (2 * bf1 + 2);
-        draws += (size_t)(pk.nsets + pk.nl) * ((size_t)pk.bf + 1);
-        draws += n + 1;                 // random polynomial + its blind
-        draws += (size_t)pk.npieces;    // h pieces
-        draws += 1;                     // f blind
-        draws += n + 1 + 2 * (size_t)pk.k;
-        pk.rng_bytes = draws * 64;
-    }
+    const char* qenv = getenv("BZH_QUOTIENT");
+    pk.q_select = (pk.q_builtin && !(qenv && !strcmp(qenv, "interp"))) ? BZH_QUOTIENT_BUILTIN : BZH_QUOTIENT_INTERPRETER;
     BZH_HIP_TRY(ctx, hipStreamSynchronize(st));
     *out = pkp.release();
     return BZH_OK;
@@ -1579,116 +1862,18 @@ struct Prover {
                          per_proof ? nc : 0, size, pg.result_slot, B, nslots, d_out);
     }
 
-    // the quotient through VM v2: `build` returns the terms in protocol order and sets *tinv to the 1 / (X^n - 1) column node.
-    // Returns BZH_E_RANGE when the program does not fit VM v2 (the caller falls back to the plain fold through `run`).
-    template <class BuildTerms>
-    int run2(uint64_t pkey, BuildTerms build, const Cols& reg, size_t size, uint32_t* d_out) {
-        if (size % 128) return BZH_E_RANGE;   // VM v2 runs whole 128-row workgroups (tiny test domains take the plain fold)
-        const Program2* pgp = nullptr;
+    // the quotient through VM v2 (the program compiled at bzh_pk_create), as the builtin kernel, the caller's module or the
+    // interpreter.  Returns BZH_E_RANGE when the circuit does not fit VM v2 (the caller falls back to the plain fold through `run`).
+    int run_quotient(const Cols& reg, size_t size, uint32_t* d_out) {
+        if (!pk.q_ok || size % 128 || size != pk.en) return BZH_E_RANGE;
         hipFunction_t q_fn = nullptr;
+        bzh_quotient_launch_fn q_builtin = nullptr;
         {
-        // first use on this key: compile the program and evaluate the hoisted columns, all under the key's lock (other ctxs
-        // sharing the key wait here once); the hoisted columns are written on THIS ctx's stream, so it is drained before the
-        // lock is released and every other stream may read them
-        std::lock_guard<std::mutex> lk(pk.mu);
-        auto it = pk.progs2.find(pkey);
-        if (it == pk.progs2.end()) {
-            const bool built_hoist_before = pk.hoist != nullptr;
-            EPool ep;
-            int tinv = -1;
-            const std::vector<int> terms = build(ep, &tinv);
-            Compiler2 cc(ep);
-            // Hoisting: maximal subexpressions over proof-independent columns (stride 0: fixed / permutation / Lagrange
-            // columns of the key) and literal constants that contain a multiplication -- the compressed-selector products
-            // q prod (j - q) of every gate -- are evaluated ONCE on the extended coset into columns owned by the key.
-            if (!pk.hoist && !getenv("BZH_NO_HOIST")) {
-                const size_t nn = ep.n.size();
-                std::vector<char> indep(nn, 0);
-                std::vector<int> muls(nn, 0);
-                for (size_t i = 0; i < nn; i++) {   // children precede parents in the pool
-                    const ENode& e = ep.n[i];
-                    if (e.tag == EX_CONST) indep[i] = 1;
-                    else if (e.tag == EX_SYMBOL) indep[i] = 0;
-                    else if (e.tag == EX_QUERY) indep[i] = reg.stride[e.col] == 0;
-                    else if (e.tag == EX_NEG) indep[i] = indep[e.a], muls[i] = muls[e.a];
-                    else if (e.tag == EX_SCALE) indep[i] = indep[e.a], muls[i] = muls[e.a] + 1;
-                    else indep[i] = indep[e.a] && indep[e.b], muls[i] = muls[e.a] + muls[e.b] + (e.tag == EX_MUL);
-                }
-                std::vector<int> picked;
-                std::vector<char> seen(nn, 0);
-                std::vector<int> stack(terms.begin(), terms.end());
-                while (!stack.empty()) {
-                    const int i = stack.back();
-                    stack.pop_back();
-                    if (seen[i]) continue;
-                    seen[i] = 1;
-                    const ENode& e = ep.n[i];
-                    if (e.tag == EX_CONST || e.tag == EX_SYMBOL || e.tag == EX_QUERY) continue;
-                    if (indep[i] && muls[i] >= 1) {
-                        picked.push_back(i);
-                        continue;
-                    }
-                    if (e.a >= 0) stack.push_back(e.a);
-                    if (e.b >= 0) stack.push_back(e.b);
-                }
-                std::sort(picked.begin(), picked.end());
-                if (!picked.empty() && picked.size() <= 512) {
-                    uint32_t* buf = nullptr;
-                    if (hipMalloc((void**)&buf, picked.size() * size * 32) == hipSuccess) {
-                        pk.hoist = buf;
-                        pk.hoist_cols = picked.size();
-                        const size_t ncols = reg.ptr.size();
-                        for (size_t hi = 0; hi < picked.size(); hi++) {
-                            Compiler c1(ep);
-                            c1.prog.result_slot = c1.emit(picked[hi]);
-                            if (c1.overflow) return BZH_E_RANGE;
-                            const Program& pg = c1.prog;
-                            std::vector<uint32_t> cv(std::max<size_t>(pg.consts.size(), 1) * 8);
-                            for (size_t i = 0; i < pg.consts.size(); i++) memcpy(&cv[i * 8], pg.consts[i].val, 32);
-                            char* stage = (char*)arena.alloc(cv.size() * 4 + pg.ops.size() * sizeof(bzh_expr_op) + ncols * 16 + 1024);
-                            if (!stage) return BZH_E_OOM;
-                            uint32_t* d_consts = (uint32_t*)stage;
-                            char* d_prog = stage + ((cv.size() * 4 + 255) & ~(size_t)255);
-                            char* d_ptrs = d_prog + ((pg.ops.size() * sizeof(bzh_expr_op) + 255) & ~(size_t)255);
-                            char* d_strides = d_ptrs + ((ncols * 8 + 255) & ~(size_t)255);
-                            PV_TRY(h2d_small(ctx, d_consts, cv.data(), cv.size() * 4));
-                            PV_TRY(h2d_small(ctx, d_prog, pg.ops.data(), pg.ops.size() * sizeof(bzh_expr_op)));
-                            PV_TRY(h2d_small(ctx, d_ptrs, reg.ptr.data(), ncols * 8));
-                            PV_TRY(h2d_small(ctx, d_strides, reg.stride.data(), ncols * 8));
-                            int nslots = pg.result_slot + 1;
-                            for (auto& o : pg.ops) nslots = std::max(nslots, (int)o.dst + 1);
-                            PV_TRY(expr_eval(ctx, field, d_prog, (int)pg.ops.size(), (const uint32_t* const*)d_ptrs, (const size_t*)d_strides,
-                                             d_consts, 0, size, pg.result_slot, 1, nslots, pk.hoist + hi * size * 8));
-                            cc.hoisted[picked[hi]] = (int)(ncols + hi);
-                        }
-                    }
-                }
-            }
-            cc.quotient(terms, tinv);
-            cc.prog.nlds = cc.nlds();
-            if (getenv("BZH_PROVE_TRACE")) {
-                size_t muls = 0;
-                for (auto& o : cc.prog.ops) muls += ((o.code >> 4) < 3 && ((o.code >> 2) & 3) == V2_MUL);
-                fprintf(stderr, "[bzh_prove_batch] quotient program (VM v2): %zu terms, %zu ops, %zu multiplications, %d LDS slots, %zu constants, %zu hoisted columns%s\n",
-                        terms.size(), cc.prog.ops.size(), muls, cc.prog.nlds, cc.prog.consts.size(), pk.hoist_cols, cc.prog.ok ? "" : " -- NOT usable");
-                // instruction mix: form (SS/SL/LL/UN) x operation, and the kinds of the memory operands
-                size_t hist[4][4] = {{0}}, kinds[4] = {0};
-                for (auto& o : cc.prog.ops) {
-                    const int form = o.code >> 4, oo = (o.code >> 2) & 3;
-                    hist[form & 3][oo]++;
-                    if (form == V2_SL || form == V2_LL) kinds[o.b_kind & 3]++;
-                    if (form == V2_LL || (form == V2_UN && oo != V2_NEG)) kinds[o.a_kind & 3]++;
-                }
-                fprintf(stderr, "[bzh_prove_batch]   mix  SS add/sub/mul/rsub %zu/%zu/%zu/%zu  SL %zu/%zu/%zu/%zu  LL %zu/%zu/%zu/%zu  UN neg/load/store %zu/%zu/%zu ; operands column/const/lds %zu/%zu/%zu\n",
-                        hist[0][0], hist[0][1], hist[0][2], hist[0][3], hist[1][0], hist[1][1], hist[1][2], hist[1][3], hist[2][0], hist[2][1],
-                        hist[2][2], hist[2][3], hist[3][0], hist[3][1], hist[3][2], kinds[BZH_EXPR_COLUMN], kinds[BZH_EXPR_CONST], kinds[BZH_EXPR_LDS]);
-            }
-            if (pk.hoist && !built_hoist_before) BZH_HIP_TRY(ctx, hipStreamSynchronize(st));
-            it = pk.progs2.insert({pkey, std::move(cc.prog)}).first;
+            std::lock_guard<std::mutex> lk(pk.mu);
+            if (pk.q_select == BZH_QUOTIENT_MODULE) q_fn = pk.q_fn;
+            else if (pk.q_select == BZH_QUOTIENT_BUILTIN) q_builtin = pk.q_builtin;
         }
-        pgp = &it->second;
-        q_fn = pk.q_fn;
-        }
+        const Program2* pgp = &pk.qprog;
         const Program2& pg = *pgp;
         if (!pg.ok) return BZH_E_RANGE;
         const size_t nc = pg.consts.size(), ncols = reg.ptr.size() + pk.hoist_cols;
@@ -1725,7 +1910,13 @@ struct Prover {
             for (size_t i = 0; i < reg.stride.size(); i++) cols_read += reg.stride[i] ? (double)B : 1.0;
             ctx->alg_bytes[BZH_T_QUOTIENT] += (cols_read + (double)B) * (double)size * 32.0;
         }
-        if (q_fn) {   // the same program as compiled code (bzh_pk_set_quotient_module)
+        if (q_builtin) {   // the same program as a kernel generated at build time
+            ScopedTimer t(ctx, BZH_T_QUOTIENT);
+            q_builtin((unsigned)(size / 128), (unsigned)B, (void*)st, (const uint32_t* const*)d_ptrs, (const size_t*)d_strides, d_consts, nc, size, d_out);
+            BZH_HIP_TRY(ctx, hipGetLastError());
+            return BZH_OK;
+        }
+        if (q_fn) {   // the same program as a code object of the caller's (bzh_pk_set_quotient_module)
             ScopedTimer t(ctx, BZH_T_QUOTIENT);
             const uint32_t* const* a_cols = (const uint32_t* const*)d_ptrs;
             const size_t* a_strides = (const size_t*)d_strides;
@@ -2028,77 +2219,16 @@ int Prover<C>::prove(const uint32_t* d_advice_in, const uint64_t* instances, siz
     if (!h) return BZH_E_OOM;
     {
         Cols reg;
-        for (int i = 0; i < na; i++) reg.add(key(K_ADV, i), adv_cosets + (size_t)i * en * 8, (size_t)na * en);
-        for (int i = 0; i < nf; i++) reg.add(key(K_FIX, i), pk.fixed_cosets + (size_t)i * en * 8, 0);
-        for (int i = 0; i < ni; i++) reg.add(key(K_INST, i), inst_cosets + (size_t)i * en * 8, (size_t)ni * en);
-        for (size_t j = 0; j < m; j++) reg.add(key(K_SIGMA, j), pk.sigma_cosets + j * en * 8, 0);
-        for (int i = 0; i < nsets; i++) reg.add(key(K_PZ, i), z_cosets + (size_t)i * en * 8, (size_t)nz * en);
-        for (int i = 0; i < nl; i++) {
-            reg.add(key(K_LA, i), lk[i].cosets, 2 * en);
-            reg.add(key(K_LS, i), lk[i].cosets + en * 8, 2 * en);
-            reg.add(key(K_LZ, i), z_cosets + (size_t)(nsets + i) * en * 8, (size_t)nz * en);
-        }
-        reg.add(key(K_MISC, M_L0), pk.l0, 0);
-        reg.add(key(K_MISC, M_LLAST), pk.l_last, 0);
-        reg.add(key(K_MISC, M_LBLIND), pk.l_blind, 0);
-        reg.add(key(K_MISC, M_X), pk.x_col, 0);
-        reg.add(key(K_MISC, M_TINV), pk.tinv_col, 0);
-        const int e = (int)ext;
-        auto build_terms = [&](EPool& ep, int* tinv) -> std::vector<int> {
-            auto Q = [&](uint64_t kk, int rot = 0) { return ep.query(reg.at(kk), rot); };
-            auto col_q = [&](std::pair<int, int> col) {
-                return Q(key(col.first == CX_ADVICE ? K_ADV : (col.first == CX_FIXED ? K_FIX : K_INST), col.second));
-            };
-            const Fe<SF> onef = fe_one<SF>();
-            auto one = [&] { return ep.cnst(onef); };
-            auto l0 = [&] { return Q(key(K_MISC, M_L0)); };
-            auto l_last = [&] { return Q(key(K_MISC, M_LLAST)); };
-            auto active = [&] { return ep.sub(one(), ep.add(l_last(), Q(key(K_MISC, M_LBLIND)))); };
-            std::vector<int> terms;
-            for (int g : pk.gates) terms.push_back(lower(pk, g, ep, reg, e));
-            if (nsets) {
-                terms.push_back(ep.mul(l0(), ep.sub(one(), Q(key(K_PZ, 0)))));
-                const uint64_t zl = key(K_PZ, nsets - 1);
-                terms.push_back(ep.mul(l_last(), ep.sub(ep.mul(Q(zl), Q(zl)), Q(zl))));
-                for (int i = 1; i < nsets; i++) terms.push_back(ep.mul(l0(), ep.sub(Q(key(K_PZ, i)), Q(key(K_PZ, i - 1), last_rot * e))));
-                for (int i = 0; i < nsets; i++) {
-                    const size_t c0 = (size_t)i * pk.chunk_len, c1 = std::min(m, c0 + pk.chunk_len);
-                    int left = Q(key(K_PZ, i), e), right = Q(key(K_PZ, i));
-                    for (size_t gj = c0; gj < c1; gj++) {
-                        left = ep.mul(left, ep.add(ep.add(col_q(pk.perm_columns[gj]), ep.mul(ep.sym(SY_BETA), Q(key(K_SIGMA, gj)))), ep.sym(SY_GAMMA)));
-                        const int cur = ep.mul(ep.sym(SY_BD0 + (int)gj), Q(key(K_MISC, M_X)));
-                        right = ep.mul(right, ep.add(ep.add(col_q(pk.perm_columns[gj]), cur), ep.sym(SY_GAMMA)));
-                    }
-                    terms.push_back(ep.mul(active(), ep.sub(left, right)));
-                }
-            }
-            for (int i = 0; i < nl; i++) {
-                auto z0 = [&] { return Q(key(K_LZ, i)); };
-                auto a_p = [&] { return Q(key(K_LA, i)); };
-                auto s_p = [&] { return Q(key(K_LS, i)); };
-                auto comp = [&](const std::vector<int>& es) {
-                    std::vector<int> t;
-                    for (int x : es) t.push_back(lower(pk, x, ep, reg, e));
-                    return ep.horner(t, ep.sym(SY_THETA));
-                };
-                terms.push_back(ep.mul(l0(), ep.sub(one(), z0())));
-                terms.push_back(ep.mul(l_last(), ep.sub(ep.mul(z0(), z0()), z0())));
-                const int lhs = ep.mul(ep.mul(Q(key(K_LZ, i), e), ep.add(a_p(), ep.sym(SY_BETA))), ep.add(s_p(), ep.sym(SY_GAMMA)));
-                const int rhs = ep.mul(ep.mul(z0(), ep.add(comp(pk.lookups[i].first), ep.sym(SY_BETA))),
-                                       ep.add(comp(pk.lookups[i].second), ep.sym(SY_GAMMA)));
-                terms.push_back(ep.mul(active(), ep.sub(lhs, rhs)));
-                terms.push_back(ep.mul(l0(), ep.sub(a_p(), s_p())));
-                terms.push_back(ep.mul(ep.mul(active(), ep.sub(a_p(), s_p())), ep.sub(a_p(), Q(key(K_LA, i), -e))));
-            }
-            *tinv = Q(key(K_MISC, M_TINV));
-            return terms;
-        };
+        QuotientPtrs qp;
+        qp.adv = adv_cosets, qp.inst = inst_cosets, qp.z = z_cosets;
+        for (int i = 0; i < nl; i++) qp.lk.push_back(lk[i].cosets);
+        quotient_registry(pk, qp, reg);
         // VM v2 (gate-factored fold, shared subexpressions in LDS); the plain Horner fold through VM v1 if it does not fit
-        int qrc = getenv("BZH_QUOTIENT_V1") ? BZH_E_RANGE : run2(key(41, 0), build_terms, reg, en, h);
+        int qrc = getenv("BZH_QUOTIENT_V1") ? BZH_E_RANGE : run_quotient(reg, en, h);
         if (qrc == BZH_E_RANGE) {
             qrc = run(key(40, 0), [&](EPool& ep) {
                 int tinv = -1;
-                const std::vector<int> terms = build_terms(ep, &tinv);
+                const std::vector<int> terms = quotient_terms<SF>(pk, reg, ep, &tinv);
                 return ep.mul(ep.horner(terms, ep.sym(SY_Y)), tinv);
             }, reg, en, h);
         }
@@ -3008,12 +3138,11 @@ int bzh_pk_set_lagrange(bzh_pk* pk, const bzh_bases* g_lagrange) {
 
 int bzh_pk_quotient_stats(bzh_pk* pk, uint32_t* ops, uint32_t* multiplications, uint32_t* lds_slots, uint32_t* hoisted_columns) {
     if (!pk) return BZH_E_ARG;
-    std::lock_guard<std::mutex> lk(pk->mu);
     uint32_t no = 0, nm = 0, nl = 0;
-    for (auto& kv : pk->progs2) {   // the quotient program (compiled at the first proof)
-        no = (uint32_t)kv.second.ops.size();
-        nl = (uint32_t)kv.second.nlds;
-        for (auto& o : kv.second.ops) nm += ((o.code >> 4) < 3 && ((o.code >> 2) & 3) == bzh::V2_MUL);
+    if (pk->q_ok) {
+        no = (uint32_t)pk->qprog.ops.size();
+        nl = (uint32_t)pk->qprog.nlds;
+        for (auto& o : pk->qprog.ops) nm += ((o.code >> 4) < 3 && ((o.code >> 2) & 3) == bzh::V2_MUL);
     }
     if (ops) *ops = no;
     if (multiplications) *multiplications = nm;
@@ -3022,17 +3151,62 @@ int bzh_pk_quotient_stats(bzh_pk* pk, uint32_t* ops, uint32_t* multiplications, 
     return BZH_OK;
 }
 
-int bzh_pk_quotient_source(bzh_pk* pk, char* buf, size_t cap, size_t* len) {
-    if (!pk || !len) return BZH_E_ARG;
-    std::lock_guard<std::mutex> lk(pk->mu);
-    if (pk->progs2.empty()) return BZH_E_RANGE;   // compiled at the key's first proof
-    const std::string src = bzh::program2_source(pk->progs2.begin()->second, pk->field);
+static int copy_text(const std::string& src, char* buf, size_t cap, size_t* len) {
     *len = src.size();
     if (buf && cap) {
         const size_t n = std::min(cap - 1, src.size());
         memcpy(buf, src.data(), n);
         buf[n] = 0;
     }
+    return BZH_OK;
+}
+
+int bzh_pk_quotient_source(bzh_pk* pk, char* buf, size_t cap, size_t* len) {
+    if (!pk || !len) return BZH_E_ARG;
+    if (!pk->q_ok) return BZH_E_RANGE;   // the circuit does not fit VM v2
+    return copy_text(bzh::program2_source(pk->qprog, pk->field), buf, cap, len);
+}
+
+int bzh_quotient_source_for_circuit(int curve, const uint8_t* circuit, size_t circuit_len, char* buf, size_t cap, size_t* len,
+                                    uint64_t* program_hash) {
+    if (!circuit || !len) return BZH_E_ARG;
+    bzh_pk pk;
+    int rc = BZH_E_ARG;
+    if (curve == BZH_CURVE_VESTA) {
+        bzh::ParsedKey<bzh::CurveScalar<bzh::VestaCurve>::SF> po;
+        rc = bzh::pk_parse_t<bzh::VestaCurve>(circuit, circuit_len, pk, po);
+    } else if (curve == BZH_CURVE_PALLAS) {
+        bzh::ParsedKey<bzh::CurveScalar<bzh::PallasCurve>::SF> po;
+        rc = bzh::pk_parse_t<bzh::PallasCurve>(circuit, circuit_len, pk, po);
+    }
+    if (rc) return rc;
+    if (!pk.q_ok) return BZH_E_RANGE;
+    if (program_hash) *program_hash = pk.q_hash;
+    return copy_text(bzh::program2_source(pk.qprog, pk.field, true), buf, cap, len);
+}
+
+int bzh_pk_quotient_select(bzh_pk* pk, int flavour) {
+    if (!pk) return BZH_E_ARG;
+    std::lock_guard<std::mutex> lk(pk->mu);
+    switch (flavour) {
+        case BZH_QUOTIENT_INTERPRETER: break;
+        case BZH_QUOTIENT_BUILTIN:
+            if (!pk->q_builtin) return BZH_E_RANGE;
+            break;
+        case BZH_QUOTIENT_MODULE:
+            if (!pk->q_fn) return BZH_E_RANGE;
+            break;
+        default: return BZH_E_ARG;
+    }
+    pk->q_select = flavour;
+    return BZH_OK;
+}
+
+int bzh_pk_quotient_selected(bzh_pk* pk, int* flavour, int* builtin_available) {
+    if (!pk) return BZH_E_ARG;
+    std::lock_guard<std::mutex> lk(pk->mu);
+    if (flavour) *flavour = pk->q_select;
+    if (builtin_available) *builtin_available = pk->q_builtin != nullptr;
     return BZH_OK;
 }
 
@@ -3047,8 +3221,9 @@ int bzh_pk_set_quotient_module(bzh_ctx* ctx, bzh_pk* pk, const void* code_object
         pk->q_module = nullptr;
         pk->q_fn = nullptr;
     }
-    if (!code_object || !len) return BZH_OK;   // back to the interpreter
-    if (pk->progs2.empty()) return BZH_E_RANGE;
+    if (pk->q_select == BZH_QUOTIENT_MODULE) pk->q_select = pk->q_builtin ? BZH_QUOTIENT_BUILTIN : BZH_QUOTIENT_INTERPRETER;
+    if (!code_object || !len) return BZH_OK;   // back to the key's default
+    if (!pk->q_ok) return BZH_E_RANGE;
     hipModule_t mod = nullptr;
     BZH_HIP_TRY(ctx, hipModuleLoadData(&mod, code_object));
     hipFunction_t fn = nullptr;
@@ -3057,8 +3232,7 @@ int bzh_pk_set_quotient_module(bzh_ctx* ctx, bzh_pk* pk, const void* code_object
     unsigned long long have = 0;
     const bool ok = hipModuleGetFunction(&fn, mod, "jit_quotient") == hipSuccess &&
                     hipModuleGetGlobal(&hsym, &hbytes, mod, "jit_program_hash") == hipSuccess && hbytes == 8 &&
-                    hipMemcpy(&have, hsym, 8, hipMemcpyDeviceToHost) == hipSuccess &&
-                    have == bzh::program2_hash(pk->progs2.begin()->second, pk->field);
+                    hipMemcpy(&have, hsym, 8, hipMemcpyDeviceToHost) == hipSuccess && have == pk->q_hash;
     if (!ok) {
         (void)hipModuleUnload(mod);
         ctx->last_error = "bzh_pk_set_quotient_module: not a module generated from this key's quotient program";
@@ -3066,6 +3240,7 @@ int bzh_pk_set_quotient_module(bzh_ctx* ctx, bzh_pk* pk, const void* code_object
     }
     pk->q_module = mod;
     pk->q_fn = fn;
+    pk->q_select = BZH_QUOTIENT_MODULE;
     return BZH_OK;
 }
 

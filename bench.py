@@ -156,8 +156,7 @@ def parse():
     ap.add_argument("--mix-divisor", type=int, default=1, help="mixed_board_shot: divide the fixed batch (256 Board + 2560 Shot) by this")
     ap.add_argument("--window-bits", type=int, default=0, help="SRS window-table width (0: 8 for --batch 1, else the planner's)")
     ap.add_argument("--no-quotient-codegen", action="store_true",
-                    help="proof_k* workloads: keep the interpreted quotient evaluator (default: its program is compiled with hipcc at setup, "
-                         "bzh_pk_quotient_source / bzh_pk_set_quotient_module)")
+                    help="proof_k* workloads: the interpreted quotient evaluator (default: the circuit's kernel built into libbzh2.so)")
     ap.add_argument("--explicit-rng", action="store_true",
                     help="proof_k* workloads: generate every proof's random stream on the host (numpy) and pass it to bzh_prove_batch "
                          "instead of a 32-byte seed per proof expanded on the device (bzh_prove_batch_seeded)")
@@ -283,16 +282,12 @@ class ProofRunner:
         self.step_batches = [[] for _ in range(workers)]      # every batch of the current plan (for the record gather)
         self.np_rng = [np.random.default_rng(seed + 1000 + wi) for wi in range(workers)]
         self.kind_id = 1 if kind == "shot" else 0           # bzh2.wire.KIND_SHOT / KIND_BOARD
-        # The quotient evaluator as compiled code (bzh_pk_quotient_source -> hipcc -> bzh_pk_set_quotient_module): the program exists
-        # after a key's first proof, so every key proves one witness here (setup, like keygen), then gets the module -- one
-        # compilation per circuit and process, cached on disk.
-        self.quotient_codegen = False
-        if ProofRunner.QUOTIENT_CODEGEN:
-            self._prove_slice(0, 0, 1)
-            self.quotient_codegen = self.pk.compile_quotient()
-            self.last_batch = [[] for _ in range(workers)]
-            self.last_insts = [[] for _ in range(workers)]
-            self.step_batches = [[] for _ in range(workers)]
+        # The quotient evaluator: the reference's circuits have their kernel inside libbzh2.so (generated at build time, picked
+        # by bzh_pk_create); --no-quotient-codegen selects the interpreter instead.
+        from bzh2 import native as Nn
+        if not ProofRunner.QUOTIENT_CODEGEN:
+            self.pk.quotient_select(Nn.QUOTIENT_INTERPRETER)
+        self.quotient_codegen = self.pk.quotient_selected()[0] != Nn.QUOTIENT_INTERPRETER
 
     def worker_ctxs(self):
         return [(st, types.SimpleNamespace(ctx=c)) for st, c in zip(self.streams, self.ctxs)]
@@ -490,7 +485,7 @@ class Workload:
             self.alg_bytes_step = 0
             self.desc = {"k": k, "circuit": self.runner.circuit_desc, "proof_bytes": None,
                          "driver": "native (bzh_synthesize_* + %s)" % ("bzh_prove_batch" if ProofRunner.EXPLICIT_RNG else "bzh_prove_batch_seeded"),
-                         "quotient_evaluator": "compiled from the key's program at setup (hipcc, bzh_pk_set_quotient_module)" if self.runner.quotient_codegen else "interpreted (k_expr_vm2)",
+                         "quotient_evaluator": "builtin kernel (the circuit's program as straight-line code, generated and linked when libbzh2.so was built)" if self.runner.quotient_codegen else "interpreted (k_expr_vm2)",
                          "randomness": ("every draw generated on the host and passed in (%d bytes per proof)" % self.runner.rng_bytes) if ProofRunner.EXPLICIT_RNG
                          else "a fresh 32-byte seed per proof, expanded on the device (ChaCha20) -- the reference draws OsRng inside create_proof"}
             self.result = torch.zeros((1, 12), dtype=torch.int64, device=device)
@@ -808,7 +803,7 @@ def main():
         qt = timings.get("quotient", {"ms": 0.0, "launches": 0, "algorithmic_bytes": 0.0})
         peaks = ubench_peaks()
         # the quotient kernel's name in the profiles: the interpreter, or the key's program as compiled code
-        qname = "jit_quotient" if getattr(getattr(wl, "runner", None), "quotient_codegen", False) else "k_expr_vm2"
+        qname = "bzh_quotient" if getattr(getattr(wl, "runner", None), "quotient_codegen", False) else "k_expr_vm2"
         if args.workload == "ntt22":
             dom_ms = nt["ms"] / max(nt["launches"], 1) * (nt["launches"] / max(args.steps, 1))  # all passes of one NTT
             alg = wl.alg_bytes_step

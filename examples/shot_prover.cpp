@@ -21,6 +21,8 @@
 #include <string>
 #include <vector>
 
+#include <sys/random.h>
+
 #include "bzh2.h"
 
 #define CHECK(expr)                                                                              \
@@ -31,6 +33,22 @@
             return 1;                                                                            \
         }                                                                                        \
     } while (0)
+
+// OsRng: getrandom(2); the fixed generator only on request
+static void fill_random(uint8_t* out, size_t n, bool fixed_seed, std::mt19937_64& gen) {
+    if (!fixed_seed) {
+        size_t got = 0;
+        while (got < n) {
+            const ssize_t r = getrandom(out + got, n - got, 0);
+            if (r <= 0) break;
+            got += (size_t)r;
+        }
+        if (got == n) return;
+        fprintf(stderr, "getrandom failed\n");
+        exit(1);
+    }
+    for (size_t i = 0; i < n; i++) out[i] = (uint8_t)gen();
+}
 
 int main(int argc, char** argv) {
     const size_t batch = argc > 1 ? (size_t)atoi(argv[1]) : 16;
@@ -66,14 +84,17 @@ int main(int argc, char** argv) {
     uint32_t num_advice = 0, n_rows = 0, usable = 0;
     CHECK(bzh_pk_info(pk, &rng_bytes, &max_proof, &num_advice, &n_rows, &usable));
 
-    // `batch` circuits: same board and shot, a fresh trapdoor each (pallas::Scalar::random)
+    // `batch` circuits: same board and shot, a fresh trapdoor each (pallas::Scalar::random(&mut OsRng)).  Seeds and
+    // trapdoors MUST come from the OS generator: a predictable seed makes every blind of the proof predictable and breaks
+    // zero-knowledge.  BZH_EXAMPLE_FIXED_SEED=1 (benchmarks / reproducible runs only) uses mt19937_64(42) instead.
+    const bool fixed_seed = getenv("BZH_EXAMPLE_FIXED_SEED") != nullptr;
     std::mt19937_64 gen(42);
     std::vector<uint64_t> boards(4 * batch), shots(4 * batch), hits(4 * batch, 0), trapdoors(4 * batch);
     for (size_t b = 0; b < batch; b++) {
         memcpy(&boards[4 * b], board_state, 32);
         memcpy(&shots[4 * b], shot, 32);
         hits[4 * b] = 1;
-        for (int i = 0; i < 4; i++) trapdoors[4 * b + i] = gen();
+        fill_random((uint8_t*)&trapdoors[4 * b], 32, fixed_seed, gen);
         trapdoors[4 * b + 3] &= 0x3fffffffffffffffull;            // < 2^254 < q
     }
     std::vector<uint64_t> advice(batch * num_advice * (size_t)n_rows * 4), instances(batch * 4 * 4);
@@ -81,34 +102,13 @@ int main(int argc, char** argv) {
     std::vector<size_t> lens(batch);
     std::vector<int> ok(batch);
     double best = 1e30;
-    bool compiled_quotient = false;
+    // the quotient evaluator: ShotCircuit's kernel is inside libbzh2.so (generated when the library was built) and was picked
+    // by bzh_pk_create; BZH_EXAMPLE_NO_CODEGEN=1 selects the interpreter
+    if (getenv("BZH_EXAMPLE_NO_CODEGEN")) CHECK(bzh_pk_quotient_select(pk, BZH_QUOTIENT_INTERPRETER));
+    int flavour = 0;
+    CHECK(bzh_pk_quotient_selected(pk, &flavour, nullptr));
     for (int s = 0; s < steps; s++) {
-        if (s == 1 && !getenv("BZH_EXAMPLE_NO_CODEGEN")) {
-            // after the first proof the key's quotient program exists: compile it once (hipcc as a child process) and install it
-            size_t len = 0;
-            if (bzh_pk_quotient_source(pk, nullptr, 0, &len) == BZH_OK && len) {
-                std::string src(len + 1, '\0');
-                CHECK(bzh_pk_quotient_source(pk, &src[0], len + 1, &len));
-                const std::string base = std::string(getenv("GRAFT_OUT") ? getenv("GRAFT_OUT") : "/tmp") + "/shot_quotient";
-                if (FILE* f = fopen((base + ".hip").c_str(), "w")) {
-                    fwrite(src.data(), 1, len, f);
-                    fclose(f);
-                    const std::string cmd = "/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 --genco -I battlezips-halo2_amd/csrc " + base +
-                                            ".hip -o " + base + ".hsaco 2>/dev/null";
-                    if (system(cmd.c_str()) == 0) {
-                        if (FILE* g2 = fopen((base + ".hsaco").c_str(), "rb")) {
-                            std::vector<char> code;
-                            char tmp[65536];
-                            size_t n;
-                            while ((n = fread(tmp, 1, sizeof(tmp), g2)) > 0) code.insert(code.end(), tmp, tmp + n);
-                            fclose(g2);
-                            compiled_quotient = bzh_pk_set_quotient_module(ctx, pk, code.data(), code.size()) == BZH_OK;
-                        }
-                    }
-                }
-            }
-        }
-        for (auto& v : seeds) v = (uint8_t)gen();                 // OsRng
+        fill_random(seeds.data(), seeds.size(), fixed_seed, gen);   // OsRng: every blinding factor of a proof derives from its seed
         const auto t0 = std::chrono::steady_clock::now();
         CHECK(bzh_synthesize_shot(ctx, circuit, batch, boards.data(), trapdoors.data(), shots.data(), hits.data(), advice.data(),
                                   BZH_FORM_MONTGOMERY, BZH_MEM_HOST, instances.data(), 0));
@@ -131,7 +131,20 @@ int main(int argc, char** argv) {
         for (size_t i = 0; i < lens[b]; i++) h = (h ^ proofs[b * max_proof + i]) * 1099511628211ull;
     printf("{\"circuit\": \"ShotCircuit k=11\", \"batch\": %zu, \"best_ms\": %.2f, \"proofs_per_s\": %.1f, \"proof_bytes\": %zu, \"verified\": %zu, "
            "\"quotient\": \"%s\", \"fnv1a\": \"%016llx\"}\n", batch, best, batch / best * 1e3, lens[0], accepted,
-           compiled_quotient ? "compiled" : "interpreted", (unsigned long long)h);
+           flavour == BZH_QUOTIENT_BUILTIN ? "builtin kernel" : (flavour == BZH_QUOTIENT_MODULE ? "module" : "interpreted"), (unsigned long long)h);
+    // what the reference's wasm frontend returns per proof (src/wasm/circuit_wasm.rs:27-31,164-170): {commitment, proof}
+    {
+        const size_t stride = bzh_record_stride(max_proof);
+        std::vector<uint8_t> rec(stride);
+        CHECK(bzh_record_encode(instances.data(), 4, proofs.data(), lens[0], /*kind: Shot*/ 1, 0, rec.data(), stride));
+        size_t jl = 0;
+        CHECK(bzh_record_to_json(rec.data(), stride, nullptr, 0, &jl));
+        std::string json(jl + 1, '\0');
+        CHECK(bzh_record_to_json(rec.data(), stride, &json[0], jl + 1, &jl));
+        std::vector<uint8_t> back(stride);
+        CHECK(bzh_record_from_json(json.c_str(), jl, 1, 0, back.data(), stride));   // canonical check of verify_shot (:86-116)
+        printf("{\"record_json_bytes\": %zu, \"round_trip\": %s}\n", jl, back == rec ? "true" : "false");
+    }
     bzh_pk_free(ctx, pk);
     bzh_circuit_free(circuit);
     bzh_params_free(ctx, params);

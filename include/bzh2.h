@@ -266,7 +266,8 @@ int bzh_ipa_verify(bzh_ctx* ctx, const bzh_bases* bases, const uint64_t* commitm
  *                  bzh2.circuit_data.serialize_circuit for test circuits):
  *                  fixed / permutation polynomials in Lagrange, coefficient and extended-coset form, l_0 / l_last /
  *                  l_blind, resident on the device.  `srs`: n + 2 points G_0..G_(n-1), U, W with a window table
- *                  (bzh_bases_precompute); it must outlive the key.
+ *                  (bzh_bases_precompute).  LIFETIME: the key BORROWS `srs` (and the table given to
+ *                  bzh_pk_set_lagrange): both must outlive the key -- free the key before bzh_params_free / bzh_bases_free.
  * bzh_prove_batch  create_proof for `batch` independent witnesses of that circuit in lockstep (one launch per kernel
  *                  class per protocol phase for all of them); every proof is byte-identical to proving its witness
  *                  alone.  advice: batch x num_advice x n field elements (`form`, `mem`; rows past the usable ones are
@@ -275,8 +276,9 @@ int bzh_ipa_verify(bzh_ctx* ctx, const bzh_bases* bases, const uint64_t* commitm
  *                  upstream's draw order (bzh_pk_info reports the byte count); proofs: batch records of
  *                  proof_stride bytes, lengths in proof_lens.  BZH_E_RANGE: a witness does not satisfy the circuit
  *                  (surplus quotient coefficients) or a lookup input is not in its table.
- *                  A key serves one call at a time (its device arena and program cache are per key): concurrent batches
- *                  use one key per host thread, as bench.py does. */
+ *                  A key is shared, read-only state (upstream's &ProvingKey): several host threads may prove / verify on
+ *                  ONE key concurrently, each through its own ctx -- the per-call workspace lives with the (key, ctx) pair
+ *                  inside the library.  Calls through one ctx are serialised as everywhere else. */
 typedef struct bzh_pk bzh_pk;
 int bzh_pk_create(bzh_ctx* ctx, const bzh_bases* srs, const uint8_t* circuit, size_t circuit_len, bzh_pk** out);
 int bzh_pk_free(bzh_ctx* ctx, bzh_pk* pk);
@@ -285,17 +287,36 @@ int bzh_pk_free(bzh_ctx* ctx, bzh_pk* pk);
  * bytes) as committing their coefficients to g, but sparse / small witness columns then cost the MSM almost nothing.
  * NULL returns to coefficient-basis commitments.  The table must outlive the key. */
 int bzh_pk_set_lagrange(bzh_pk* pk, const bzh_bases* g_lagrange);
-/* the quotient's evaluator program (compiled at the key's first proof; zeros before): instructions, field multiplications per
+/* the quotient's evaluator program (compiled on the host at bzh_pk_create): instructions, field multiplications per
  * extended-domain row, LDS slots, proof-independent subexpressions hoisted into key-owned coset columns */
 int bzh_pk_quotient_stats(bzh_pk* pk, uint32_t* ops, uint32_t* multiplications, uint32_t* lds_slots, uint32_t* hoisted_columns);
-/* The quotient evaluator as compiled code.  bzh_pk_quotient_source returns the key's evaluator program (available after the
- * key's first proof, BZH_E_RANGE before) as straight-line HIP source: *len = its length, copied NUL-terminated into buf (cap
- * bytes) when buf != NULL.  Compile it for gfx950 against csrc/field.cuh (`hipcc -O3 -std=c++17 --offload-arch=gfx950 --genco
- * -I <csrc>`, ~5 s; or hiprtc) and hand the code object to bzh_pk_set_quotient_module: the quotient pass of every later proof
- * launches it instead of the interpreter (BoardCircuit, 16 x 2^17 rows: 9.0 ms against 12.5 ms; same proof bytes).  A module
- * generated from another program is refused (BZH_E_ARG: it carries the program's hash); NULL / 0 returns to the interpreter. */
+/* The quotient evaluator as compiled code.  The program depends on the circuit only (not on k, the SRS or a witness), so for
+ * the reference's two circuits (ShotCircuit, BoardCircuit) the kernels are generated when the library is BUILT
+ * (csrc/gen_quotient.cpp -> quotient_builtin.hip, linked into libbzh2.so) and picked up by bzh_pk_create through the program's
+ * hash: no compiler is needed where the library runs.  For any other circuit bzh_pk_quotient_source returns the key's program
+ * as straight-line HIP source (*len = its length, copied NUL-terminated into buf when buf != NULL): compile it for gfx950
+ * against csrc/field.cuh (`hipcc -O3 -std=c++17 --offload-arch=gfx950 --genco -I <csrc>`, ~5 s; or hiprtc) and hand the code
+ * object to bzh_pk_set_quotient_module, which selects it (BoardCircuit, 64 x 2^17 rows: 35.5 ms against the interpreter's 49.5 ms;
+ * same proof bytes).  A module generated from another program is refused (BZH_E_ARG: it carries the program's hash); NULL / 0
+ * unloads the module and returns to the key's default (the builtin kernel if there is one, else the interpreter).
+ * bzh_pk_quotient_select picks explicitly (BZH_E_RANGE when that flavour is not available for this key);
+ * bzh_pk_quotient_selected reports the current choice and whether a builtin kernel exists.  Environment: BZH_QUOTIENT=interp
+ * makes the interpreter every new key's default. */
+typedef enum { BZH_QUOTIENT_INTERPRETER = 0, BZH_QUOTIENT_BUILTIN = 1, BZH_QUOTIENT_MODULE = 2 } bzh_quotient_flavour;
 int bzh_pk_quotient_source(bzh_pk* pk, char* buf, size_t cap, size_t* len);
 int bzh_pk_set_quotient_module(bzh_ctx* ctx, bzh_pk* pk, const void* code_object, size_t len);
+int bzh_pk_quotient_select(bzh_pk* pk, int flavour);
+int bzh_pk_quotient_selected(bzh_pk* pk, int* flavour, int* builtin_available);
+/* Host only (no ctx, no GPU): the quotient program of a circuit blob as the source text of a BUILTIN kernel (namespace
+ * bzh_q_<hash> with the kernel bzh_quotient_<hash> and a host function `launch`), and the program hash.  This is what the
+ * build-time generator calls; BZH_E_RANGE if the circuit does not fit the evaluator (such circuits use the VM v1 fold). */
+int bzh_quotient_source_for_circuit(int curve, const uint8_t* circuit, size_t circuit_len, char* buf, size_t cap, size_t* len,
+                                    uint64_t* program_hash);
+/* launcher of one builtin kernel, and the table the generated file exports (used inside the library) */
+typedef void (*bzh_quotient_launch_fn)(unsigned grid_x, unsigned grid_y, void* hip_stream, const uint32_t* const* cols, const size_t* strides,
+                                       const uint32_t* consts, size_t const_stride, size_t size, uint32_t* out);
+typedef struct { uint64_t program_hash; bzh_quotient_launch_fn launch; const char* name; } bzh_builtin_quotient;
+const bzh_builtin_quotient* bzh_builtin_quotients(size_t* count);
 int bzh_pk_info(const bzh_pk* pk, size_t* rng_bytes_per_proof, size_t* max_proof_bytes, uint32_t* num_advice, uint32_t* n_rows,
                 uint32_t* usable_rows);
 /* bzh_verify_batch  plonk::verify_proof (SingleVerifier; benches/board.rs:80-86) for `batch` proofs of the key's circuit:
@@ -311,7 +332,10 @@ int bzh_prove_batch(bzh_ctx* ctx, bzh_pk* pk, size_t batch, const uint64_t* advi
 /* create_proof with the randomness drawn inside the library, as the reference does from OsRng (benches/shot.rs:68): proof b's
  * stream is ChaCha20 keyed by seeds[b] (32 bytes; 64-bit block counter from 0, zero nonce), block i being the i-th 64-byte draw
  * (ff::Field::random), expanded on the device -- no rng_bytes_per_proof (2 MB at k = 14) to generate and upload per proof.
- * The proofs are exactly those of bzh_prove_batch fed with bzh_rng_expand(seeds[b], 0, rng_bytes_per_proof / 64, ..). */
+ * The proofs are exactly those of bzh_prove_batch fed with bzh_rng_expand(seeds[b], 0, rng_bytes_per_proof / 64, ..).
+ * SECURITY: every blinding factor of proof b is a function of seeds[b]; the seeds (and the bytes given to bzh_prove_batch)
+ * MUST come from a cryptographically secure generator (getrandom(2), OsRng, os.urandom), fresh per proof -- a predictable or
+ * reused seed voids zero-knowledge.  Fixed seeds are for tests and benchmarks only. */
 int bzh_prove_batch_seeded(bzh_ctx* ctx, bzh_pk* pk, size_t batch, const uint64_t* advice, int form, int mem, const uint64_t* instances,
                            size_t instance_rows, const uint8_t* seeds, uint8_t* proofs, size_t proof_stride, size_t* proof_lens);
 /* host: draws [first_draw, first_draw + draws) of the stream of `seed`, 64 bytes each, into out */

@@ -97,3 +97,35 @@ def test_cpp_example_client_compiles_against_the_header():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     subprocess.check_call([cxx, "-std=c++17", "-fsyntax-only", "-Wall", "-I", os.path.join(root, "include"),
                            os.path.join(root, "examples", "shot_prover.cpp")])
+
+
+def test_builtin_quotient_kernels_cover_the_references_circuits(bzh2_lib):
+    """The quotient kernels of ShotCircuit and BoardCircuit are generated when the library is built (csrc/gen_quotient.cpp)
+    and found by program hash; the program depends on the circuit only, so the hash is the same at every k -- checked here on
+    the host (bzh_quotient_source_for_circuit needs no GPU), together with the generated table inside libbzh2.so."""
+    import ctypes
+    from bzh2 import circuits as Cm
+    L = bzh2_lib.load()
+
+    class Entry(ctypes.Structure):
+        _fields_ = [("program_hash", ctypes.c_uint64), ("launch", ctypes.c_void_p), ("name", ctypes.c_char_p)]
+    L.bzh_builtin_quotients.restype = ctypes.POINTER(Entry)
+    L.bzh_builtin_quotients.argtypes = [ctypes.POINTER(ctypes.c_size_t)]
+    n = ctypes.c_size_t()
+    tab = L.bzh_builtin_quotients(ctypes.byref(n))
+    table = {tab[i].name.decode(): tab[i].program_hash for i in range(n.value)}
+    assert set(table) == {"ShotCircuit", "BoardCircuit"} and all(tab[i].launch for i in range(n.value))
+    L.bzh_quotient_source_for_circuit.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t,
+                                                  ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_uint64)]
+    for kind, name, ks in ((Cm.SHOT, "ShotCircuit", (11, 13)), (Cm.BOARD, "BoardCircuit", (12, 14))):
+        for k in ks:
+            lay = Cm.CircuitLayout(kind, k)
+            blob = lay.blob()
+            lay.close()
+            ln, h = ctypes.c_size_t(), ctypes.c_uint64()
+            assert L.bzh_quotient_source_for_circuit(0, blob, len(blob), None, 0, ctypes.byref(ln), ctypes.byref(h)) == 0
+            assert h.value == table[name], (name, k)
+            buf = ctypes.create_string_buffer(ln.value + 1)
+            assert L.bzh_quotient_source_for_circuit(0, blob, len(blob), buf, ln.value + 1, ctypes.byref(ln), ctypes.byref(h)) == 0
+            assert ("bzh_quotient_%016x" % h.value) in buf.value.decode()
+    assert L.bzh_quotient_source_for_circuit(0, b"junk", 4, None, 0, ctypes.byref(ln), ctypes.byref(h)) == bzh2_lib.E_ARG

@@ -171,47 +171,61 @@ def test_seeded_randomness_gives_the_proofs_of_the_expanded_streams(gpu_ctx, sho
     assert pkb.prove_batch(advb, instb, None, seeds=[sd]) == pkb.prove_batch(advb, instb, [N.rng_expand(sd, 0, pkb.rng_bytes // 64)])
 
 
-def test_compiled_quotient_module_gives_the_same_proofs(gpu_ctx, shot_setup, board_setup):
-    """bzh_pk_quotient_source -> hipcc -> bzh_pk_set_quotient_module: the key's evaluator program as straight-line code
-    produces the proofs of the interpreter, bit for bit; a module generated from another circuit's program is refused;
-    NULL returns to the interpreter."""
+def test_compiled_quotient_flavours_give_the_same_proofs(gpu_ctx, shot_setup, board_setup):
+    """The key's evaluator program runs three ways: the interpreter (k_expr_vm2), the kernel generated when libbzh2.so was
+    built (found by program hash at bzh_pk_create: the default for the reference's circuits, no compiler at run time) and a
+    code object compiled by the caller (bzh_pk_quotient_source -> hipcc -> bzh_pk_set_quotient_module, the path for foreign
+    circuits).  Same proofs bit for bit; a module generated from another circuit's program is refused; NULL returns to the
+    key's default.  (tests/test_gpu_real_circuit_parity.py compares the first two with the ORACLE prover.)"""
     import shutil
     import bzh2
     from bzh2 import circuits as Cm, native as N
-    if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
-        pytest.skip("no hipcc on this box")
     rng = random.Random(15)
     lay, blob, pk, _ = shot_setup
     circuits = _shot_circuits(Cm, rng, 3)
     adv, insts = lay.synthesize(circuits)
     seeds = [bytes(rng.getrandbits(8) for _ in range(32)) for _ in circuits]
-    want = pk.prove_batch(adv, insts, None, seeds=seeds)                  # interpreter (and makes the program exist)
-    src = pk.quotient_source()
-    assert "jit_quotient" in src and "jit_program_hash" in src
-    shot_code = N.compile_quotient_source(src)
-    assert shot_code is not None
-    pk.set_quotient_module(shot_code)
+    assert pk.quotient_selected() == (N.QUOTIENT_BUILTIN, True)
+    builtin = pk.prove_batch(adv, insts, None, seeds=seeds)
+    pk.quotient_select(N.QUOTIENT_INTERPRETER)
     try:
+        assert pk.quotient_selected()[0] == N.QUOTIENT_INTERPRETER
+        want = pk.prove_batch(adv, insts, None, seeds=seeds)
+        assert builtin == want
+        with pytest.raises(bzh2.BzhError) as e:
+            pk.quotient_select(N.QUOTIENT_MODULE)                          # no module installed
+        assert e.value.status == bzh2.E_RANGE
+        if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
+            return
+        src = pk.quotient_source()
+        assert "jit_quotient" in src and "jit_program_hash" in src
+        shot_code = N.compile_quotient_source(src)
+        assert shot_code is not None
+        pk.set_quotient_module(shot_code)
+        assert pk.quotient_selected()[0] == N.QUOTIENT_MODULE
         assert pk.prove_batch(adv, insts, None, seeds=seeds) == want
-        # BoardCircuit: its own module works, the Shot module is refused
+        # BoardCircuit: the Shot module is refused, its own flavours agree
         layb, _, pkb, _ = board_setup
         deck, _ = _random_deck(rng)
         ships, state = Cm.board_witness(deck, None)
         cb = [Cm.BoardCircuit(ships, state, rng.randrange(FQ))]
         advb, instb = layb.synthesize(cb)
         sd = [bytes(rng.getrandbits(8) for _ in range(32))]
-        wantb = pkb.prove_batch(advb, instb, None, seeds=sd)
+        wantb = pkb.prove_batch(advb, instb, None, seeds=sd)              # builtin
         with pytest.raises(bzh2.BzhError) as e:
             pkb.set_quotient_module(shot_code)
         assert e.value.status == bzh2.E_ARG
-        assert pkb.compile_quotient()
+        assert pkb.quotient_selected()[0] == N.QUOTIENT_BUILTIN
+        pkb.quotient_select(N.QUOTIENT_INTERPRETER)
         try:
             assert pkb.prove_batch(advb, instb, None, seeds=sd) == wantb
         finally:
-            pkb.set_quotient_module(None)
-        assert pkb.prove_batch(advb, instb, None, seeds=sd) == wantb
+            pkb.quotient_select(N.QUOTIENT_BUILTIN)
+        pk.set_quotient_module(None)
+        assert pk.quotient_selected()[0] == N.QUOTIENT_BUILTIN          # NULL: back to the key's default
     finally:
         pk.set_quotient_module(None)
+        pk.quotient_select(N.QUOTIENT_BUILTIN)
     assert pk.prove_batch(adv, insts, None, seeds=seeds) == want
 
 

@@ -36,14 +36,16 @@ def _setup(ctx, kind, k):
 
 
 def _both_evaluators(pk, adv, insts, streams):
-    """the proofs of the interpreter and of the compiled quotient kernel for the same inputs"""
-    pk.set_quotient_module(None)
-    interp = pk.prove_batch(adv, insts, streams)
-    assert pk.compile_quotient(), "no compiled quotient kernel for this circuit"
+    """the proofs of the interpreter and of the compiled quotient kernel (built into libbzh2.so for the reference's circuits:
+    no compiler at run time) for the same inputs"""
+    from bzh2 import native as N
+    assert pk.quotient_selected() == (N.QUOTIENT_BUILTIN, True), "the key did not pick up the kernel generated at build time"
+    compiled = pk.prove_batch(adv, insts, streams)
+    pk.quotient_select(N.QUOTIENT_INTERPRETER)
     try:
-        compiled = pk.prove_batch(adv, insts, streams)
+        interp = pk.prove_batch(adv, insts, streams)
     finally:
-        pk.set_quotient_module(None)
+        pk.quotient_select(N.QUOTIENT_BUILTIN)
     return interp, compiled
 
 
@@ -81,7 +83,6 @@ def test_real_board_circuit_production_at_bench_sizes(gpu_ctx, oracle_c, k, batc
     from bzh2 import circuits as Cm
     lay, prm, pk = _setup(gpu_ctx, "board", k)
     try:
-        assert pk.compile_quotient()
         circuits = R.board_circuits(Cm, 1700 + k, batch)
         adv, insts = lay.synthesize(circuits)
         seeds = [R.rng_stream("production-%d-%d" % (k, b), 32) for b in range(batch)]

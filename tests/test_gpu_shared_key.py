@@ -49,8 +49,8 @@ def test_threads_share_one_key_and_get_the_private_keys_proofs(gpu_ctx):
         assert not errors, errors
         for wi in range(workers):
             assert got[wi][0] == want[wi] and got[wi][1] == want[wi], wi
-        # the compiled quotient module is installed once and serves every ctx
-        assert pk.compile_quotient()
+        # the interpreter, selected on the shared key, serves every ctx too
+        pk.quotient_select(N.QUOTIENT_INTERPRETER)
         again = pk.prove_batch(jobs[2][0], jobs[2][1], None, seeds=jobs[2][2], ctx=ctxs[1])
         assert again == want[2]
         pk.close()
