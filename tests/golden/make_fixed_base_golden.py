@@ -4,9 +4,11 @@
 Reads (as text) the constant tables the reference's own tests check
 (`generator`, `z`, `lagrange_coeffs` tests at
 src/utils/constants/fixed_bases/board_commit_{v,r}.rs:2940-2960) and writes a
-SMALL sampled fixture: both GENERATOR pairs, all 85 Z values (u64 each) and 48
-sampled U rows per base (always including the last window, which uses the
-offset scalar).  Only numbers are emitted -- no reference source text.
+fixture: both GENERATOR pairs, all 85 Z values (u64 each) and ALL 680 U values per
+base ("U": 85 windows x 8, the 1 360 y-coordinate known answers behind the
+reference's `z` tests), plus the 48-row sample "U_rows" (always including the last
+window, which uses the offset scalar) the slow big-int check walks.  Only numbers
+are emitted -- no reference source text.
 
 Run in the build container (needs /root/reference):
     python tests/golden/make_fixed_base_golden.py
@@ -56,6 +58,7 @@ def main():
             "generator": [hex(gx), hex(gy)],
             "Z": zs,
             "U_rows": [[w, k, hex(U[w][k])] for (w, k) in sorted(rows)],
+            "U": [[hex(U[w][k]) for k in range(8)] for w in range(85)],
         }
     with open(OUT, "w") as f:
         json.dump(out, f, indent=1)

@@ -2,6 +2,8 @@
 (`generator` tests, src/utils/constants/fixed_bases/board_commit_{v,r}.rs:2941-2948, data in tests/golden/fixed_bases.json)
 and against the oracle's independent hash_to_curve (oracle/pasta.py) on Vesta for the SRS messages."""
 import json
+
+import pytest
 import os
 
 import pasta as O
@@ -36,3 +38,31 @@ def test_srs_generators_match_the_oracle():
     for dom, msg in (("z.cash:test", b""), ("z.cash:test", b"Trans rights now!"), ("battlezips:hash2curve", b"v" * 200)):
         for cid, name in ((bzh2.CURVE_PALLAS, "pallas"), (bzh2.CURVE_VESTA, "vesta")):
             assert Pm.hash_to_curve(cid, dom, msg) == O.hash_to_curve(name, dom, msg)
+
+
+@pytest.mark.parametrize("base,name", [(0, "v"), (1, "r")])
+def test_product_fixed_base_tables_reproduce_every_reference_constant(base, name):
+    """bzh_fixed_base_tables derives Z, U and the Lagrange coefficients of both commitment bases from the generators
+    (csrc/circuit/ecc.hpp) -- the tables PedersenCommitmentChip's fixed-base multiplication witnesses from.  Against the
+    reference's checked-in constants, all of them: 85 Z and 680 U per base (board_commit_{v,r}.rs:17-2927), and the two
+    properties its `z` / `lagrange_coeffs` tests assert through halo2_gadgets' test_zs_and_us / test_lagrange_coeffs
+    (:2950-2960): u^2 = y + z with z - y a non-square, and the degree-7 interpolant of window w takes the value
+    x([(k+2) 8^w] B) at k (last window: the offset scalar)."""
+    import coracle as C
+    import numpy as np
+    from bzh2 import circuits as Cm
+    b = GOLD["bases"][name]
+    z, u, lagrange = Cm.fixed_base_tables(base)
+    assert z == b["Z"]
+    assert u == [[int(x, 16) for x in row] for row in b["U"]]
+    G = C.points_to_array([tuple(int(x, 16) for x in b["generator"])])[0]
+    P, Q = O.P, O.Q
+    for w in range(85):
+        for k in range(8):
+            s = ((k + 2) * 8 ** w if w < 84 else k * 8 ** 84 - sum(2 * 8 ** j for j in range(84))) % Q
+            out = np.zeros(8, dtype=np.uint64)
+            C.lib().orc_point_mul(1, C._p(C.int_to_limbs(s)), C._p(G), C._p(out))
+            x, y = C.limbs_to_int(out[:4]), C.limbs_to_int(out[4:])
+            assert (u[w][k] * u[w][k] - z[w] - y) % P == 0
+            assert pow((z[w] - y) % P, (P - 1) // 2, P) == P - 1, "z - y must be a non-square"
+            assert sum(c * pow(k, j, P) for j, c in enumerate(lagrange[w])) % P == x, (w, k)
