@@ -18,6 +18,10 @@ struct bzh_bases {
     int device = 0;
     int pre_c = 0;     // != 0: d_xy holds the window table, row w = 2^(pre_c * w) * G_i
     int pre_nwin = 0;
+    // Several tables side by side (one per proof: the IPA's collapsed generators, msm_collapse_table): the rows of the table
+    // array are row_stride points apart (0: n) and vector v of a batch reads the columns [v * vec_col_stride, + n)
+    size_t row_stride = 0;
+    size_t vec_col_stride = 0;
 };
 
 struct bzh_ctx {
@@ -251,6 +255,14 @@ int ntt_run_padded(bzh_ctx* ctx, int field, uint32_t* d_dst, const uint32_t* d_s
                    const uint64_t* omega, const uint64_t* coset_shift);
 int bases_to_montgomery(bzh_ctx* ctx, int curve, uint32_t* d_xy, size_t n);
 int bases_precompute(bzh_ctx* ctx, bzh_bases* bases, int window_bits);
+// The IPA's generator collapse on the device.  For every proof b of `batch`: G'[b][i] = sum_{t < cnt} s[b][t] * G[i + t*m], i < m
+// = n_srs / cnt, evaluated through the SRS window table `srs` (n_srs + 2 points), followed by U and W (the table's last two
+// points), and expanded into a per-proof window table of c_tail-bit rows.  d_s: batch x cnt Montgomery scalars.
+// d_table: ceil(256 / c_tail) rows of batch * (m + 2) affine points; d_scratch: msm_collapse_scratch_bytes() bytes.
+// `out` is filled to describe the table array to msm_run_paired (it borrows d_table).
+size_t msm_collapse_scratch_bytes(const bzh_bases* srs, size_t cnt, size_t batch, int c_tail);
+int msm_collapse_table(bzh_ctx* ctx, const bzh_bases* srs, const uint32_t* d_s, size_t cnt, size_t batch, int c_tail, uint32_t* d_table,
+                       void* d_scratch, bzh_bases* out);
 // polyops.hip (device pointers, Montgomery form)
 int field_convert(bzh_ctx* ctx, int field, uint32_t* d, size_t count, int to_mont);
 int poly_batch_invert(bzh_ctx* ctx, int field, uint32_t* d, size_t count);

@@ -16,6 +16,17 @@
 // MSM (U and W are the last two entries of the table).  Output bytes are identical to the
 // collapsing formulation (tests/test_gpu_ipa.py pins them against the oracle's restatement of
 // upstream under a shared randomness stream).
+//
+// Round 3: ONE collapse instead of k.  Every round over the original table costs nwin * n bucket additions whatever the
+// round, 14 x 24 n at k = 14 -- a third of a proof's additions.  At round j* the folded generators
+//     G'[i] = sum_{t < 2^j*} s_t G_(i + t m),  m = n / 2^j*
+// are materialised ONCE per proof through the same window table (msm_collapse_table, csrc/msm.hip: the scalars are shared by
+// all i, so the bucket method runs with the level as the outer loop and one output per lane: (2^j* nwin + 2 levels) additions
+// per output instead of a 255-bit double-and-add per term) and given their own small window table; the remaining rounds are
+// the same paired MSMs on m points.  Additions per opening: 24 n j* + ~48 n + 150 m + 26 m (k - j*) instead of 24 n k
+// (k = 14, j* = 4: 168 n against 336 n).  The group elements L_j, R_j are the same, hence the proof bytes.  Used when the
+// batch is large enough to be throughput-bound (the collapse is two long per-lane chains: it would lengthen a single
+// proof); BZH_IPA_COLLAPSE = 0 disables it, = j forces round j at any batch size; BZH_IPA_TAIL_C sets the tail window.
 #include <cstring>
 #include <vector>
 
@@ -277,7 +288,7 @@ template <class P>
 __global__ void __launch_bounds__(256) k_ipa_round_vectors(const uint32_t* __restrict__ p, const uint32_t* __restrict__ s, size_t n,
                                                              unsigned log_m, const uint32_t* __restrict__ vlr,
                                                              const uint32_t* __restrict__ hc, const uint32_t* __restrict__ rands,
-                                                             size_t nrand, unsigned round, uint32_t* __restrict__ lr) {
+                                                             size_t nrand, size_t rand_n, unsigned round, uint32_t* __restrict__ lr) {
     const size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x, b = blockIdx.y;
     const size_t m = (size_t)1 << log_m, half = m >> 1;
     const uint32_t* pb = p + b * m * 8;
@@ -297,7 +308,7 @@ __global__ void __launch_bounds__(256) k_ipa_round_vectors(const uint32_t* __res
         }
     } else if (g == n) {
         const Fe<P> zz = fe_load<P>(hc + (b * kHc + 2) * 8);
-        const uint32_t* rd = rands + (b * nrand + n + 1 + 2 * (size_t)round) * 8;
+        const uint32_t* rd = rands + (b * nrand + rand_n + 1 + 2 * (size_t)round) * 8;   // rand_n: the opening's full length
         fe_store(L + n * 8, fe_mul(fe_load<P>(vlr + b * 16), zz));
         fe_store(R + n * 8, fe_mul(fe_load<P>(vlr + b * 16 + 8), zz));
         fe_store(L + (n + 1) * 8, fe_load<P>(rd));
@@ -311,7 +322,7 @@ template <class P>
 __global__ void __launch_bounds__(256) k_ipa_round_vectors_paired(const uint32_t* __restrict__ p, const uint32_t* __restrict__ s,
                                                                     size_t n, unsigned log_m, const uint32_t* __restrict__ vlr,
                                                                     const uint32_t* __restrict__ hc,
-                                                                    const uint32_t* __restrict__ rands, size_t nrand,
+                                                                    const uint32_t* __restrict__ rands, size_t nrand, size_t rand_n,
                                                                     unsigned round, uint32_t* __restrict__ lr) {
     const size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x, b = blockIdx.y;
     const size_t m = (size_t)1 << log_m, half = m >> 1;
@@ -322,7 +333,7 @@ __global__ void __launch_bounds__(256) k_ipa_round_vectors_paired(const uint32_t
         fe_store(V + g * 8, fe_mul(fe_load<P>(p + (b * m + src) * 8), fe_load<P>(s + (b * (n >> log_m) + t) * 8)));
     } else if (g == n) {
         const Fe<P> zz = fe_load<P>(hc + (b * kHc + 2) * 8);
-        const uint32_t* rd = rands + (b * nrand + n + 1 + 2 * (size_t)round) * 8;
+        const uint32_t* rd = rands + (b * nrand + rand_n + 1 + 2 * (size_t)round) * 8;
         fe_store(V + n * 8, fe_mul(fe_load<P>(vlr + b * 16), zz));
         fe_store(V + (n + 1) * 8, fe_load<P>(rd));
         fe_store(V + (n + 2) * 8, fe_mul(fe_load<P>(vlr + b * 16 + 8), zz));
@@ -390,11 +401,46 @@ static int ipa_open_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_po
     const size_t nrand = n + 1 + 2 * (size_t)k, ntail = 1 + 2 * (size_t)k;
     hipStream_t st = ctx->stream;
 
+    // The generator collapse: at round jstar the folded generators get their own tables and the rounds continue on m points
+    // (header).  jstar minimises  24 n j + 48 n + 150 m + 26 m (k - j)  over the rounds that leave m >= 64.
+    unsigned jstar = 0;
+    int tail_c = 9;
+    {
+        static const int env_j = [] {
+            const char* e = getenv("BZH_IPA_COLLAPSE");
+            return e ? atoi(e) : -1;
+        }();
+        static const int env_c = [] {
+            const char* e = getenv("BZH_IPA_TAIL_C");
+            return e ? atoi(e) : 0;
+        }();
+        if (env_c >= 4 && env_c <= 13) tail_c = env_c;
+        if (bases->pre_c != 0 && !bases->vec_col_stride && env_j != 0) {
+            if (env_j > 0) {
+                if ((unsigned)env_j + 1 < k) jstar = (unsigned)env_j;   // forced (tests): any batch size, m >= 2
+            } else if (B >= 8 && k >= 9) {
+                double best = 24.0 * (double)n * k * 0.9;               // at least 10 % fewer additions than no collapse
+                for (unsigned j = 1; j + 6 <= k; j++) {
+                    const double m = (double)(n >> j);
+                    const double cost = 24.0 * n * j + 48.0 * n + 150.0 * m + 26.0 * m * (k - j);
+                    if (cost < best) {
+                        best = cost;
+                        jstar = j;
+                    }
+                }
+            }
+            if (jstar && (size_t)(2 * ((size_t)1 << jstar) * bases->pre_nwin) * 4 > 48 * 1024) jstar = 0;   // item lists must fit LDS
+        }
+    }
+    const size_t tail_m = jstar ? n >> jstar : 0;
+    const int tail_nwin = (256 + tail_c - 1) / tail_c;
+    const size_t tail_scratch = jstar ? msm_collapse_scratch_bytes(bases, (size_t)1 << jstar, B, tail_c) : 0;
     // device arena (workspace slot 4), per proof: raw rng | rand scalars | s_poly | p x2 | b x2 | s x2 | LR | S scalars | small
     const size_t per = nrand * 16 + nrand * 8 + n * 8 + 2 * n * 8 + 2 * n * 8 + 2 * n * 8 + 2 * (n + 4) * 8 + (n + 2) * 8 +
                        (kHc + 4) * 8;
+    const size_t tail_words = jstar ? B * (tail_m + 2) * (size_t)tail_nwin * 16 + (tail_scratch + 3) / 4 + 64 : 0;
     void* arena = nullptr;
-    IPA_TRY(ws_ensure(ctx, 4, B * per * 4 + 256, &arena));
+    IPA_TRY(ws_ensure(ctx, 4, (B * per + tail_words) * 4 + 256, &arena));
     uint32_t* cur = (uint32_t*)arena;
     auto take = [&](size_t w) {
         uint32_t* r = cur;
@@ -413,6 +459,8 @@ static int ipa_open_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_po
     uint32_t* d_lr = take(B * 2 * (n + 4) * 8);
     const bool paired = bases->pre_c != 0 && k >= 1;  // window table: L_j and R_j of a proof share one dense vector
     uint32_t* d_commit = take(B * (n + 2) * 8);
+    uint32_t* d_tail_table = jstar ? take(B * (tail_m + 2) * (size_t)tail_nwin * 16) : nullptr;
+    void* d_tail_scratch = jstar ? (void*)take((tail_scratch + 3) / 4) : nullptr;
     uint32_t* d_hc = take(B * kHc * 8);
     uint32_t* d_dv = take(B * 8);       // s(x3) / v per proof
     uint32_t* d_vlr = take(B * 2 * 8);  // value_l, value_r per proof
@@ -476,17 +524,31 @@ static int ipa_open_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_po
     BZH_HIP_TRY(ctx, hipGetLastError());
 
     std::vector<Fe<SF>> us(B), pre(B + 1);
+    // the instance the rounds run on: the SRS and n points, or (from round jstar on) the per-proof tables and tail_m points
+    const bzh_bases* rb = bases;
+    bzh_bases tail_bases;
+    size_t rn = n;          // points of the current instance
+    unsigned j0 = 0;        // the round its s vector restarted at
     for (unsigned j = 0; j < k; j++) {
-        const size_t m = n >> j, half = m >> 1, cnt = (size_t)1 << j;
+        if (jstar && j == jstar) {
+            IPA_TRY(msm_collapse_table(ctx, bases, s_cur, (size_t)1 << j, B, tail_c, d_tail_table, d_tail_scratch, &tail_bases));
+            rb = &tail_bases;
+            rn = tail_m;
+            j0 = j;
+            // s restarts at (1): the folded generators ARE the instance now
+            std::vector<Fe<SF>> ones(B, fe_one<SF>());
+            IPA_TRY(h2d_small(ctx, s_cur, ones.data(), B * 32));
+        }
+        const size_t m = n >> j, half = m >> 1, cnt = (size_t)1 << (j - j0);
         hipLaunchKernelGGL((k_ipa_inner2<SF>), dim3((unsigned)B, 2), dim3(256), 0, st, p_cur, b_cur, half, d_vlr);
         if (paired) {
-            hipLaunchKernelGGL((k_ipa_round_vectors_paired<SF>), grid2(n + 1), dim3(g256), 0, st, p_cur, s_cur, n, k - j, d_vlr, d_hc,
-                               d_rand, nrand, j, d_lr);
+            hipLaunchKernelGGL((k_ipa_round_vectors_paired<SF>), grid2(rn + 1), dim3(g256), 0, st, p_cur, s_cur, rn, k - j, d_vlr, d_hc,
+                               d_rand, nrand, n, j, d_lr);
             BZH_HIP_TRY(ctx, hipGetLastError());
-            IPA_TRY(msm_run_paired(ctx, bases, d_lr, n, k - j, B, BZH_FORM_MONTGOMERY, (uint32_t*)d_out));
+            IPA_TRY(msm_run_paired(ctx, rb, d_lr, rn, k - j, B, BZH_FORM_MONTGOMERY, (uint32_t*)d_out));
         } else {
             hipLaunchKernelGGL((k_ipa_round_vectors<SF>), grid2(n + 1), dim3(g256), 0, st, p_cur, s_cur, n, k - j, d_vlr, d_hc,
-                               d_rand, nrand, j, d_lr);
+                               d_rand, nrand, n, j, d_lr);
             BZH_HIP_TRY(ctx, hipGetLastError());
             IPA_TRY(msm_run(ctx, bases, d_lr, n + 2, 2 * B, BZH_FORM_MONTGOMERY, (uint32_t*)d_out));
         }

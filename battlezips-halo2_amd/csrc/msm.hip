@@ -235,7 +235,8 @@ __global__ void __launch_bounds__(T) k_msm_accumulate(const uint32_t* __restrict
                                                                   int M, size_t chunk, uint4* __restrict__ buckets,
                                                                   uint4* __restrict__ partials, size_t row_len,
                                                                   size_t row_stride, size_t dup_from,
-                                                                  unsigned long long* __restrict__ add_counter) {
+                                                                  unsigned long long* __restrict__ add_counter,
+                                                                  size_t vec_col_stride, size_t vec0) {
     using P = typename C::Base;
     extern __shared__ __align__(16) uint32_t lds[];
     uint32_t* cnt = lds;  // index m in [0, M]; cnt[0] stays 0
@@ -308,7 +309,8 @@ __global__ void __launch_bounds__(T) k_msm_accumulate(const uint32_t* __restrict
     // e / row_len, column e % row_len of a table whose rows are row_stride points apart
     // (row_len < row_stride when a prefix of the table is used).  row_len == 0: plain bases.
     const bool remap = row_len != 0 && row_len != row_stride;
-    const uint32_t* base0 = bases + c0 * 16;
+    // (per-proof tables side by side: vector vec0 + b reads its own columns)
+    const uint32_t* base0 = bases + ((vec0 + b) * vec_col_stride + c0) * 16;
     const uint32_t total = cnt[M], maxpop = scratch[31];
     if (add_counter && tid == 0 && total) atomicAdd(add_counter, (unsigned long long)total);   // profiling: bucket additions actually made
     const uint32_t L = (total + T - 1) / T;
@@ -1012,7 +1014,7 @@ static int msm_run_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_sca
         p.chunk = (p.chunk + 63) & ~(size_t)63;
         p.nchunks = (n_eff + p.chunk - 1) / p.chunk;
         row_len = n;
-        row_stride = bases->n;
+        row_stride = bases->row_stride ? bases->row_stride : bases->n;
     }
     acc_nwin = pre ? 1 : p.nwin;
     MsmPair pair{0, 0, 0};
@@ -1031,7 +1033,7 @@ static int msm_run_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_sca
         const char* e = getenv("BZH_MSM_GS");
         return e ? atoi(e) : 0;
     }();
-    const bool use_gs = pre && gs_env != 0 && n_eff < ((size_t)1 << 31) && n_eff >= 4096;
+    const bool use_gs = pre && gs_env != 0 && n_eff < ((size_t)1 << 31) && n_eff >= 4096 && !bases->vec_col_stride;
     constexpr int GT = 512;  // threads per region workgroup
     size_t gs_nreg = 1;
     if (use_gs) {
@@ -1171,7 +1173,8 @@ static int msm_run_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_sca
 #define BZH_LAUNCH_ACC(TT)                                                                                              \
     hipLaunchKernelGGL((k_msm_accumulate<C, TT>), grid, dim3(TT), acc_lds, ctx->stream, bases->d_xy,                      \
                        (const uint16_t*)d_digits, n_eff, acc_nwin, M_acc, p.chunk, (uint4*)d_buckets, d_partials, row_len, \
-                       row_stride, pair_in ? n - 2 : (size_t)0, ctx->profiling ? ctx->d_add_counter : nullptr)
+                       row_stride, pair_in ? n - 2 : (size_t)0, ctx->profiling ? ctx->d_add_counter : nullptr,            \
+                       bases->vec_col_stride, b0)
             if (acc_threads == 128) BZH_LAUNCH_ACC(128);
             else if (acc_threads == 512) BZH_LAUNCH_ACC(512);
             else BZH_LAUNCH_ACC(256);
@@ -1302,6 +1305,225 @@ int bases_to_montgomery(bzh_ctx* ctx, int curve, uint32_t* d_xy, size_t n) {
     }
     BZH_HIP_TRY(ctx, hipGetLastError());
     return BZH_OK;
+}
+
+
+// ---------------------------------------------------------------------------
+// The IPA's generator collapse (ipa.hip): after j rounds the folded generators are
+//     G'[i] = sum_{t < cnt} s[t] * G[i + t*m],   cnt = 2^j, m = n / cnt,
+// the SAME cnt scalars for every i.  With the SRS window table (row w = 2^(c w) G) and s[t] = sum_w D[t][w] 2^(c w),
+//     G'[i] = sum_{(t, w)} D[t][w] * Row_w[i + t*m]:  cnt * nwin items per output, and the item list (t, w, D) is shared by all i.
+// |D| = a * 2^h + r with h = ceil((c - 1) / 2): G' = 2^h * sum sgn a Row + sum sgn r Row, each sum by the bucket method with the
+// bucket LEVEL as the outer loop: a lane owns one output i, walks the levels from the top and keeps
+//     acc (the bucket of this level), running (the sum of the buckets above and at it), total (the sum of the running sums),
+// i.e. (items + 2 * levels) additions per output instead of a 255-bit double-and-add per term.  The loop bounds depend on s
+// only, so they are wave-uniform, and a wave's table reads are 64 consecutive points.
+// ---------------------------------------------------------------------------
+template <class C>
+__global__ void __launch_bounds__(256) k_collapse_generators(const uint32_t* __restrict__ table, size_t row_stride, int c, int nwin,
+                                                               const uint16_t* __restrict__ digits, size_t cnt, size_t m, size_t n_srs,
+                                                               uint32_t* __restrict__ out, size_t out_cols) {
+    using P = typename C::Base;
+    extern __shared__ __align__(16) uint32_t lds[];
+    const int h = c / 2;                         // |D| <= 2^(c-1) = a * 2^h + r, a <= 2^(c-1-h), r < 2^h
+    const int levels_a = 1 << (c - 1 - h), levels_r = (1 << h) - 1, LV = (levels_a > levels_r ? levels_a : levels_r) + 2;
+    const int nitems = (int)cnt * nwin;
+    uint32_t* startA = lds;                      // [LV]: first list position of level v (exclusive scan), pass A
+    uint32_t* startR = lds + LV;
+    uint32_t* fillA = lds + 2 * LV;              // running fill cursors of the scatter
+    uint32_t* fillR = lds + 3 * LV;
+    uint32_t* listA = lds + 4 * LV;              // [nitems]: (t * nwin + w) | sign << 31, sorted by level
+    uint32_t* listR = listA + nitems;
+    const int tid = threadIdx.x;
+    const size_t b = blockIdx.y;
+    const uint16_t* dg = digits + b * (size_t)nwin * cnt;   // [w][t]
+    for (int i = tid; i < 4 * LV; i += 256) lds[i] = 0;
+    __syncthreads();
+    for (int e = tid; e < nitems; e += 256) {
+        const uint32_t mag = dg[e] & 0x7fffu;
+        if (mag >> h) atomicAdd(&startA[mag >> h], 1u);
+        if (mag & ((1u << h) - 1u)) atomicAdd(&startR[mag & ((1u << h) - 1u)], 1u);
+    }
+    __syncthreads();
+    if (tid < 2) {   // exclusive scans (a few dozen levels)
+        uint32_t* st = tid ? startR : startA;
+        uint32_t* fl = tid ? fillR : fillA;
+        uint32_t run = 0;
+        for (int v = 0; v < LV; v++) {
+            const uint32_t k = st[v];
+            st[v] = run;
+            fl[v] = run;
+            run += k;
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < nitems; e += 256) {
+        const uint32_t d = dg[e], mag = d & 0x7fffu;
+        const uint32_t w = (uint32_t)e / (uint32_t)cnt, t = (uint32_t)e - w * (uint32_t)cnt;
+        const uint32_t ent = (t * (uint32_t)nwin + w) | ((d & 0x8000u) << 16);
+        if (mag >> h) listA[atomicAdd(&fillA[mag >> h], 1u)] = ent;
+        if (mag & ((1u << h) - 1u)) listR[atomicAdd(&fillR[mag & ((1u << h) - 1u)], 1u)] = ent;
+    }
+    __syncthreads();
+    // the scatter order inside a level depends on the atomics: additions commute, the SUM does not depend on it
+    const size_t i = blockIdx.x * (size_t)256 + tid;
+    if (i < m) {
+        Xyzz<P> sums[2];
+#pragma unroll 1
+        for (int pass = 0; pass < 2; pass++) {
+            const uint32_t* st = pass ? startR : startA;
+            const uint32_t* ls = pass ? listR : listA;
+            const int top = pass ? levels_r : levels_a;
+            Xyzz<P> running = xyzz_identity<P>(), total = xyzz_identity<P>();
+            bool any = false;
+#pragma unroll 1
+            for (int v = top; v >= 1; v--) {
+                const uint32_t lo = st[v], hi = st[v + 1];
+                if (lo < hi) {
+                    Xyzz<P> acc = xyzz_identity<P>();
+                    for (uint32_t e = lo; e < hi; e++) {
+                        const uint32_t ent = ls[e], tw = ent & 0x7fffffffu;
+                        const uint32_t t = tw / (uint32_t)nwin, w = tw - t * (uint32_t)nwin;
+                        Affine<P> q = affine_load<P>(table + ((size_t)w * row_stride + (size_t)t * m + i) * 16);
+                        if (!aff_is_id(q)) {
+                            if (ent >> 31) q.y = fe_neg(q.y);
+                            xyzz_madd(acc, q);
+                        }
+                    }
+                    xyzz_add(running, acc);
+                    any = true;
+                }
+                if (any) xyzz_add(total, running);
+            }
+            sums[pass] = total;
+        }
+        Xyzz<P> r = sums[0];
+        for (int k = 0; k < h; k++) r = xyzz_dbl(r);
+        xyzz_add(r, sums[1]);
+        const Affine<P> a = xyzz_to_affine(r);
+        uint32_t* o = out + (b * out_cols + i) * 16;
+        fe_store(o, a.x);
+        fe_store(o + 8, a.y);
+    }
+    if (blockIdx.x == 0 && tid < 32) {   // U, W ride along as the last two columns: 2 x 16 words
+        const int pt = tid >> 4, wd = tid & 15;
+        out[(b * out_cols + m + pt) * 16 + wd] = table[(n_srs + pt) * 16 + wd];
+    }
+}
+
+// Window-table rows 1 .. nwin-1 for npts points whose row 0 is in place (row w = 2^(c w) * row 0, rows npts points apart):
+// one thread per point walks the rows in XYZZ (c doublings each, parked in `scratch` with the running product of the zzz
+// coordinates), inverts that product ONCE and walks back handing every row its own inverse (Montgomery's trick along the
+// rows of a point: no cross-lane traffic), where 1 / zz = (1 / zzz)^2 * zz^2.
+template <class C>
+__global__ void __launch_bounds__(256) k_expand_rows_shared_inverse(uint32_t* __restrict__ table, size_t npts, int c, int nwin,
+                                                                      uint4* __restrict__ scratch) {
+    using P = typename C::Base;
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= npts) return;
+    const Affine<P> p0 = affine_load<P>(table + i * 16);
+    if (aff_is_id(p0)) {
+        for (int w = 1; w < nwin; w++) {
+            uint32_t* o = table + ((size_t)w * npts + i) * 16;
+            fe_store(o, p0.x);
+            fe_store(o + 8, p0.y);
+        }
+        return;
+    }
+    // scratch planes: 10 x uint4 per (row, point): x, y, zz, zzz, prefix
+    const size_t stride = npts * (size_t)(nwin - 1);
+    auto put = [&](int plane, size_t slot, const Fe<P>& v) {
+        scratch[(size_t)(2 * plane) * stride + slot] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+        scratch[(size_t)(2 * plane + 1) * stride + slot] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+    };
+    auto get = [&](int plane, size_t slot) {
+        const uint4 a = scratch[(size_t)(2 * plane) * stride + slot], b = scratch[(size_t)(2 * plane + 1) * stride + slot];
+        Fe<P> v;
+        v.l[0] = a.x, v.l[1] = a.y, v.l[2] = a.z, v.l[3] = a.w, v.l[4] = b.x, v.l[5] = b.y, v.l[6] = b.z, v.l[7] = b.w;
+        return v;
+    };
+    Xyzz<P> q = xyzz_dbl_affine(p0);
+    Fe<P> prefix = fe_one<P>();
+    for (int w = 1; w < nwin; w++) {
+        if (w > 1) q = xyzz_dbl(q);
+        for (int k = 1; k < c; k++) q = xyzz_dbl(q);
+        const size_t slot = (size_t)(w - 1) * npts + i;
+        put(4, slot, prefix);   // product of the zzz of the rows before this one
+        prefix = fe_mul(prefix, q.zzz);
+        put(0, slot, q.x);
+        put(1, slot, q.y);
+        put(2, slot, q.zz);
+        put(3, slot, q.zzz);
+    }
+    Fe<P> inv = fe_inv(prefix);
+    for (int w = nwin - 1; w >= 1; w--) {
+        const size_t slot = (size_t)(w - 1) * npts + i;
+        const Fe<P> zzz = get(3, slot), zz = get(2, slot);
+        const Fe<P> izzz = fe_mul(inv, get(4, slot));
+        inv = fe_mul(inv, zzz);
+        const Fe<P> t = fe_mul(izzz, zz);            // 1 / zz = (zz / zzz)^2
+        const Fe<P> izz = fe_sqr(t);
+        uint32_t* o = table + ((size_t)w * npts + i) * 16;
+        fe_store(o, fe_mul(get(0, slot), izz));
+        fe_store(o + 8, fe_mul(get(1, slot), izzz));
+    }
+}
+
+size_t msm_collapse_scratch_bytes(const bzh_bases* srs, size_t cnt, size_t batch, int c_tail) {
+    const size_t n = srs->n - 2, m = n / cnt, npts = batch * (m + 2);
+    const int nwin_t = (256 + c_tail - 1) / c_tail;
+    return npts * (size_t)(nwin_t - 1) * 160 + batch * cnt * (size_t)srs->pre_nwin * 2 + 4096;
+}
+
+template <class C, class SF>
+static int msm_collapse_table_t(bzh_ctx* ctx, const bzh_bases* srs, const uint32_t* d_s, size_t cnt, size_t batch, int c_tail,
+                                uint32_t* d_table, void* d_scratch, bzh_bases* out) {
+    const size_t n = srs->n - 2, m = n / cnt, cols = m + 2, npts = batch * cols;
+    const int c = srs->pre_c, nwin = srs->pre_nwin, nwin_t = (256 + c_tail - 1) / c_tail;
+    if (!c || cnt < 2 || m * cnt != n || m < 2 || c_tail < 4 || c_tail > 13 || batch > 65535) return BZH_E_ARG;
+    uint16_t* d_digits = (uint16_t*)((char*)d_scratch + npts * (size_t)(nwin_t - 1) * 160);
+    DigitOffset off;
+    for (int k = 0; k < 8; k++) off.l[k] = 0;
+    for (int w = 0; w < nwin - 1; w++) {
+        const int pos = c * w + (c - 1);
+        off.l[pos >> 5] |= 1u << (pos & 31);
+    }
+    const size_t total = batch * cnt;
+    const MsmPair nopair{0, 0, 0};
+    hipLaunchKernelGGL((k_msm_digits<SF>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, d_s, cnt, total,
+                       BZH_FORM_MONTGOMERY, c, nwin, off, d_digits, nopair);
+    {
+        ScopedTimer t(ctx, BZH_T_MSM_ACCUMULATE);
+        const int hh = c / 2, la = 1 << (c - 1 - hh), lr = (1 << hh) - 1, LV = (la > lr ? la : lr) + 2;
+        const size_t lds = ((size_t)4 * LV + 2 * cnt * (size_t)nwin) * 4;
+        if (lds > 60 * 1024) return BZH_E_RANGE;
+        hipLaunchKernelGGL((k_collapse_generators<C>), dim3((unsigned)((m + 255) / 256), (unsigned)batch), dim3(256), lds, ctx->stream,
+                           srs->d_xy, srs->row_stride ? srs->row_stride : srs->n, c, nwin, (const uint16_t*)d_digits, cnt, m, n, d_table,
+                           cols);
+        hipLaunchKernelGGL((k_expand_rows_shared_inverse<C>), dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, ctx->stream, d_table, npts,
+                           c_tail, nwin_t, (uint4*)d_scratch);
+    }
+    BZH_HIP_TRY(ctx, hipGetLastError());
+    *out = bzh_bases();
+    out->curve = srs->curve;
+    out->n = cols;
+    out->d_xy = d_table;
+    out->device = srs->device;
+    out->pre_c = c_tail;
+    out->pre_nwin = nwin_t;
+    out->row_stride = npts;
+    out->vec_col_stride = cols;
+    return BZH_OK;
+}
+
+int msm_collapse_table(bzh_ctx* ctx, const bzh_bases* srs, const uint32_t* d_s, size_t cnt, size_t batch, int c_tail, uint32_t* d_table,
+                       void* d_scratch, bzh_bases* out) {
+    switch (srs->curve) {
+        case BZH_CURVE_VESTA: return msm_collapse_table_t<VestaCurve, FpParams>(ctx, srs, d_s, cnt, batch, c_tail, d_table, d_scratch, out);
+        case BZH_CURVE_PALLAS: return msm_collapse_table_t<PallasCurve, FqParams>(ctx, srs, d_s, cnt, batch, c_tail, d_table, d_scratch, out);
+        case BZH_CURVE_BN254: return msm_collapse_table_t<Bn254Curve, BnFrParams>(ctx, srs, d_s, cnt, batch, c_tail, d_table, d_scratch, out);
+    }
+    return BZH_E_ARG;
 }
 
 }  // namespace bzh

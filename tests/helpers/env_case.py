@@ -43,6 +43,15 @@ def main():
     assert pk.verify_batch(insts, proofs) == [True, True]
     for p in proofs:
         h.update(p)
+    # (c) a batch of 8 (the size from which the opening collapses its generators by itself), fresh trapdoors
+    fleet = {(3, 3), (3, 4), (3, 5), (3, 6), (3, 7), (5, 4), (6, 4), (7, 4), (8, 4), (0, 1), (1, 1), (2, 1), (0, 5), (0, 6), (0, 7), (6, 1), (7, 1)}
+    circuits8 = [Cm.ShotCircuit(state, r.randrange(1 << 250), Cm.shot_serialize([i], [9 - i]), BinaryValue.from_u8(1 if (i, 9 - i) in fleet else 0))
+                 for i in range(8)]
+    adv8, insts8 = lay.synthesize(circuits8)
+    proofs8 = pk.prove_batch(adv8, insts8, None, seeds=[bytes([40 + i]) * 32 for i in range(8)])
+    assert pk.verify_batch(insts8, proofs8) == [True] * 8
+    for p in proofs8:
+        h.update(p)
     print("DIGEST", h.hexdigest())
 
 

@@ -1,6 +1,7 @@
 """The library's tuning knobs and fallback paths (environment variables read once per process) must not change a single
 bit: the global-sort MSM path, other accumulate workgroup / chunk sizes, the quotient VM v1 fallback, no hoisted
-columns, other shared-subexpression slot counts.  Each setting runs tests/helpers/env_case.py in its own process; all digests
+columns, other shared-subexpression slot counts, the interpreted quotient, the LDS-tile NTT kernel, and the opening's
+generator collapse off / forced at several rounds and tail windows.  Each setting runs tests/helpers/env_case.py in its own process; all digests
 (MSM results + the bytes of two real ShotCircuit proofs under fixed seeds) must equal the default's."""
 import os
 import subprocess
@@ -21,12 +22,20 @@ SETTINGS = [
     {"BZH_NO_HOIST": "1"},
     {"BZH_VM2_CSE": "0"},
     {"BZH_VM2_CSE": "6"},
+    {"BZH_QUOTIENT": "interp"},
+    {"BZH_NTT_LDS": "1"},
+    {"BZH_IPA_COLLAPSE": "0"},                              # no generator collapse (the default collapses from batch 8 on)
+    {"BZH_IPA_COLLAPSE": "1"},                              # forced at round 1, also for the 2-proof batch
+    {"BZH_IPA_COLLAPSE": "3", "BZH_IPA_TAIL_C": "7"},
+    {"BZH_IPA_COLLAPSE": "6", "BZH_IPA_TAIL_C": "11"},
+    {"BZH_IPA_COLLAPSE": "9", "BZH_IPA_TAIL_C": "5"},      # m = 4 folded generators
 ]
 
 
 def _digest(extra):
     env = dict(os.environ)
-    for k in ("BZH_MSM_GS", "BZH_ACC_THREADS", "BZH_ACC_CHUNK", "BZH_QUOTIENT_V1", "BZH_NO_HOIST", "BZH_VM2_CSE"):
+    for k in ("BZH_MSM_GS", "BZH_ACC_THREADS", "BZH_ACC_CHUNK", "BZH_QUOTIENT_V1", "BZH_NO_HOIST", "BZH_VM2_CSE", "BZH_QUOTIENT", "BZH_NTT_LDS",
+              "BZH_IPA_COLLAPSE", "BZH_IPA_TAIL_C"):
         env.pop(k, None)
     env.update(extra)
     out = subprocess.run([sys.executable, CASE], env=env, capture_output=True, text=True, timeout=600)
