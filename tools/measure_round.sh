@@ -1,6 +1,7 @@
 #!/bin/bash
-# Round measurements on the GPU box: bench lines, rocprofv3 kernel stats (same commands), into gpurun_out/final/.
+# Round measurements on the GPU box: bench lines, rocprofv3 kernel stats (same commands), PMC traffic, into gpurun_out/final/.
 # Usage (from the repo root, under gpurun): bash tools/measure_round.sh
+# (No compiler runs at measurement time any more: the quotient kernels are inside libbzh2.so.)
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/final
@@ -15,11 +16,15 @@ python3 $R/bench.py --no-cpu-baseline --workload proof_k11 --batch 1 --concurren
 python3 $R/bench.py --no-cpu-baseline --workload proof_k11 --batch 128 --concurrency 8 --steps 8 --warmup 2 > $O/proof_k11_b128c8_bench.json 2> /dev/null && echo k11 done
 python3 $R/bench.py --no-cpu-baseline --workload proof_k12 --batch 64 --concurrency 4 --steps 8 --warmup 2 > $O/proof_k12_b64c4_bench.json 2> /dev/null && echo k12 done
 python3 $R/bench.py --no-cpu-baseline --workload proof_k12 --batch 1 --concurrency 1 --steps 10 --warmup 3 > $O/proof_k12_b1c1_bench.json 2> /dev/null && echo k12 b1 done
+python3 $R/bench.py --no-cpu-baseline --workload proof_k17 --batch 8 --concurrency 4 --steps 4 --warmup 1 > $O/proof_k17_b8c4_bench.json 2> /dev/null && echo k17 done
 python3 $R/bench.py --no-cpu-baseline --workload verify_k14 --batch 64 --steps 5 --warmup 2 > $O/verify_k14_b64_bench.json 2> /dev/null && echo verify done
-python3 $R/bench.py --no-cpu-baseline --workload ntt22 --steps 10 --warmup 2 > $O/ntt22_bench.json 2> /dev/null && echo ntt22 done
-python3 $R/bench.py --no-cpu-baseline --workload msm24 --steps 5 --warmup 2 > $O/msm24_bench.json 2> /dev/null && echo msm24 done
+for cv in vesta pallas bn254; do
+  python3 $R/bench.py --no-cpu-baseline --workload ntt22 --curve $cv --steps 10 --warmup 2 > $O/ntt22_${cv}_bench.json 2> /dev/null && echo ntt22 $cv done
+  python3 $R/bench.py --no-cpu-baseline --workload msm24 --curve $cv --steps 5 --warmup 2 > $O/msm24_${cv}_bench.json 2> /dev/null && echo msm24 $cv done
+done
+python3 $R/bench.py --no-cpu-baseline --workload mixed_board_shot --mix-divisor 4 --steps 3 --warmup 1 > $O/mixed_div4_bench.json 2> /dev/null && echo mixed done
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python3 $R/bench.py --no-cpu-baseline --concurrency 1 --steps 3 --warmup 1 > $O/pmc_fetch.log 2>&1 && echo pmc fetch done
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python3 $R/bench.py --no-cpu-baseline --concurrency 1 --steps 3 --warmup 1 > $O/pmc_write.log 2>&1 && echo pmc write done
 python3 $R/tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write > $O/proof_k14_pmc_traffic.json && rm -rf $O/pmc_fetch $O/pmc_write && echo pmc merged
-(cd $R && bash examples/run_example.sh > $O/example_cpp_client.txt 2>&1; tail -1 $O/example_cpp_client.txt)
+(cd $R && bash examples/run_example.sh 64 3 > $O/example_cpp_client.txt 2>&1; tail -2 $O/example_cpp_client.txt)
 ls $O
