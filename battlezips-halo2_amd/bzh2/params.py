@@ -67,7 +67,7 @@ class Params:
         g, gl = _VP(), _VP()
         L.bzh_params_bases(h, ctypes.byref(g), ctypes.byref(gl))
         self.bases = Bases(ctx, g, CURVE_VESTA, self.n + 2)
-        self.bases_lagrange = Bases(ctx, gl, CURVE_VESTA, self.n + 2)
+        self.bases_lagrange = Bases(ctx, gl, CURVE_VESTA, self.n + 3)    # (g_lagrange | u | w | g_0)
         self._borrowers = []     # weak references to the proving keys built on these tables (they borrow, include/bzh2.h)
 
     def points(self, want_g: bool = True, want_lagrange: bool = True):

@@ -478,13 +478,17 @@ int bzh_params_create(bzh_ctx* ctx, unsigned k, const char* cache_dir, int windo
         }
     }
     p->from_cache = loaded;
-    std::vector<uint64_t> tbl((n + 2) * 8);
+    // (g | u | w) and (g_lagrange | u | w | g_0): sum_r g_lagrange[r] = g_0 (the Lagrange polynomials sum to 1), so a column with
+    // a long constant stretch is committed as (column - c) + c * g_0 -- the grand products of the permutation argument stay at
+    // their final value from the last copy constraint to the blinding rows (csrc/prove.hip: commit, shift_row)
+    std::vector<uint64_t> tbl((n + 3) * 8);
     for (int which = 0; which < 2; which++) {
         memcpy(tbl.data(), which ? p->g_lagrange.data() : p->g.data(), n * 64);
         memcpy(&tbl[n * 8], p->u, 64);
         memcpy(&tbl[(n + 1) * 8], p->w, 64);
+        memcpy(&tbl[(n + 2) * 8], p->g.data(), 64);
         bzh_bases* h = nullptr;
-        int rc = bzh_bases_upload(ctx, BZH_CURVE_VESTA, tbl.data(), n + 2, BZH_FORM_CANONICAL, BZH_MEM_HOST, &h);
+        int rc = bzh_bases_upload(ctx, BZH_CURVE_VESTA, tbl.data(), n + 2 + (which ? 1 : 0), BZH_FORM_CANONICAL, BZH_MEM_HOST, &h);
         if (!rc) rc = bzh_bases_precompute(ctx, h, window_bits);
         if (rc) {
             if (h) bzh_bases_free(ctx, h);

@@ -1,0 +1,690 @@
+// Part of the whole-proof translation unit (csrc/prove.hip): the COMPILER -- circuit expressions as serialised, the evaluator's
+// expression pool (hash-consed DAG), the VM v1 compiler, the VM v2 quotient compiler (y-folding by gate, shared subexpressions,
+// hoisting), the program's hash and its straight-line HIP source, the column registry, the device arena and the blob reader.
+// Host code only.  Included inside namespace bzh { namespace { (prove_kernels.cuh opens them).
+#pragma once
+// ---------------------------------------------------------------------------
+// circuit expressions (as serialised) and evaluator expressions (over a column registry)
+// ---------------------------------------------------------------------------
+enum { CX_CONST = 0, CX_ADVICE = 1, CX_FIXED = 2, CX_INSTANCE = 3, CX_NEG = 4, CX_ADD = 5, CX_MUL = 6, CX_SCALE = 7 };
+struct CNode {
+    uint8_t tag;
+    uint32_t col = 0;
+    int32_t rot = 0;
+    uint32_t val[8] = {0};  // Montgomery
+    int a = -1, b = -1;
+};
+
+enum { EX_CONST, EX_SYMBOL, EX_QUERY, EX_NEG, EX_ADD, EX_MUL, EX_SCALE };
+struct ENode {
+    uint8_t tag;
+    int32_t col = 0, rot = 0;  // EX_QUERY: registry index, rotation; EX_SYMBOL: col = symbol id
+    uint32_t val[8] = {0};
+    int a = -1, b = -1;
+};
+// challenge symbols bound per proof
+enum { SY_THETA, SY_BETA, SY_GAMMA, SY_Y, SY_XN, SY_X1, SY_X2, SY_X4, SY_BD0 /* + permutation column index */ };
+
+struct ConstEnt {
+    int sym = -1;  // >= 0: symbol id, else literal
+    uint32_t val[8] = {0};
+};
+struct Program {
+    std::vector<bzh_expr_op> ops;
+    std::vector<ConstEnt> consts;
+    int result_slot = 0;
+};
+
+struct EPool {
+    std::vector<ENode> n;
+    // hash-consing: structurally equal nodes are one node, so that shared subexpressions of the constraint polynomials
+    // (a gate's selector product, x_q - x_p of the addition gates, ...) show up as shared nodes of a DAG
+    struct NodeKey {
+        uint8_t tag;
+        int32_t col, rot, a, b;
+        uint32_t val[8];
+        bool operator<(const NodeKey& o) const { return memcmp(this, &o, sizeof(NodeKey)) < 0; }
+    };
+    std::map<NodeKey, int> interned;
+    int push(const ENode& e) {
+        NodeKey k;
+        memset(&k, 0, sizeof(k));
+        k.tag = e.tag;
+        k.col = e.col, k.rot = e.rot, k.a = e.a, k.b = e.b;
+        memcpy(k.val, e.val, 32);
+        auto it = interned.find(k);
+        if (it != interned.end()) return it->second;
+        n.push_back(e);
+        interned[k] = (int)n.size() - 1;
+        return (int)n.size() - 1;
+    }
+    template <class F>
+    int cnst(const F& v) {
+        ENode e;
+        e.tag = EX_CONST;
+        memcpy(e.val, v.l, 32);
+        return push(e);
+    }
+    int sym(int id) {
+        ENode e;
+        e.tag = EX_SYMBOL;
+        e.col = id;
+        return push(e);
+    }
+    int query(int col, int rot = 0) {
+        ENode e;
+        e.tag = EX_QUERY;
+        e.col = col;
+        e.rot = rot;
+        return push(e);
+    }
+    int un(uint8_t tag, int a) {
+        ENode e;
+        e.tag = tag;
+        e.a = a;
+        return push(e);
+    }
+    int bin(uint8_t tag, int a, int b) {
+        ENode e;
+        e.tag = tag;
+        e.a = a;
+        e.b = b;
+        return push(e);
+    }
+    int neg(int a) { return un(EX_NEG, a); }
+    int add(int a, int b) { return bin(EX_ADD, a, b); }
+    int sub(int a, int b) { return add(a, neg(b)); }
+    int mul(int a, int b) { return bin(EX_MUL, a, b); }
+    int horner(const std::vector<int>& terms, int ch) {  // ((t0 * ch + t1) * ch + t2) ...
+        int acc = terms[0];
+        for (size_t i = 1; i < terms.size(); i++) acc = add(mul(acc, ch), terms[i]);
+        return acc;
+    }
+};
+
+// Sethi-Ullman ordered emission into at most BZH_EXPR_MAX_SLOTS live intermediates (VM v1; tests/helpers/expr.py
+// compiles the same format for the public bzh_expr_eval entry point); leaves are free operands
+struct Compiler {
+    const EPool& pool;
+    Program prog;
+    std::vector<int> free_slots, depth;
+    bool overflow = false;
+    explicit Compiler(const EPool& p) : pool(p), depth(p.n.size(), -1) {
+        for (int s = BZH_EXPR_MAX_SLOTS - 1; s >= 0; s--) free_slots.push_back(s);
+    }
+    int depth_of(int i) {
+        if (depth[i] >= 0) return depth[i];
+        const ENode& e = pool.n[i];
+        int d;
+        if (e.tag == EX_CONST || e.tag == EX_SYMBOL || e.tag == EX_QUERY) d = 0;
+        else if (e.tag == EX_NEG || e.tag == EX_SCALE) d = std::max(1, depth_of(e.a));
+        else {
+            const int da = depth_of(e.a), db = depth_of(e.b);
+            d = da != db ? std::max(da, db) : da + 1;
+        }
+        return depth[i] = d;
+    }
+    int alloc() {
+        if (free_slots.empty()) {
+            overflow = true;
+            return 0;
+        }
+        const int s = free_slots.back();
+        free_slots.pop_back();
+        return s;
+    }
+    int const_index(int sym, const uint32_t* val) {
+        for (size_t i = 0; i < prog.consts.size(); i++) {
+            const ConstEnt& c = prog.consts[i];
+            if (sym >= 0 ? c.sym == sym : (c.sym < 0 && !memcmp(c.val, val, 32))) return (int)i;
+        }
+        ConstEnt c;
+        c.sym = sym;
+        if (sym < 0) memcpy(c.val, val, 32);
+        prog.consts.push_back(c);
+        return (int)prog.consts.size() - 1;
+    }
+    struct Opnd {
+        int kind, idx, rot, release;
+    };
+    Opnd operand(int i) {
+        const ENode& e = pool.n[i];
+        if (e.tag == EX_CONST) return {BZH_EXPR_CONST, const_index(-1, e.val), 0, -1};
+        if (e.tag == EX_SYMBOL) return {BZH_EXPR_CONST, const_index(e.col, nullptr), 0, -1};
+        if (e.tag == EX_QUERY) return {BZH_EXPR_COLUMN, e.col, e.rot, -1};
+        const int s = emit(i);
+        return {BZH_EXPR_SLOT, s, 0, s};
+    }
+    void push(int op, int dst, const Opnd& a, const Opnd& b) {
+        bzh_expr_op o;
+        o.op = (uint8_t)op;
+        o.dst = (uint8_t)dst;
+        o.a_kind = (uint8_t)a.kind;
+        o.b_kind = (uint8_t)b.kind;
+        o.a_idx = a.idx;
+        o.b_idx = b.idx;
+        o.a_rot = a.rot;
+        o.b_rot = b.rot;
+        prog.ops.push_back(o);
+    }
+    int emit(int i) {
+        const ENode& e = pool.n[i];
+        const Opnd none{BZH_EXPR_SLOT, 0, 0, -1};
+        if (e.tag == EX_CONST || e.tag == EX_SYMBOL || e.tag == EX_QUERY) {
+            const Opnd a = operand(i);
+            const int d = alloc();
+            push(BZH_EXPR_COPY, d, a, none);
+            return d;
+        }
+        if (e.tag == EX_NEG) {
+            const Opnd a = operand(e.a);
+            const int d = a.release >= 0 ? a.release : alloc();
+            push(BZH_EXPR_NEG, d, a, none);
+            return d;
+        }
+        if (e.tag == EX_SCALE) {
+            const Opnd a = operand(e.a);
+            const int d = a.release >= 0 ? a.release : alloc();
+            push(BZH_EXPR_MUL, d, a, Opnd{BZH_EXPR_CONST, const_index(-1, e.val), 0, -1});
+            return d;
+        }
+        // the deeper child first, so that the shallower one never needs more slots than are left
+        Opnd a, b;
+        if (depth_of(e.b) > depth_of(e.a)) {
+            b = operand(e.b);
+            a = operand(e.a);
+        } else {
+            a = operand(e.a);
+            b = operand(e.b);
+        }
+        const int d = a.release >= 0 ? a.release : (b.release >= 0 ? b.release : alloc());
+        push(e.tag == EX_ADD ? BZH_EXPR_ADD : BZH_EXPR_MUL, d, a, b);
+        if (a.release >= 0 && a.release != d) free_slots.push_back(a.release);
+        if (b.release >= 0 && b.release != d) free_slots.push_back(b.release);
+        return d;
+    }
+};
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Compiler2: the quotient's program for VM v2 (csrc/exprvm.hip: four stack registers + an LDS slot file).
+//   value = (sum_j term_j y^(N-1-j)) * t_inv, terms in protocol order.  Consecutive terms of the form S * C_j with the
+//   same S (a gate's constraints under its -- compressed -- selector) are folded as
+//       ACC <- ACC y^m + S (C_0 y^(m-1) + ... + C_(m-1))
+//   so the selector product is evaluated and multiplied in once per gate; inside a gate, subexpressions used more than
+//   once are computed once and parked in LDS slots.  The arithmetic is exact field arithmetic: the value, hence every
+//   proof byte, is the same as the plain Horner fold's.
+// ---------------------------------------------------------------------------------------------------------------
+struct ExprOp2 {  // mirrors csrc/exprvm.hip
+    uint8_t code, a_kind, b_kind, pad;
+    int32_t a_idx, b_idx;
+    int16_t a_rot, b_rot;
+};
+enum { BZH_EXPR_LDS = 3 };
+enum { V2_ADD = 0, V2_SUB = 1, V2_MUL = 2, V2_RSUB = 3 };
+enum { V2_SS = 0, V2_SL = 1, V2_LL = 2, V2_UN = 3, V2_NEG = 0, V2_LOAD = 1, V2_STORE = 2 };
+// LDS slots: 0 ACC, 1 IN, then the shared-subexpression slots, spill slots last (allocated only if a program uses them)
+static constexpr int kV2Regs = 4, kV2LdsAcc = 0, kV2LdsInner = 1, kV2LdsCse0 = 2, kV2LdsCseMax = 8, kV2LdsSpills = 2;
+enum { SY_YPOW0 = 4096 /* + m: y^m */ };
+
+struct Program2 {
+    std::vector<ExprOp2> ops;
+    std::vector<ConstEnt> consts;
+    bool ok = true;
+    int nlds = 2;
+};
+
+// FNV-1a over the instruction words: ties a compiled quotient module to the program it was generated from
+static uint64_t program2_hash(const Program2& pg, int field) {
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](const void* p, size_t n) {
+        for (size_t i = 0; i < n; i++) h = (h ^ ((const uint8_t*)p)[i]) * 1099511628211ull;
+    };
+    mix(&field, sizeof(field));
+    mix(&pg.nlds, sizeof(pg.nlds));
+    for (const ExprOp2& o : pg.ops) {
+        const int32_t w[7] = {o.code, o.a_kind, o.a_idx, o.a_rot, o.b_kind, o.b_idx, o.b_rot};
+        mix(w, sizeof(w));
+    }
+    return h;
+}
+
+// The VM v2 program as straight-line HIP source (compiled by the caller with hipcc / hiprtc against csrc/field.cuh and handed
+// back through bzh_pk_set_quotient_module).  The evaluation stack r0..r3 and the slot file become local values; every memory
+// operand is loaded one instruction ahead of its use and a scheduling barrier follows every instruction -- without it the
+// compiler hoists all ~750 leaf loads to the top (255 VGPRs and scratch); with it 106 VGPRs, four waves per SIMD.  Measured
+// on the BoardCircuit program (1 361 instructions, 16 x 2^17 rows): 9.0 ms against the interpreter's 12.5 ms, same bits.
+// builtin != 0: the flavour linked into libbzh2.so at build time (csrc/gen_quotient.cpp -> quotient_builtin.hip): kernel named
+// after the program hash inside its own namespace, a host launcher, no module-level hash symbol.
+static std::string program2_source(const Program2& pg, int field, bool builtin = false) {
+    std::string src;
+    char buf[512];
+    auto add = [&](const char* fmt, auto... a) {
+        snprintf(buf, sizeof(buf), fmt, a...);
+        src += buf;
+    };
+    const unsigned long long hash = (unsigned long long)program2_hash(pg, field);
+    char kname[64];
+    if (builtin) snprintf(kname, sizeof(kname), "bzh_quotient_%016llx", hash);
+    else snprintf(kname, sizeof(kname), "jit_quotient");
+    add("// generated by libbzh2 (%s): quotient evaluator, %zu instructions\n", builtin ? "bzh_quotient_source_for_circuit" : "bzh_pk_quotient_source",
+        pg.ops.size());
+    if (builtin) add("namespace bzh_q_%016llx {\n", hash);
+    else src += "#include \"field.cuh\"\n";
+    src += "using namespace bzh;\n";
+    add("typedef %s P;\n", field == BZH_FIELD_FQ ? "FqParams" : "FpParams");
+    if (!builtin) add("extern \"C\" __device__ __attribute__((used)) unsigned long long jit_program_hash = 0x%llxull;\n", hash);
+    // measured alternatives, all slower: the multiplication inlined (492 vs 514 proofs/s), barriers after multiplications only
+    // (498), 0 / 4 / 6 shared-subexpression slots instead of 2 (478 / 503 / 505)
+    src += "__device__ __noinline__ Fe<P> mulx(const Fe<P> a, const Fe<P> b) { return fe_mul(a, b); }\n";
+    add("extern \"C\" __global__ void __launch_bounds__(128) %s(const uint32_t* const* __restrict__ cols, ", kname);
+    src += "const size_t* __restrict__ strides, const uint32_t* __restrict__ consts, size_t const_stride, size_t size, "
+           "uint32_t* __restrict__ out) {\n"
+           "    const size_t r = blockIdx.x * (size_t)128 + threadIdx.x, v = blockIdx.y;\n"
+           "    if (r >= size) return;\n"
+           "    const size_t mask = size - 1;\n"
+           "    const uint32_t* cv = consts + v * const_stride * 8;\n"
+           "    Fe<P> r0 = fe_zero<P>(), r1 = r0, r2 = r0, r3 = r0;\n";
+    for (int i = 0; i < std::max(pg.nlds, 1); i++) add("    Fe<P> s%d = r0;\n", i);
+    const size_t nops = pg.ops.size();
+    auto is_mem = [](int kind) { return kind == BZH_EXPR_COLUMN || kind == BZH_EXPR_CONST; };
+    auto emit_load = [&](const char* name, size_t i, int kind, int idx, int rot) {
+        if (kind == BZH_EXPR_COLUMN)
+            add("    const Fe<P> %s%zu = fe_load<P>(cols[%d] + (v * strides[%d] + ((r + (size_t)(long)(%d)) & mask)) * 8);\n", name, i, idx, idx, rot);
+        else if (kind == BZH_EXPR_CONST)
+            add("    const Fe<P> %s%zu = fe_load<P>(cv + %d * 8);\n", name, i, idx);
+    };
+    auto emit_loads = [&](size_t i) {
+        if (i >= nops) return;
+        const ExprOp2& o = pg.ops[i];
+        const int form = o.code >> 4, op = (o.code >> 2) & 3;
+        if (form == V2_LL || (form == V2_UN && op == V2_LOAD)) emit_load("la", i, o.a_kind, o.a_idx, o.a_rot);
+        if (form == V2_SL || form == V2_LL) emit_load("lb", i, o.b_kind, o.b_idx, o.b_rot);
+    };
+    auto operand = [&](const char* name, size_t i, int kind, int idx) -> std::string {
+        char t[32];
+        if (is_mem(kind)) snprintf(t, sizeof(t), "%s%zu", name, i);
+        else snprintf(t, sizeof(t), "s%d", idx);
+        return t;
+    };
+    auto arith = [&](int op, const std::string& a, const std::string& b) -> std::string {
+        switch (op) {
+            case V2_ADD: return "fe_add(" + a + ", " + b + ")";
+            case V2_SUB: return "fe_sub(" + a + ", " + b + ")";
+            case V2_MUL: return "mulx(" + a + ", " + b + ")";
+            default: return "fe_sub(" + b + ", " + a + ")";   // RSUB: b - a
+        }
+    };
+    static const char* const regs[4] = {"r0", "r1", "r2", "r3"};
+    emit_loads(0);
+    for (size_t i = 0; i < nops; i++) {
+        const ExprOp2& o = pg.ops[i];
+        const int form = o.code >> 4, op = (o.code >> 2) & 3, pos = o.code & 3;
+        emit_loads(i + 1);
+        const std::string ra = regs[pos];
+        if (form == V2_SS) {
+            src += "    " + ra + " = " + arith(op, ra, regs[(pos + 1) & 3]) + ";\n";
+        } else if (form == V2_SL) {
+            src += "    " + ra + " = " + arith(op, ra, operand("lb", i, o.b_kind, o.b_idx)) + ";\n";
+        } else if (form == V2_LL) {
+            src += "    " + ra + " = " + arith(op, operand("la", i, o.a_kind, o.a_idx), operand("lb", i, o.b_kind, o.b_idx)) + ";\n";
+        } else if (op == V2_NEG) {
+            src += "    " + ra + " = fe_neg(" + ra + ");\n";
+        } else if (op == V2_LOAD) {
+            src += "    " + ra + " = " + operand("la", i, o.a_kind, o.a_idx) + ";\n";
+        } else {
+            add("    s%d = %s;\n", o.a_idx, ra.c_str());
+        }
+        src += "    __builtin_amdgcn_sched_barrier(0);\n";
+    }
+    src += "    fe_store(out + (v * size + r) * 8, r0);\n}\n";
+    if (builtin) {
+        add("static void launch(unsigned gx, unsigned gy, void* st, const uint32_t* const* cols, const size_t* strides, const uint32_t* consts, "
+            "size_t nc, size_t size, uint32_t* out) {\n    hipLaunchKernelGGL(%s, dim3(gx, gy), dim3(128), 0, (hipStream_t)st, cols, strides, consts, nc, size, out);\n}\n", kname);
+        add("}  // namespace bzh_q_%016llx\n", hash);
+    }
+    return src;
+}
+
+struct Compiler2 {
+    const EPool& pool;
+    Program2 prog;
+    int depth = 0;                       // registers r0..r(depth-1) hold the evaluation stack
+    std::map<int, int> cse;              // node -> LDS slot holding its value (current scope)
+    std::map<int, int> hoisted;          // node -> registry column holding its precomputed values (proof-independent)
+    std::vector<int> label;              // Sethi-Ullman numbers (leaves 0), memoised per scope
+    int spill_used = 0, cse_slots = 2, max_lds = kV2LdsInner;   // measured (k = 14, batch 16): 2 shared-subexpression slots beat 0, 4, 6, 8 -- occupancy matters more than the last 40 multiplications
+    explicit Compiler2(const EPool& p) : pool(p), label(p.n.size(), -1) {
+        if (const char* e = getenv("BZH_VM2_CSE")) cse_slots = std::max(0, std::min(kV2LdsCseMax, atoi(e)));
+    }
+    int nlds() const { return max_lds + 1; }
+
+    struct Leaf {
+        int kind, idx, rot;
+    };
+    int const_index(int sym, const uint32_t* val) {
+        for (size_t i = 0; i < prog.consts.size(); i++) {
+            const ConstEnt& c = prog.consts[i];
+            if (sym >= 0 ? c.sym == sym : (c.sym < 0 && !memcmp(c.val, val, 32))) return (int)i;
+        }
+        ConstEnt c;
+        c.sym = sym;
+        if (sym < 0) memcpy(c.val, val, 32);
+        prog.consts.push_back(c);
+        return (int)prog.consts.size() - 1;
+    }
+    bool is_leaf(int i) const {
+        const ENode& e = pool.n[i];
+        return e.tag == EX_CONST || e.tag == EX_SYMBOL || e.tag == EX_QUERY || cse.count(i) || hoisted.count(i);
+    }
+    Leaf leaf_of(int i) {
+        auto ih = hoisted.find(i);
+        if (ih != hoisted.end()) return {BZH_EXPR_COLUMN, ih->second, 0};
+        auto it = cse.find(i);
+        if (it != cse.end()) return {BZH_EXPR_LDS, it->second, 0};
+        const ENode& e = pool.n[i];
+        if (e.tag == EX_CONST) return {BZH_EXPR_CONST, const_index(-1, e.val), 0};
+        if (e.tag == EX_SYMBOL) return {BZH_EXPR_CONST, const_index(e.col, nullptr), 0};
+        if (e.rot < -32768 || e.rot > 32767) prog.ok = false;
+        return {BZH_EXPR_COLUMN, e.col, e.rot};
+    }
+    int label_of(int i) {
+        if (is_leaf(i)) return 0;
+        if (label[i] >= 0) return label[i];
+        const ENode& e = pool.n[i];
+        int d;
+        if (e.tag == EX_NEG || e.tag == EX_SCALE) d = std::max(1, label_of(e.a));
+        else {
+            const int la = label_of(e.a), lb = label_of(e.b);
+            d = (la == 0 && lb == 0) ? 1 : (la == lb ? la + 1 : std::max(la, lb));
+        }
+        return label[i] = d;
+    }
+    void op(int form, int o, int pos, Leaf a = {0, 0, 0}, Leaf b = {0, 0, 0}) {
+        if (pos < 0 || pos >= kV2Regs) prog.ok = false;
+        ExprOp2 x;
+        x.code = (uint8_t)((form << 4) | (o << 2) | (pos & 3));
+        x.a_kind = (uint8_t)a.kind, x.b_kind = (uint8_t)b.kind, x.pad = 0;
+        x.a_idx = a.idx, x.b_idx = b.idx;
+        x.a_rot = (int16_t)a.rot, x.b_rot = (int16_t)b.rot;
+        prog.ops.push_back(x);
+    }
+    // a - b is add(a, neg(b)) in the pool: peel the negation so that it costs no instruction
+    bool is_plain_neg(int i) const { return pool.n[i].tag == EX_NEG && !cse.count(i); }
+
+    // emit node i: its value ends up in a new top-of-stack register
+    void emit(int i) {
+        if (is_leaf(i)) {
+            op(V2_UN, V2_LOAD, depth, leaf_of(i));
+            depth++;
+            return;
+        }
+        const ENode& e = pool.n[i];
+        if (e.tag == EX_NEG) {
+            emit(e.a);
+            op(V2_UN, V2_NEG, depth - 1);
+        } else if (e.tag == EX_SCALE) {
+            const Leaf c{BZH_EXPR_CONST, const_index(-1, e.val), 0};
+            if (is_leaf(e.a)) {
+                op(V2_LL, V2_MUL, depth, leaf_of(e.a), c);
+                depth++;
+            } else {
+                emit(e.a);
+                op(V2_SL, V2_MUL, depth - 1, Leaf{0, 0, 0}, c);
+            }
+        } else {
+            int a = e.a, b = e.b, o = e.tag == EX_ADD ? V2_ADD : V2_MUL;
+            if (e.tag == EX_ADD) {   // a + (-b') = a - b' ; (-a') + b = b - a'
+                if (is_plain_neg(b)) b = pool.n[b].a, o = V2_SUB;
+                else if (is_plain_neg(a)) {
+                    const int t = pool.n[a].a;
+                    a = b, b = t, o = V2_SUB;
+                }
+            }
+            binary(o, a, b);
+        }
+        park(i);
+    }
+    void binary(int o, int a, int b) {
+        const bool la = is_leaf(a), lb = is_leaf(b);
+        const int rev = o == V2_SUB ? V2_RSUB : o;   // operands swapped
+        if (la && lb) {
+            op(V2_LL, o, depth, leaf_of(a), leaf_of(b));
+            depth++;
+        } else if (lb) {
+            emit(a);
+            op(V2_SL, o, depth - 1, Leaf{0, 0, 0}, leaf_of(b));
+        } else if (la) {
+            emit(b);
+            op(V2_SL, rev, depth - 1, Leaf{0, 0, 0}, leaf_of(a));
+        } else {
+            const int na = label_of(a), nb = label_of(b);
+            const bool a_first = na >= nb;
+            const int first = a_first ? a : b, second = a_first ? b : a;
+            emit(first);
+            if (depth + std::max(1, label_of(second)) > kV2Regs) {
+                // not enough registers for the other side: park this one in a spill slot and use it as a leaf
+                if (spill_used >= kV2LdsSpills) {
+                    prog.ok = false;
+                    return;
+                }
+                const int sl = kV2LdsCse0 + cse_slots + spill_used++;
+                max_lds = std::max(max_lds, sl);
+                op(V2_UN, V2_STORE, depth - 1, Leaf{BZH_EXPR_LDS, sl, 0});
+                depth--;
+                emit(second);
+                op(V2_SL, a_first ? rev : o, depth - 1, Leaf{0, 0, 0}, Leaf{BZH_EXPR_LDS, sl, 0});
+                spill_used--;
+            } else {
+                emit(second);
+                op(V2_SS, a_first ? o : rev, depth - 2);
+                depth--;
+            }
+        }
+    }
+    // shared subexpression bookkeeping for the current scope
+    std::map<int, int> want;   // node -> LDS slot it is to be parked in after its first evaluation
+    void park(int i) {
+        auto it = want.find(i);
+        if (it == want.end() || cse.count(i)) return;
+        op(V2_UN, V2_STORE, depth - 1, Leaf{BZH_EXPR_LDS, it->second, 0});
+        cse[i] = it->second;
+        std::fill(label.begin(), label.end(), -1);   // nodes above it are cheaper to reach now
+    }
+    void count_uses(int i, std::map<int, int>& uses, std::map<int, int>& weight) {
+        const ENode& e = pool.n[i];
+        if (e.tag == EX_CONST || e.tag == EX_SYMBOL || e.tag == EX_QUERY || hoisted.count(i)) return;
+        if (uses[i]++) return;
+        int w = 1;
+        if (e.a >= 0) {
+            count_uses(e.a, uses, weight);
+            w += weight.count(e.a) ? weight[e.a] : 0;
+        }
+        if (e.b >= 0) {
+            count_uses(e.b, uses, weight);
+            w += weight.count(e.b) ? weight[e.b] : 0;
+        }
+        weight[i] = w;
+    }
+    void open_scope(const std::vector<int>& roots) {
+        cse.clear();
+        want.clear();
+        std::fill(label.begin(), label.end(), -1);
+        std::map<int, int> uses, weight;
+        for (int r : roots) count_uses(r, uses, weight);
+        std::vector<std::pair<long, int>> cand;
+        for (auto& kv : uses) {
+            if (kv.second >= 2) cand.push_back({-(long)(kv.second - 1) * weight[kv.first], kv.first});
+        }
+        std::sort(cand.begin(), cand.end());
+        for (size_t k = 0; k < cand.size() && k < (size_t)cse_slots; k++) {
+            want[cand[k].second] = kV2LdsCse0 + (int)k;
+            max_lds = std::max(max_lds, kV2LdsCse0 + (int)k);
+        }
+    }
+
+    // the whole quotient: terms in protocol order, y = symbol SY_Y, result (times t_inv) in r0
+    void quotient(const std::vector<int>& terms, int tinv_node) {
+        struct Group {
+            int s;                  // shared left factor (-1: none)
+            std::vector<int> c;     // the other factors, or the whole terms
+        };
+        std::vector<Group> groups;
+        for (int t : terms) {
+            const ENode& e = pool.n[t];
+            const int s = (e.tag == EX_MUL) ? e.a : -1;
+            if (s >= 0 && !groups.empty() && groups.back().s == s) groups.back().c.push_back(e.b);
+            else groups.push_back(Group{s, {s >= 0 ? e.b : t}});
+        }
+        const Leaf y{BZH_EXPR_CONST, const_index(SY_Y, nullptr), 0};
+        const Leaf acc{BZH_EXPR_LDS, kV2LdsAcc, 0}, inner{BZH_EXPR_LDS, kV2LdsInner, 0};
+        bool first_group = true;
+        for (auto& g : groups) {
+            std::vector<int> roots = g.c;
+            if (g.s >= 0) roots.push_back(g.s);
+            open_scope(roots);
+            const size_t m = g.c.size();
+            if (m > 64) prog.ok = false;   // y^m symbols are provided up to 64
+            for (size_t j = 0; j < m; j++) {
+                depth = 0;
+                if (j == 0) {
+                    emit(g.c[0]);
+                } else if (label_of(g.c[j]) < kV2Regs) {
+                    op(V2_LL, V2_MUL, 0, inner, y);          // r0 = IN y
+                    depth = 1;
+                    emit(g.c[j]);                            // r1 = C_j
+                    op(V2_SS, V2_ADD, 0);
+                    depth = 1;
+                } else {
+                    emit(g.c[j]);                            // r0 = C_j (needs every register)
+                    op(V2_LL, V2_MUL, 1, inner, y);          // r1 = IN y
+                    op(V2_SS, V2_ADD, 0);
+                }
+                if (j + 1 < m) op(V2_UN, V2_STORE, 0, inner);
+            }
+            // r0 = sum_j C_j y^(m-1-j); times the shared factor
+            if (g.s >= 0) {
+                if (is_leaf(g.s)) {
+                    op(V2_SL, V2_MUL, 0, Leaf{0, 0, 0}, leaf_of(g.s));
+                } else if (label_of(g.s) < kV2Regs) {
+                    depth = 1;
+                    emit(g.s);
+                    op(V2_SS, V2_MUL, 0);
+                } else {
+                    op(V2_UN, V2_STORE, 0, inner);
+                    depth = 0;
+                    emit(g.s);
+                    op(V2_SL, V2_MUL, 0, Leaf{0, 0, 0}, inner);
+                }
+            }
+            if (!first_group) {                              // ACC = ACC y^m + r0
+                const Leaf ym{BZH_EXPR_CONST, const_index(m == 1 ? SY_Y : SY_YPOW0 + (int)m, nullptr), 0};
+                op(V2_LL, V2_MUL, 1, acc, ym);
+                op(V2_SS, V2_ADD, 0);
+            }
+            op(V2_UN, V2_STORE, 0, acc);
+            first_group = false;
+        }
+        cse.clear();
+        want.clear();
+        op(V2_SL, V2_MUL, 0, Leaf{0, 0, 0}, leaf_of(tinv_node));
+    }
+};
+
+// column registry of one batched evaluation: (device pointer, elements between consecutive proofs; 0 = shared)
+struct Cols {
+    std::vector<const uint32_t*> ptr;
+    std::vector<size_t> stride;
+    std::map<uint64_t, int> index;
+    int add(uint64_t key, const uint32_t* p, size_t s) {
+        auto it = index.find(key);
+        if (it != index.end()) return it->second;
+        const int i = (int)ptr.size();
+        index[key] = i;
+        ptr.push_back(p);
+        stride.push_back(s);
+        return i;
+    }
+    int at(uint64_t key) const { return index.at(key); }
+};
+// registry keys
+enum { K_ADV = 1, K_FIX, K_INST, K_SIGMA, K_IDENT, K_PZ, K_LA, K_LS, K_LZ, K_MISC };
+enum { M_L0, M_LLAST, M_LBLIND, M_X, M_TINV, M_AC, M_SC, M_A, M_S, M_ACC, M_Q, M_R, M_F, M_H0 /* + i */ };
+static inline uint64_t key(int kind, uint64_t i) { return ((uint64_t)kind << 32) | i; }
+
+// device arena: grow-only blocks, reset at the start of every call
+struct Arena {
+    struct Block {
+        char* p;
+        size_t size, used;
+    };
+    std::vector<Block> blocks;
+    int device = 0;
+    size_t requested = 0;  // bytes handed out since the last reset
+    // A call's allocation sequence is deterministic, so after the first call of a given shape the arena is ONE block
+    // that every later call bumps through without touching hipMalloc (overflow blocks are merged at the next reset).
+    void reset() {
+        if (blocks.size() > 1) {
+            const size_t want = requested + (requested >> 4) + ((size_t)1 << 20);
+            release();
+            Block nb;
+            nb.size = want;
+            nb.used = 0;
+            if (hipMalloc((void**)&nb.p, nb.size) == hipSuccess) blocks.push_back(nb);
+        }
+        for (auto& b : blocks) b.used = 0;
+        requested = 0;
+    }
+    void release() {
+        for (auto& b : blocks) (void)hipFree(b.p);
+        blocks.clear();
+    }
+    void* alloc(size_t bytes) {
+        bytes = (bytes + 255) & ~(size_t)255;
+        requested += bytes;
+        for (auto& b : blocks)
+            if (b.size - b.used >= bytes) {
+                void* r = b.p + b.used;
+                b.used += bytes;
+                return r;
+            }
+        Block nb;
+        nb.size = std::max(bytes, (size_t)256 << 20);
+        if (hipMalloc((void**)&nb.p, nb.size) != hipSuccess) return nullptr;
+        nb.used = bytes;
+        blocks.push_back(nb);
+        return nb.p;
+    }
+};
+
+struct Reader {
+    const uint8_t* p;
+    const uint8_t* end;
+    bool ok = true;
+    uint32_t u32() {
+        if (end - p < 4) {
+            ok = false;
+            return 0;
+        }
+        uint32_t v;
+        memcpy(&v, p, 4);
+        p += 4;
+        return v;
+    }
+    uint8_t u8() {
+        if (end - p < 1) {
+            ok = false;
+            return 0;
+        }
+        return *p++;
+    }
+    const uint8_t* bytes(size_t n) {
+        if ((size_t)(end - p) < n) {
+            ok = false;
+            return nullptr;
+        }
+        const uint8_t* r = p;
+        p += n;
+        return r;
+    }
+};
