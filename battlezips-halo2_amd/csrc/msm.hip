@@ -1322,7 +1322,8 @@ int bases_to_montgomery(bzh_ctx* ctx, int curve, uint32_t* d_xy, size_t n) {
 template <class C>
 __global__ void __launch_bounds__(256) k_collapse_generators(const uint32_t* __restrict__ table, size_t row_stride, int c, int nwin,
                                                                const uint16_t* __restrict__ digits, size_t cnt, size_t m, size_t n_srs,
-                                                               uint32_t* __restrict__ out, size_t out_cols) {
+                                                               uint32_t* __restrict__ out, size_t out_cols,
+                                                               unsigned long long* __restrict__ add_counter) {
     using P = typename C::Base;
     extern __shared__ __align__(16) uint32_t lds[];
     const int h = c / 2;                         // |D| <= 2^(c-1) = a * 2^h + r, a <= 2^(c-1-h), r < 2^h
@@ -1367,6 +1368,10 @@ __global__ void __launch_bounds__(256) k_collapse_generators(const uint32_t* __r
     __syncthreads();
     // the scatter order inside a level depends on the atomics: additions commute, the SUM does not depend on it
     const size_t i = blockIdx.x * (size_t)256 + tid;
+    if (add_counter && tid == 0) {   // profiling: mixed additions of this workgroup's outputs (both passes)
+        const size_t live = min((size_t)256, m - min(m, blockIdx.x * (size_t)256));
+        atomicAdd(add_counter, (unsigned long long)(fillA[LV - 1] + fillR[LV - 1]) * live);
+    }
     if (i < m) {
         Xyzz<P> sums[2];
 #pragma unroll 1
@@ -1499,7 +1504,7 @@ static int msm_collapse_table_t(bzh_ctx* ctx, const bzh_bases* srs, const uint32
         if (lds > 60 * 1024) return BZH_E_RANGE;
         hipLaunchKernelGGL((k_collapse_generators<C>), dim3((unsigned)((m + 255) / 256), (unsigned)batch), dim3(256), lds, ctx->stream,
                            srs->d_xy, srs->row_stride ? srs->row_stride : srs->n, c, nwin, (const uint16_t*)d_digits, cnt, m, n, d_table,
-                           cols);
+                           cols, ctx->profiling ? ctx->d_add_counter : nullptr);
         hipLaunchKernelGGL((k_expand_rows_shared_inverse<C>), dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, ctx->stream, d_table, npts,
                            c_tail, nwin_t, (uint4*)d_scratch);
     }

@@ -819,7 +819,7 @@ def main():
             # bytes the library counted per launch (bzh_ctx_work) over the same launches
             dom_ms = acc["ms"] / max(acc["launches"], 1)
             alg = acc["algorithmic_bytes"] / max(acc["launches"], 1)
-            dom_name = "k_msm_accumulate (mean over the %d launches of one step)" % (acc["launches"] // max(args.steps, 1))
+            dom_name = "k_msm_accumulate (mean over the launches of a proof batch: commitments, opening rounds before and after the generator collapse)"
             wl.alg_bytes_step = (acc["algorithmic_bytes"] + nt["algorithmic_bytes"] + qt["algorithmic_bytes"]) / max(args.steps, 1)
         else:
             dom_ms = acc["ms"] / max(acc["launches"], 1)
@@ -843,7 +843,7 @@ def main():
         # separate runs of this same command), if one exists for this workload and kernel
         traffic, traffic_src = None, None
         want_kernel = qname if dom_name.startswith(qname) else "k_msm_accumulate"
-        for tag in ("r02", "r01_h", "r01_e"):
+        for tag in ("r03", "r02", "r01_h", "r01_e"):
             tj = os.path.join(ROOT, "profiles", "%s_%s_pmc_traffic.json" % (tag, args.workload))
             if traffic is not None or not os.path.exists(tj) or args.workload == "ntt22":
                 continue
@@ -859,7 +859,7 @@ def main():
                 if launches:
                     traffic = tot / launches
                     traffic_src = os.path.relpath(tj, ROOT) + (" (real circuit, one default-size batch in flight; mean over %d launches)" % launches
-                                                               if tag == "r02" else " (round-1 synthetic circuit: stale for the real one)")
+                                                               if tag in ("r03", "r02") else " (round-1 synthetic circuit: stale for the real one)")
             except Exception:
                 traffic = None
         line = {
