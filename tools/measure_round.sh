@@ -16,7 +16,7 @@ python3 $R/bench.py --no-cpu-baseline --workload proof_k11 --batch 1 --concurren
 python3 $R/bench.py --no-cpu-baseline --workload proof_k11 --batch 128 --concurrency 8 --steps 8 --warmup 2 > $O/proof_k11_b128c8_bench.json 2> /dev/null && echo k11 done
 python3 $R/bench.py --no-cpu-baseline --workload proof_k12 --batch 64 --concurrency 4 --steps 8 --warmup 2 > $O/proof_k12_b64c4_bench.json 2> /dev/null && echo k12 done
 python3 $R/bench.py --no-cpu-baseline --workload proof_k12 --batch 1 --concurrency 1 --steps 10 --warmup 3 > $O/proof_k12_b1c1_bench.json 2> /dev/null && echo k12 b1 done
-python3 $R/bench.py --no-cpu-baseline --workload proof_k17 --batch 8 --concurrency 4 --steps 4 --warmup 1 > $O/proof_k17_b8c4_bench.json 2> /dev/null && echo k17 done
+python3 $R/bench.py --no-cpu-baseline --workload proof_k17 --batch 8 --concurrency 4 --steps 4 --warmup 2 > $O/proof_k17_b8c4_bench.json 2> /dev/null && echo k17 done
 python3 $R/bench.py --no-cpu-baseline --workload verify_k14 --batch 64 --steps 5 --warmup 2 > $O/verify_k14_b64_bench.json 2> /dev/null && echo verify done
 for cv in vesta pallas bn254; do
   python3 $R/bench.py --no-cpu-baseline --workload ntt22 --curve $cv --steps 10 --warmup 2 > $O/ntt22_${cv}_bench.json 2> /dev/null && echo ntt22 $cv done
