@@ -16,7 +16,7 @@ def pytest_configure(config):
     lib = os.path.join(ROOT, "battlezips-halo2_amd", "libbzh2.so")
     if not os.path.exists(lib):
         import subprocess
-        subprocess.call(["make", "-C", os.path.join(ROOT, "battlezips-halo2_amd", "csrc"), "-j4", "ARCH=gfx950"],
+        subprocess.call(["make", "-C", os.path.join(ROOT, "battlezips-halo2_amd", "csrc"), "-j8", "ARCH=gfx950"],
                         stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 
 
