@@ -198,6 +198,83 @@ BZH_HD void xyzz_add_inl(Xyzz<P>& acc, const Xyzz<P>& q) {
     acc = xyzz_add_impl_inl(acc, q);
 }
 
+// ---------------------------------------------------------------------------
+// acc += q with the FOUR lanes of a quad working on ONE addition (latency mode).  A wave64 issues one VALU instruction per
+// four cycles whatever its lanes hold, so a dependent chain of additions on one wave costs ~3 700 issue slots per addition
+// (6-8 us): the bucket reductions and final sums of a single proof are such chains.  Here every lane of a quad holds the same
+// acc and q, computes ONE of the (up to four) independent products of each of the addition's four dependency levels and gets
+// the others by quad broadcasts (DPP quad_perm, no LDS): 4 multiplications + ~190 selects + ~120 broadcasts per lane instead
+// of 14 multiplications -- ~2.5 x shorter chains for a quarter of the lanes.  All four lanes return the same result.
+// ---------------------------------------------------------------------------
+template <class P>
+__device__ __forceinline__ Fe<P> fe_quad_bcast(const Fe<P>& v, int k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    Fe<P> o;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        o.l[i] = k == 0   ? (uint32_t)__builtin_amdgcn_mov_dpp((int)v.l[i], 0x00, 0xf, 0xf, true)
+                 : k == 1 ? (uint32_t)__builtin_amdgcn_mov_dpp((int)v.l[i], 0x55, 0xf, 0xf, true)
+                 : k == 2 ? (uint32_t)__builtin_amdgcn_mov_dpp((int)v.l[i], 0xaa, 0xf, 0xf, true)
+                          : (uint32_t)__builtin_amdgcn_mov_dpp((int)v.l[i], 0xff, 0xf, 0xf, true);
+    }
+    return o;
+#else
+    return v;   // (host pass of the compiler: never executed)
+#endif
+}
+// operand of quad lane ql out of four candidates, by lane masks (m[k] = all ones in lane k of the quad): a chain of `?:` on the
+// lane index is turned into a table in scratch memory by the compiler -- 64 scratch round trips per addition
+struct QuadMasks {
+    uint32_t m0, m1, m2, m3;
+};
+__device__ __forceinline__ QuadMasks quad_masks(int ql) {
+    QuadMasks q;
+    q.m0 = ql == 0 ? 0xffffffffu : 0u;
+    q.m1 = ql == 1 ? 0xffffffffu : 0u;
+    q.m2 = ql == 2 ? 0xffffffffu : 0u;
+    q.m3 = ql == 3 ? 0xffffffffu : 0u;
+    return q;
+}
+template <class P>
+__device__ __forceinline__ Fe<P> fe_sel4(const QuadMasks& q, const Fe<P>& a0, const Fe<P>& a1, const Fe<P>& a2, const Fe<P>& a3) {
+    Fe<P> o;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o.l[i] = (a0.l[i] & q.m0) | (a1.l[i] & q.m1) | (a2.l[i] & q.m2) | (a3.l[i] & q.m3);
+    return o;
+}
+template <class P>
+__device__ __forceinline__ void xyzz_add_quad(Xyzz<P>& acc, const Xyzz<P>& q, int ql) {
+    if (xyzz_is_id(q)) return;            // (the same data in all four lanes: uniform inside the quad)
+    if (xyzz_is_id(acc)) {
+        acc = q;
+        return;
+    }
+    const QuadMasks qm = quad_masks(ql);
+    // level 1: u1 = x1 zz2, u2 = x2 zz1, s1 = y1 zzz2, s2 = y2 zzz1
+    Fe<P> t = fe_mul(fe_sel4(qm, acc.x, q.x, acc.y, q.y), fe_sel4(qm, q.zz, acc.zz, q.zzz, acc.zzz));
+    const Fe<P> u1 = fe_quad_bcast(t, 0), u2 = fe_quad_bcast(t, 1), s1 = fe_quad_bcast(t, 2), s2 = fe_quad_bcast(t, 3);
+    const Fe<P> pp_ = fe_sub(u2, u1), r = fe_sub(s2, s1);
+    if (fe_is_zero(pp_)) {                // same x: doubling or the inverse -- rare, all four lanes take the plain path
+        if (fe_is_zero(r)) acc = xyzz_dbl(acc);
+        else acc = xyzz_identity<P>();
+        return;
+    }
+    // level 2: pp = P^2, rr = R^2, zz12 = zz1 zz2, zzz12 = zzz1 zzz2
+    t = fe_mul(fe_sel4(qm, pp_, r, acc.zz, acc.zzz), fe_sel4(qm, pp_, r, q.zz, q.zzz));
+    const Fe<P> pp = fe_quad_bcast(t, 0), rr = fe_quad_bcast(t, 1), zz12 = fe_quad_bcast(t, 2), zzz12 = fe_quad_bcast(t, 3);
+    // level 3: ppp = P pp, qq = u1 pp, zz3 = zz12 pp   (lane 3 repeats lane 0's product)
+    t = fe_mul(fe_sel4(qm, pp_, u1, zz12, pp_), pp);
+    const Fe<P> ppp = fe_quad_bcast(t, 0), qq = fe_quad_bcast(t, 1), zz3 = fe_quad_bcast(t, 2);
+    const Fe<P> x3 = fe_sub(fe_sub(rr, ppp), fe_dbl(qq));
+    // level 4: a = R (qq - x3), b = s1 ppp, zzz3 = zzz12 ppp
+    t = fe_mul(fe_sel4(qm, r, s1, zzz12, s1), fe_sel4(qm, fe_sub(qq, x3), ppp, ppp, ppp));
+    const Fe<P> ya = fe_quad_bcast(t, 0), yb = fe_quad_bcast(t, 1), zzz3 = fe_quad_bcast(t, 2);
+    acc.x = x3;
+    acc.y = fe_sub(ya, yb);
+    acc.zz = zz3;
+    acc.zzz = zzz3;
+}
+
 // XYZZ -> Jacobian (X:Y:Z) with x = X/Z^2, y = Y/Z^3: Z = ZZZ/ZZ would need an
 // inversion; instead scale: X' = X*ZZ... use (X*ZZZ^2... ) -- simplest exact
 // map without inversion: Z = ZZZ * ZZ^-1 is avoided by X' = X * ZZ, Y' = Y * ZZZ,

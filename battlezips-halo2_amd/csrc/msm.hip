@@ -568,6 +568,146 @@ __global__ void __launch_bounds__(64) k_msm_reduce_wave(const uint4* __restrict_
 }
 
 // ---------------------------------------------------------------------------
+// Latency mode (a handful of segments: a single proof's MSMs).  The same reduction with FOUR lanes per logical lane
+// (xyzz_add_quad, csrc/curve.cuh): 16 logical lanes per wave, lane t owns L = M/16 buckets, the suffix scan and the final sum
+// run over 4 + 4 shuffle steps of 4 * d lanes.  2L + 8 quad additions of ~1 500 issue slots instead of 2(M/64) + 12 of ~3 700.
+// ---------------------------------------------------------------------------
+template <class C>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) k_msm_reduce_quad(const uint4* __restrict__ buckets, int M, int nclass, size_t spv,
+                                                         size_t aseg_mult, uint4* __restrict__ winsums, int form,
+                                                         uint32_t* __restrict__ out_xyz) {
+    using P = typename C::Base;
+    const int lane = threadIdx.x, ll = lane >> 2, ql = lane & 3;
+    const size_t aseg = blockIdx.x / nclass, cls = blockIdx.x - aseg * nclass, MS = (size_t)M * nclass;
+    const size_t segi = ((aseg / spv) * nclass + cls) * spv + aseg % spv;
+    const uint4* seg = buckets + aseg * aseg_mult * MS * 8 + cls * M;
+    const int L = M >> 4;  // host guarantees M >= 16, a power of two
+
+    Xyzz<P> S = xyzz_identity<P>(), W = xyzz_identity<P>();
+    for (int k = L; k >= 1; k--) {
+        const Xyzz<P> bkt = planes_get<P>(seg, MS, (size_t)(ll * L + k - 1));   // the four lanes of a quad read the same bucket
+        xyzz_add_quad(S, bkt, ql);
+        xyzz_add_quad(W, S, ql);
+    }
+    Xyzz<P> suf = S;
+#pragma unroll 1
+    for (int d = 1; d < 16; d <<= 1) {
+        const Xyzz<P> o = xyzz_shfl_down(suf, 4 * d);
+        if (ll + d < 16) xyzz_add_quad(suf, o, ql);
+    }
+    if (ll >= 1) {
+        for (int k = L; k > 1; k >>= 1) suf = xyzz_dbl_inl(suf);
+        xyzz_add_quad(W, suf, ql);
+    }
+#pragma unroll 1
+    for (int d = 8; d >= 1; d >>= 1) {
+        const Xyzz<P> o = xyzz_shfl_down(W, 4 * d);
+        if (ll < d) xyzz_add_quad(W, o, ql);
+    }
+    if (lane == 0) reduce_emit<P>(W, winsums, (size_t)gridDim.x, segi, form, out_xyz);
+}
+
+// The same with a whole workgroup: 256 threads = 64 logical lanes (lt = tid / 4), L = M/64 buckets each; the suffix scan and
+// the final tree run over LDS planes written by lane 0 of every quad (2 * T_l * 128 B of dynamic LDS): 2L + 12 quad additions.
+template <class P>
+__device__ __forceinline__ Xyzz<P> block_tree_sum_quad(Xyzz<P> v, uint4* buf, int TL, int lt, int ql) {
+    for (int s = TL >> 1; s >= 1; s >>= 1) {
+        __syncthreads();
+        if (lt >= s && lt < 2 * s && ql == 0) planes_put(buf, (size_t)TL, (size_t)lt, v);
+        __syncthreads();
+        if (lt < s) {
+            const Xyzz<P> o = planes_get<P>(buf, (size_t)TL, (size_t)(lt + s));
+            xyzz_add_quad(v, o, ql);
+        }
+    }
+    return v;  // valid in logical lane 0
+}
+template <class C>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) k_msm_reduce_quad_wg(
+    const uint4* __restrict__ buckets, int M, int nclass, size_t spv, size_t aseg_mult, uint4* __restrict__ winsums, int form,
+    uint32_t* __restrict__ out_xyz) {
+    using P = typename C::Base;
+    extern __shared__ __align__(16) uint32_t lds[];
+    const int tid = threadIdx.x, lt = tid >> 2, ql = tid & 3, TL = blockDim.x >> 2;
+    uint4* bufA = reinterpret_cast<uint4*>(lds);
+    uint4* bufB = bufA + (size_t)TL * 8;
+    const size_t aseg = blockIdx.x / nclass, cls = blockIdx.x - aseg * nclass, MS = (size_t)M * nclass;
+    const size_t segi = ((aseg / spv) * nclass + cls) * spv + aseg % spv;
+    const uint4* seg = buckets + aseg * aseg_mult * MS * 8 + cls * M;
+    const int L = M / TL;  // host guarantees TL <= M, both powers of two
+
+    Xyzz<P> S = xyzz_identity<P>(), W = xyzz_identity<P>();
+    for (int k = L; k >= 1; k--) {
+        const Xyzz<P> bkt = planes_get<P>(seg, MS, (size_t)(lt * L + k - 1));
+        xyzz_add_quad(S, bkt, ql);
+        xyzz_add_quad(W, S, ql);
+    }
+    Xyzz<P> suf = S;
+    uint4* cur = bufA;
+    uint4* nxt = bufB;
+    for (int d = 1; d < TL; d <<= 1) {
+        if (ql == 0) planes_put(cur, (size_t)TL, (size_t)lt, suf);
+        __syncthreads();
+        if (lt + d < TL) {
+            const Xyzz<P> o = planes_get<P>(cur, (size_t)TL, (size_t)(lt + d));
+            xyzz_add_quad(suf, o, ql);
+        }
+        uint4* tmp = cur;
+        cur = nxt;
+        nxt = tmp;
+    }
+    if (lt >= 1) {
+        for (int k = L; k > 1; k >>= 1) suf = xyzz_dbl_inl(suf);
+        xyzz_add_quad(W, suf, ql);
+    }
+    const Xyzz<P> lo = block_tree_sum_quad(W, bufA, TL, lt, ql);
+    if (tid == 0) reduce_emit<P>(lo, winsums, (size_t)gridDim.x, segi, form, out_xyz);
+}
+
+// k_msm_finalize in latency mode: per window the chunk results are summed by 64 logical lanes (quads of a 256-thread
+// workgroup) and a 6-step LDS tree; the Horner pass over the windows runs on quad 0.
+template <class C>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) k_msm_finalize_quad(
+    const uint4* __restrict__ winsums, size_t nseg, int nwin, size_t nchunks, int c, int form, uint32_t* __restrict__ out_xyz) {
+    using P = typename C::Base;
+    __shared__ __align__(16) uint4 buf[64 * 8];
+    __shared__ __align__(16) uint4 wbuf[64 * 8];  // per-window sums, nwin <= 64
+    const int tid = threadIdx.x, lt = tid >> 2, ql = tid & 3;   // 64 logical lanes
+    const size_t b = blockIdx.x;
+    for (int w = 0; w < nwin; w++) {
+        Xyzz<P> acc = xyzz_identity<P>();
+        for (size_t ck = lt; ck < nchunks; ck += 64) {
+            const Xyzz<P> v = planes_get<P>(winsums, nseg, (b * (size_t)nwin + w) * nchunks + ck);
+            xyzz_add_quad(acc, v, ql);
+        }
+        if (nchunks > 1) acc = block_tree_sum_quad(acc, buf, 64, lt, ql);
+        if (tid == 0) planes_put(wbuf, 64, (size_t)w, acc);
+    }
+    __syncthreads();
+    if (lt == 0) {
+        Xyzz<P> acc = xyzz_identity<P>();
+        for (int w = nwin - 1; w >= 0; w--) {
+            for (int k = 0; k < c; k++) acc = xyzz_dbl_inl(acc);
+            const Xyzz<P> v = planes_get<P>(wbuf, 64, (size_t)w);
+            xyzz_add_quad(acc, v, ql);
+        }
+        if (tid == 0) {
+            Fe<P> X, Y, Z;
+            xyzz_to_jacobian(acc, X, Y, Z);
+            if (form == BZH_FORM_CANONICAL) {
+                X = fe_from_mont(X);
+                Y = fe_from_mont(Y);
+                Z = fe_from_mont(Z);
+            }
+            uint32_t* o = out_xyz + b * 24;
+            fe_store(o, X);
+            fe_store(o + 8, Y);
+            fe_store(o + 16, Z);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // k_msm_chunksum: bucket-wise sum of a vector's chunk segments into its first segment.  All lanes do useful
 // additions, unlike the running-sum reduction, whose per-segment cost this removes for every chunk but one:
 // (nchunks - 1) additions per bucket here against 2 per bucket AND per chunk there, plus its scan overhead.
@@ -1000,7 +1140,12 @@ static int msm_run_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_sca
         const double cus = (double)(ctx->num_cu > 0 ? ctx->num_cu : 256);
         double best = 1e300;
         size_t best_nc = cmin;
-        for (size_t nc = cmin; nc <= cmin * 8 && nc <= n_eff; nc++) {
+        static const size_t split_max = [] {
+            const char* e = getenv("BZH_ACC_SPLIT");   // tuning knob: at most this many times the minimal chunk count
+            const long v = e ? atol(e) : 16;
+            return (size_t)(v >= 1 && v <= 64 ? v : 16);
+        }();
+        for (size_t nc = cmin; nc <= cmin * split_max && nc <= n_eff; nc++) {
             const double chunk = ceil((double)n_eff / (double)nc);
             const double rounds = ceil((double)(nc * batch) / cus);
             const double t = rounds * (chunk * 10.0 + (double)p.M * 38.0 + 6000.0);
@@ -1181,7 +1326,7 @@ static int msm_run_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_sca
 #undef BZH_LAUNCH_ACC
         }
         const size_t nseg = nb * segs_per_vec;
-        bool presum = false, fused_out = false;
+        bool presum = false, fused_out = false, latency = false;
         {
             ScopedTimer t(ctx, BZH_T_MSM_REDUCE);
             // many segments (throughput regime): sum the chunks of every vector bucket-wise first, then run the
@@ -1204,7 +1349,16 @@ static int msm_run_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_sca
             // itself, no k_msm_finalize launch
             fused_out = acc_nwin == 1 && rspv == 1;
             uint32_t* fout = fused_out ? d_out + b0 * nclass * 24 : (uint32_t*)nullptr;
-            if (p.M >= 64 && rseg * nclass >= 256) {
+            // latency mode: fewer reduction waves than SIMDs -- the dependent chain, not the work, is the cost: four lanes per addition
+            static const bool no_quad = getenv("BZH_MSM_NO_QUAD") != nullptr;
+            latency = !no_quad && p.M >= 16 && rseg * nclass <= 1024;
+            if (latency && p.M >= 64 && rseg * nclass <= 256) {   // 256 workgroups of four waves: one wave per SIMD
+                hipLaunchKernelGGL((k_msm_reduce_quad_wg<C>), dim3((unsigned)(rseg * nclass)), dim3(256), (size_t)2 * 64 * 128, ctx->stream,
+                                   (const uint4*)d_buckets, p.M, nclass, rspv, mult, (uint4*)d_winsums, form, fout);
+            } else if (latency) {
+                hipLaunchKernelGGL((k_msm_reduce_quad<C>), dim3((unsigned)(rseg * nclass)), dim3(64), 0, ctx->stream,
+                                   (const uint4*)d_buckets, p.M, nclass, rspv, mult, (uint4*)d_winsums, form, fout);
+            } else if (p.M >= 64 && rseg * nclass >= 256) {
                 hipLaunchKernelGGL((k_msm_reduce_wave<C>), dim3((unsigned)(rseg * nclass)), dim3(64), 0, ctx->stream,
                                    (const uint4*)d_buckets, p.M, nclass, rspv, mult, (uint4*)d_winsums, form, fout);
             } else {
@@ -1215,9 +1369,14 @@ static int msm_run_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_sca
         if (!fused_out) {
             ScopedTimer t(ctx, BZH_T_MSM_FINALIZE);
             const size_t fchunks = (presum || use_gs) ? 1 : p.nchunks, fseg = (presum || use_gs) ? nb : nseg;
-            hipLaunchKernelGGL((k_msm_finalize<C>), dim3((unsigned)(nb * nclass)), dim3(64), 0, ctx->stream,
-                               (const uint4*)d_winsums, fseg * nclass, acc_nwin, fchunks, pre ? 0 : p.c, form,
-                               d_out + b0 * nclass * 24);
+            if (latency && acc_nwin <= 64)
+                hipLaunchKernelGGL((k_msm_finalize_quad<C>), dim3((unsigned)(nb * nclass)), dim3(256), 0, ctx->stream,
+                                   (const uint4*)d_winsums, fseg * nclass, acc_nwin, fchunks, pre ? 0 : p.c, form,
+                                   d_out + b0 * nclass * 24);
+            else
+                hipLaunchKernelGGL((k_msm_finalize<C>), dim3((unsigned)(nb * nclass)), dim3(64), 0, ctx->stream,
+                                   (const uint4*)d_winsums, fseg * nclass, acc_nwin, fchunks, pre ? 0 : p.c, form,
+                                   d_out + b0 * nclass * 24);
         }
         BZH_HIP_TRY(ctx, hipGetLastError());
     }
