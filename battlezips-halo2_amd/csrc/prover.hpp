@@ -134,6 +134,7 @@ struct Prover {
                bool lagrange = false, long shift_row = -1) {
         xy.assign(count * 8, 0);
         if (!count) return BZH_OK;
+        ArenaScope scope(arena);   // the scalar vectors and the result buffer are dead when this returns (d2h_finish below)
         static const bool no_shift = getenv("BZH_NO_COMMIT_SHIFT") != nullptr;
         const bool wide = lagrange && pk.srs_lagrange->n == n + 3;   // (g_lagrange | u | w | g_0): every vector spans the whole row
         const bool shift = wide && shift_row >= 0 && !no_shift && count <= 65535;
@@ -179,6 +180,7 @@ struct Prover {
     int evals(const uint32_t* stacked, size_t count, const std::vector<Fe<SF>>& points, std::vector<Fe<SF>>& out) {
         out.resize(count);
         if (!count) return BZH_OK;
+        ArenaScope scope(arena);
         uint32_t* xs = dalloc(count);
         uint32_t* res = dalloc(count);
         if (!xs || !res) return BZH_E_OOM;
@@ -711,6 +713,7 @@ int Prover<C>::prove(const uint32_t* d_advice_in, const uint64_t* instances, siz
         const size_t J = jobs.size();
         std::vector<std::pair<const uint32_t*, size_t>> srcs(J);
         for (size_t j = 0; j < J; j++) srcs[j] = where.at(jobs[j].first);
+        ArenaScope scope(arena);   // `gathered` is read by evals() (which ends in a stream sync) and by nothing else
         uint32_t* gathered = dalloc(B * J * n);
         if (!gathered) return BZH_E_OOM;
         PV_TRY(gather(srcs, gathered));
@@ -803,13 +806,16 @@ int Prover<C>::prove(const uint32_t* d_advice_in, const uint64_t* instances, siz
         const size_t J2 = ev_jobs.size();
         std::vector<std::pair<const uint32_t*, size_t>> srcs(J2);
         for (size_t j = 0; j < J2; j++) srcs[j] = {q_polys + ev_jobs[j].first * n * 8, nq * n};
-        uint32_t* gathered = dalloc(B * J2 * n);
-        if (!gathered) return BZH_E_OOM;
-        PV_TRY(gather(srcs, gathered));
         std::vector<Fe<SF>> pts(B * J2), ev;
         for (size_t b = 0; b < B; b++)
             for (size_t j = 0; j < J2; j++) pts[b * J2 + j] = rot(b, ev_jobs[j].second);
-        PV_TRY(evals(gathered, B * J2, pts, ev));
+        {
+            ArenaScope scope(arena);   // `gathered` lives until evals() returns (stream sync)
+            uint32_t* gathered = dalloc(B * J2 * n);
+            if (!gathered) return BZH_E_OOM;
+            PV_TRY(gather(srcs, gathered));
+            PV_TRY(evals(gathered, B * J2, pts, ev));
+        }
         size_t maxpts = 1;
         for (auto& rs : pk.rot_sets) maxpts = std::max(maxpts, rs.size());
         std::vector<Fe<SF>> r_small(B * nq * maxpts, fe_zero<SF>());

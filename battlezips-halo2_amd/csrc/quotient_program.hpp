@@ -620,12 +620,12 @@ struct Arena {
     };
     std::vector<Block> blocks;
     int device = 0;
-    size_t requested = 0;  // bytes handed out since the last reset
+    size_t live = 0, peak = 0;  // bytes handed out and not released since the last reset, and their high-water mark
     // A call's allocation sequence is deterministic, so after the first call of a given shape the arena is ONE block
     // that every later call bumps through without touching hipMalloc (overflow blocks are merged at the next reset).
     void reset() {
         if (blocks.size() > 1) {
-            const size_t want = requested + (requested >> 4) + ((size_t)1 << 20);
+            const size_t want = peak + (peak >> 4) + ((size_t)1 << 20);
             release();
             Block nb;
             nb.size = want;
@@ -633,7 +633,7 @@ struct Arena {
             if (hipMalloc((void**)&nb.p, nb.size) == hipSuccess) blocks.push_back(nb);
         }
         for (auto& b : blocks) b.used = 0;
-        requested = 0;
+        live = peak = 0;
     }
     void release() {
         for (auto& b : blocks) (void)hipFree(b.p);
@@ -641,7 +641,8 @@ struct Arena {
     }
     void* alloc(size_t bytes) {
         bytes = (bytes + 255) & ~(size_t)255;
-        requested += bytes;
+        live += bytes;
+        peak = std::max(peak, live);
         for (auto& b : blocks)
             if (b.size - b.used >= bytes) {
                 void* r = b.p + b.used;
@@ -655,6 +656,25 @@ struct Arena {
         blocks.push_back(nb);
         return nb.p;
     }
+    // Stack discipline for temporaries (a commitment's scalar vectors, gathered rows): everything allocated after mark() is
+    // handed back by pop().  Work on the buffers was enqueued on the ctx's one stream, so whatever reuses the memory runs
+    // after it.  While the arena is still a list of blocks (a key's first call) only the accounting moves: the merged block
+    // of the next call is sized by the high-water mark.
+    struct Mark {
+        size_t used, live;
+        bool single;
+    };
+    Mark mark() const { return Mark{blocks.size() == 1 ? blocks[0].used : 0, live, blocks.size() == 1}; }
+    void pop(const Mark& m) {
+        live = m.live;
+        if (m.single && blocks.size() == 1) blocks[0].used = m.used;
+    }
+};
+struct ArenaScope {
+    Arena& a;
+    Arena::Mark m;
+    explicit ArenaScope(Arena& ar) : a(ar), m(ar.mark()) {}
+    ~ArenaScope() { a.pop(m); }
 };
 
 struct Reader {
