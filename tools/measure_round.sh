@@ -23,6 +23,8 @@ for cv in vesta pallas bn254; do
   python3 $R/bench.py --no-cpu-baseline --workload msm24 --curve $cv --steps 5 --warmup 2 > $O/msm24_${cv}_bench.json 2> /dev/null && echo msm24 $cv done
 done
 python3 $R/bench.py --no-cpu-baseline --workload mixed_board_shot --mix-divisor 4 --steps 3 --warmup 1 > $O/mixed_div4_bench.json 2> /dev/null && echo mixed done
+python3 $R/bench.py --no-cpu-baseline --workload mixed_board_shot --steps 2 --warmup 1 > $O/mixed_full_bench.json 2> /dev/null && echo mixed full done
+python3 $R/bench.py --no-cpu-baseline --workload proof_k17 --batch 1 --concurrency 1 --steps 5 --warmup 2 > $O/proof_k17_b1c1_bench.json 2> /dev/null && echo k17 b1 done
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python3 $R/bench.py --no-cpu-baseline --concurrency 1 --steps 3 --warmup 1 > $O/pmc_fetch.log 2>&1 && echo pmc fetch done
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python3 $R/bench.py --no-cpu-baseline --concurrency 1 --steps 3 --warmup 1 > $O/pmc_write.log 2>&1 && echo pmc write done
 python3 $R/tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write > $O/proof_k14_pmc_traffic.json && rm -rf $O/pmc_fetch $O/pmc_write && echo pmc merged
