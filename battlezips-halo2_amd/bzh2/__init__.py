@@ -597,6 +597,23 @@ def _ctx_kate_division(self, field: int, coeffs, x: int, form: int = FORM_CANONI
 Context.kate_division = _ctx_kate_division
 
 
+def _ctx_kate_division_batch(self, field: int, coeffs, xs, form: int = FORM_CANONICAL) -> np.ndarray:
+    """`batch` kate divisions in one pass: coeffs (batch, n, 4), xs a list of `batch` integers; returns (batch, n-1, 4)."""
+    c = np.ascontiguousarray(coeffs, dtype=np.uint64)
+    batch, n = c.shape[0], c.shape[1]
+    out = np.zeros((batch, max(n - 1, 0), 4), dtype=np.uint64)
+    xv = np.ascontiguousarray(np.stack([int_to_limbs(x) for x in xs]), dtype=np.uint64)
+    L = load()
+    vp = ctypes.c_void_p
+    L.bzh_kate_division_batch.argtypes = [vp, ctypes.c_int, vp, ctypes.c_size_t, ctypes.c_size_t, vp, ctypes.c_int, ctypes.c_int, vp]
+    self._check(L.bzh_kate_division_batch(self.handle, field, _vp(c), n, batch, _vp(xv), form, MEM_HOST, _vp(out)),
+                "bzh_kate_division_batch")
+    return out
+
+
+Context.kate_division_batch = _ctx_kate_division_batch
+
+
 def permute_expression_pair(field: int, input_vals, table_vals, usable_rows: int, form: int = FORM_CANONICAL):
     """lookup::prover::permute_expression_pair over the first usable_rows rows -> (permuted_input, permuted_table)."""
     a, t = _as_elems(input_vals), _as_elems(table_vals)

@@ -292,9 +292,12 @@ int poly_eval(bzh_ctx* ctx, int field, const uint32_t* coeffs, size_t n, size_t 
 }
 
 // ---------------------------------------------------------------------------
-// kate_division: quotient of p(X) by (X - x).  With d_t = c_(n-1-t) the quotient obeys the Horner
-// recurrence r_k = x r_(k-1) + d_k, i.e. r_k = x^k * sum_(t<=k) d_t x^-t: one element-wise pass,
-// one additive scan, one element-wise pass (q_(n-2-k) = r_k, the remainder r_(n-1) = p(x) is dropped).
+// kate_division: quotient of p(X) by (X - x).  With d_t = c_(n-1-t) the quotient obeys the Horner recurrence
+// r_k = x r_(k-1) + d_k, q_(n-2-k) = r_k (the remainder r_(n-1) = p(x) is dropped).  One workgroup per polynomial: every
+// thread runs the recurrence over its own contiguous segment of L indices from zero (one multiplication per element),
+// the segment results are combined by a scan of R_t = x^L R_(t-1) + loc_t through LDS (log2(threads) steps), and a
+// second walk over the segment from the carried-in value writes the quotient -- two multiplications per coefficient and no
+// x^-1.  (The round-2 version raised x^-1 and x to the element's index per element: ~56 multiplications per coefficient.)
 // ---------------------------------------------------------------------------
 template <class P>
 __device__ __forceinline__ Fe<P> fe_pow_u64(Fe<P> base, size_t e) {
@@ -305,44 +308,58 @@ __device__ __forceinline__ Fe<P> fe_pow_u64(Fe<P> base, size_t e) {
     }
     return acc;
 }
-// x / x^-1 of vector v sit at xs + v*16 / xs + v*16 + 8; vector v's coefficients at c + v*n*8
+static constexpr int kKateMaxThreads = 1024;
+// x of vector v sits at xs + v*16 (xs + v*16 + 8 holds x^-1 for callers that still pass it: unused); vector v's n
+// coefficients at c + v*n*8, its n-1 quotient coefficients at q + v*(n-1)*8
 template <class P>
-__global__ void __launch_bounds__(kVecThreads) k_kate_pre(const uint32_t* __restrict__ c, size_t n, const uint32_t* __restrict__ xs,
-                                                            uint32_t* __restrict__ a) {
-    const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x, v = blockIdx.y;
-    if (t >= n) return;
-    fe_store(a + (v * n + t) * 8, fe_mul(fe_load<P>(c + (v * n + n - 1 - t) * 8), fe_pow_u64(fe_load<P>(xs + v * 16 + 8), t)));
-}
-template <class P>
-__global__ void __launch_bounds__(kVecThreads) k_kate_post(const uint32_t* __restrict__ c, const uint32_t* __restrict__ excl,
-                                                             const uint32_t* __restrict__ a, size_t n,
-                                                             const uint32_t* __restrict__ xs, uint32_t* __restrict__ q) {
-    const size_t k = blockIdx.x * (size_t)blockDim.x + threadIdx.x, v = blockIdx.y;
-    if (k + 1 >= n) return;  // k <= n-2
+__global__ void __launch_bounds__(kKateMaxThreads) k_kate_rows(const uint32_t* __restrict__ c, size_t n, const uint32_t* __restrict__ xs,
+                                                                 uint32_t* __restrict__ q) {
+    __shared__ uint32_t lds[8 * kKateMaxThreads];  // word w of thread t's value at lds[w * T + t]
+    const unsigned t = threadIdx.x, T = blockDim.x;
+    const size_t v = blockIdx.x, m = n - 1;
+    const size_t L = (m + T - 1) / T;
+    const size_t k0 = (size_t)t * L < m ? (size_t)t * L : m, k1 = k0 + L < m ? k0 + L : m;
     const Fe<P> x = fe_load<P>(xs + v * 16);
-    if (fe_is_zero(x)) {  // x == 0: q_i = c_(i+1)
-        fe_store(q + (v * (n - 1) + k) * 8, fe_load<P>(c + (v * n + k + 1) * 8));
-        return;
+    const uint32_t* cv = c + v * n * 8;
+    uint32_t* qv = q + v * m * 8;
+    Fe<P> R = fe_zero<P>();
+    for (size_t k = k0; k < k1; k++) R = fe_add(fe_mul(R, x), fe_load<P>(cv + (n - 1 - k) * 8));
+    Fe<P> M = fe_pow_u64(x, L);
+    auto put = [&](const Fe<P>& a) {
+#pragma unroll
+        for (int w = 0; w < 8; w++) lds[w * T + t] = a.l[w];
+    };
+    auto get = [&](unsigned from) {
+        Fe<P> a;
+#pragma unroll
+        for (int w = 0; w < 8; w++) a.l[w] = lds[w * T + from];
+        return a;
+    };
+    for (unsigned s = 1; s < T; s <<= 1) {
+        put(R);
+        __syncthreads();
+        if (t >= s) R = fe_add(R, fe_mul(M, get(t - s)));
+        __syncthreads();
+        M = fe_sqr(M);
     }
-    const Fe<P> incl = fe_add(fe_load<P>(excl + (v * n + k) * 8), fe_load<P>(a + (v * n + k) * 8));
-    fe_store(q + (v * (n - 1) + n - 2 - k) * 8, fe_mul(incl, fe_pow_u64(x, k)));
+    put(R);
+    __syncthreads();
+    Fe<P> r = t ? get(t - 1) : fe_zero<P>();
+    for (size_t k = k0; k < k1; k++) {
+        r = fe_add(fe_mul(r, x), fe_load<P>(cv + (n - 1 - k) * 8));
+        fe_store(qv + (m - 1 - k) * 8, r);
+    }
 }
 
 template <class P>
 static int kate_t(bzh_ctx* ctx, const uint32_t* d_c, size_t n, size_t batch, const uint32_t* d_xs, uint32_t* d_q) {
     if (n < 2 || !batch) return BZH_OK;
-    if (batch > 65535) return BZH_E_ARG;
-    const dim3 grid((unsigned)((n + kVecThreads - 1) / kVecThreads), (unsigned)batch), block(kVecThreads);
-    void* w = nullptr;
-    int rc = ws_ensure(ctx, 1, 2 * n * batch * 32, &w);
-    if (rc) return rc;
-    uint32_t* a = (uint32_t*)w;
-    uint32_t* sc = a + n * batch * 8;
-    hipLaunchKernelGGL((k_kate_pre<P>), grid, block, 0, ctx->stream, d_c, n, d_xs, a);
-    BZH_HIP_TRY(ctx, hipMemcpyAsync(sc, a, n * batch * 32, hipMemcpyDeviceToDevice, ctx->stream));
-    rc = prefix_scan_t<P, AddOp<P>>(ctx, sc, n, batch);
-    if (rc) return rc;
-    hipLaunchKernelGGL((k_kate_post<P>), grid, block, 0, ctx->stream, d_c, sc, a, n, d_xs, d_q);
+    if (batch > 0x7fffffffu) return BZH_E_ARG;
+    // ~8 coefficients per thread and up: 64 ... 1024 threads
+    unsigned threads = 64;
+    while (threads < (unsigned)kKateMaxThreads && (size_t)threads * 8 < n - 1) threads <<= 1;
+    ScopedTimer t(ctx, BZH_T_POLY);
+    hipLaunchKernelGGL((k_kate_rows<P>), dim3((unsigned)batch), dim3(threads), 0, ctx->stream, d_c, n, d_xs, d_q);
     BZH_HIP_TRY(ctx, hipGetLastError());
     return BZH_OK;
 }

@@ -571,11 +571,20 @@ int orc_generator_collapse(int curve_id, uint64_t *g_xy, size_t half, const uint
         used++;
     }
     for (int i = 0; i < used; i++) pthread_join(th[i], NULL);
-    for (size_t i = 0; i < half; i++) {
-        aff a; jac_to_affine(F, &a, &out[i]);
-        fe x, y; f_from_mont(F, &x, &a.x); f_from_mont(F, &y, &a.y);
+    /* upstream normalises the half points together (Curve::batch_normalize: one inversion, Montgomery's trick) */
+    fe *pref = (fe *)malloc((half ? half : 1) * sizeof(fe));
+    fe run = F->r;
+    for (size_t i = 0; i < half; i++) { pref[i] = run; if (!f_is_zero(&out[i].z)) f_mul(F, &run, &run, &out[i].z); }
+    fe inv; f_inv(F, &inv, &run);
+    for (size_t i = half; i-- > 0;) {
+        if (f_is_zero(&out[i].z)) { memset(g_xy + 8 * i, 0, 64); continue; }
+        fe zi, zi2, zi3, ax, ay, x, y;
+        f_mul(F, &zi, &inv, &pref[i]); f_mul(F, &inv, &inv, &out[i].z);
+        f_sqr(F, &zi2, &zi); f_mul(F, &zi3, &zi2, &zi);
+        f_mul(F, &ax, &out[i].x, &zi2); f_mul(F, &ay, &out[i].y, &zi3);
+        f_from_mont(F, &x, &ax); f_from_mont(F, &y, &ay);
         memcpy(g_xy + 8 * i, &x, 32); memcpy(g_xy + 8 * i + 4, &y, 32);
     }
-    free(g); free(out);
+    free(pref); free(g); free(out);
     return 0;
 }

@@ -110,3 +110,29 @@ def test_kate_division(gpu_ctx, n):
     for x in (rng.randrange(F.p), 0, 1):
         got = C.array_to_ints(gpu_ctx.kate_division(0, C.ints_to_array(c), x))
         assert got == O.kate_division(c, x, F), (n, x)
+
+
+@pytest.mark.parametrize("field,n,batch", [(0, 1000, 5), (1, 4097, 3), (0, 131072, 2), (2, 777, 4), (0, 9, 70)])
+def test_kate_division_batch(gpu_ctx, field, n, batch):
+    """arithmetic::kate_division over a batch, one point per polynomial (the multiopen's use: one workgroup per polynomial,
+    segments of the Horner recurrence stitched through LDS): ragged lengths, every field, x = 0 and x = 1 among the points;
+    big n checked through the identity p(X) = q(X) (X - x) + p(x) at a random point instead of the big-int division."""
+    import numpy as np
+    F = [O.FP, O.FQ, O.BN_FR][field]
+    rng = random.Random(900 + n + field)
+    cs = [rand_ints(rng, n, F.p) for _ in range(batch)]
+    xs = [rng.randrange(F.p) for _ in range(batch)]
+    xs[0] = 0
+    if batch > 1:
+        xs[1] = 1
+    got = gpu_ctx.kate_division_batch(field, np.stack([C.ints_to_array(c) for c in cs]), xs)
+    for v in range(batch):
+        q = C.array_to_ints(got[v])
+        if n <= 5000:
+            assert q == O.kate_division(cs[v], xs[v], F), (v, xs[v])
+        else:
+            z = rng.randrange(F.p)
+            ev = lambda poly, at: C.eval_poly(field, C.ints_to_array(poly), at)
+            pz, qz, px = ev(cs[v], z), ev(q, z), ev(cs[v], xs[v])
+            assert (qz * (z - xs[v]) + px - pz) % F.p == 0, v
+            assert q[-1] == cs[v][-1]
