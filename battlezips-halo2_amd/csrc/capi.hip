@@ -681,26 +681,11 @@ int bzh_kate_division_batch(bzh_ctx* ctx, int field, const uint64_t* coeffs, siz
     BZH_POLY_PROLOGUE(!coeffs || !xs || !out || n < 1 || !batch || batch > 65535);
     if (n == 1) return BZH_OK;
     if (mem == BZH_MEM_DEVICE && form != BZH_FORM_MONTGOMERY) return BZH_E_ARG;
-    // [x_v, x_v^-1] per vector, inverted on the host with one inversion for the whole batch; uploaded in Montgomery form
-    std::vector<uint64_t> xh(batch * 8);
+    // x_v per vector, uploaded in Montgomery form
+    std::vector<uint64_t> xh(batch * 4);
     auto go = [&](auto tag) {
         using PP = decltype(tag);
-        std::vector<Fe<PP>> xm(batch), pre(batch + 1);
-        pre[0] = fe_one<PP>();
-        for (size_t v = 0; v < batch; v++) {
-            xm[v] = load_host<PP>(xs + 4 * v, form);
-            pre[v + 1] = fe_is_zero(xm[v]) ? pre[v] : fe_mul(pre[v], xm[v]);
-        }
-        Fe<PP> inv = fe_inv(pre[batch]);
-        for (size_t v = batch; v-- > 0;) {
-            Fe<PP> xi = fe_zero<PP>();
-            if (!fe_is_zero(xm[v])) {
-                xi = fe_mul(inv, pre[v]);
-                inv = fe_mul(inv, xm[v]);
-            }
-            store_host<PP>(xh.data() + v * 8, xm[v], BZH_FORM_MONTGOMERY);
-            store_host<PP>(xh.data() + v * 8 + 4, xi, BZH_FORM_MONTGOMERY);
-        }
+        for (size_t v = 0; v < batch; v++) store_host<PP>(xh.data() + v * 4, load_host<PP>(xs + 4 * v, form), BZH_FORM_MONTGOMERY);
     };
     switch (field) {
         case BZH_FIELD_FP: go(FpParams{}); break;
@@ -709,9 +694,9 @@ int bzh_kate_division_batch(bzh_ctx* ctx, int field, const uint64_t* coeffs, siz
         default: go(BnFqParams{}); break;
     }
     Stager s{ctx, field, BZH_FORM_MONTGOMERY};
-    if ((rc = s.begin(((mem == BZH_MEM_HOST ? 2 * n : 0) + 2) * batch * 32 + 512))) return rc;
+    if ((rc = s.begin(((mem == BZH_MEM_HOST ? 2 * n : 0) + 1) * batch * 32 + 512))) return rc;
     uint32_t* d_x;
-    if ((rc = s.in(xh.data(), 2 * batch, &d_x))) return rc;
+    if ((rc = s.in(xh.data(), batch, &d_x))) return rc;
     if (mem == BZH_MEM_HOST) {
         Stager sc{ctx, field, form};
         sc.cur = s.cur;

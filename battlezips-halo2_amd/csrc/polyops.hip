@@ -147,16 +147,11 @@ __global__ void __launch_bounds__(256) k_scan_apply(uint32_t* __restrict__ data,
 // polynomial evaluation: one workgroup per (polynomial, point).  Thread t sums
 // c[t + kT] y^k with y = x^T by Horner (coalesced reads), then the block adds x^t * partial_t.
 // ---------------------------------------------------------------------------
+// p(x) of the n coefficients at c by the whole workgroup (kVecThreads threads); the sum is valid in thread 0
 template <class P>
-__global__ void __launch_bounds__(kVecThreads) k_eval_poly(const uint32_t* __restrict__ coeffs, size_t n,
-                                                             const uint32_t* __restrict__ xs, size_t x_stride,
-                                                             uint32_t* __restrict__ out) {
-    __shared__ __align__(16) uint4 sh[2 * kVecThreads];
+__device__ __forceinline__ Fe<P> block_eval_poly(const uint32_t* __restrict__ c, size_t n, const Fe<P>& x, uint4* sh) {
     constexpr int T = kVecThreads;
     const int tid = threadIdx.x;
-    const size_t b = blockIdx.x;
-    const uint32_t* c = coeffs + b * n * 8;
-    const Fe<P> x = fe_load<P>(xs + b * x_stride * 8);
     // x^t for this thread (binary method over the 8 bits of t) and y = x^T
     Fe<P> xt = fe_one<P>(), pw = x;
 #pragma unroll
@@ -174,8 +169,16 @@ __global__ void __launch_bounds__(kVecThreads) k_eval_poly(const uint32_t* __res
         }
         acc = fe_mul(acc, xt);
     }
-    acc = block_sum(acc, sh, T);
-    if (tid == 0) fe_store(out + b * 8, acc);
+    return block_sum(acc, sh, T);
+}
+template <class P>
+__global__ void __launch_bounds__(kVecThreads) k_eval_poly(const uint32_t* __restrict__ coeffs, size_t n,
+                                                             const uint32_t* __restrict__ xs, size_t x_stride,
+                                                             uint32_t* __restrict__ out) {
+    __shared__ __align__(16) uint4 sh[2 * kVecThreads];
+    const size_t b = blockIdx.x;
+    const Fe<P> acc = block_eval_poly<P>(coeffs + b * n * 8, n, fe_load<P>(xs + b * x_stride * 8), sh);
+    if (threadIdx.x == 0) fe_store(out + b * 8, acc);
 }
 
 // inner product sum_i a_i b_i per vector
@@ -309,22 +312,39 @@ __device__ __forceinline__ Fe<P> fe_pow_u64(Fe<P> base, size_t e) {
     return acc;
 }
 static constexpr int kKateMaxThreads = 1024;
-// x of vector v sits at xs + v*16 (xs + v*16 + 8 holds x^-1 for callers that still pass it: unused); vector v's n
-// coefficients at c + v*n*8, its n-1 quotient coefficients at q + v*(n-1)*8
+// Few polynomials (a single proof) would leave the chip to one workgroup each, so a polynomial may be cut into S spans of
+// G = threads * L indices, one workgroup per span: k_kate_span_totals evaluates every span but the last from zero
+// (span s covers coefficients c[n-(s+1)G .. n-1-sG], its value at x is E_s), and span s of k_kate_rows starts from the
+// carried-in value C_s = sum_(s'<s) x^(G(s-1-s')) E_s' (Horner over the preceding totals).
+template <class P>
+__global__ void __launch_bounds__(kVecThreads) k_kate_span_totals(const uint32_t* __restrict__ c, size_t n, const uint32_t* __restrict__ xs,
+                                                                    size_t G, uint32_t* __restrict__ tot) {
+    __shared__ __align__(16) uint4 sh[2 * kVecThreads];
+    const size_t s = blockIdx.x, v = blockIdx.y, S1 = gridDim.x;  // spans 0 .. S-2: all of them full
+    const Fe<P> acc = block_eval_poly<P>(c + (v * n + n - (s + 1) * G) * 8, G, fe_load<P>(xs + v * 8), sh);
+    if (threadIdx.x == 0) fe_store(tot + (v * S1 + s) * 8, acc);
+}
+// x of vector v sits at xs + v*8; vector v's n coefficients at c + v*n*8, its n-1 quotient coefficients at q + v*(n-1)*8;
+// grid (S, batch), blockDim.x * L = G; tot: the S-1 span totals per vector (unused when S = 1)
 template <class P>
 __global__ void __launch_bounds__(kKateMaxThreads) k_kate_rows(const uint32_t* __restrict__ c, size_t n, const uint32_t* __restrict__ xs,
-                                                                 uint32_t* __restrict__ q) {
+                                                                 size_t L, const uint32_t* __restrict__ tot, uint32_t* __restrict__ q) {
     __shared__ uint32_t lds[8 * kKateMaxThreads];  // word w of thread t's value at lds[w * T + t]
     const unsigned t = threadIdx.x, T = blockDim.x;
-    const size_t v = blockIdx.x, m = n - 1;
-    const size_t L = (m + T - 1) / T;
-    const size_t k0 = (size_t)t * L < m ? (size_t)t * L : m, k1 = k0 + L < m ? k0 + L : m;
-    const Fe<P> x = fe_load<P>(xs + v * 16);
+    const size_t s = blockIdx.x, S = gridDim.x, v = blockIdx.y, m = n - 1, G = (size_t)T * L;
+    const size_t kb = s * G + (size_t)t * L, k0 = kb < m ? kb : m, k1 = k0 + L < m ? k0 + L : m;
+    const Fe<P> x = fe_load<P>(xs + v * 8);
     const uint32_t* cv = c + v * n * 8;
     uint32_t* qv = q + v * m * 8;
-    Fe<P> R = fe_zero<P>();
-    for (size_t k = k0; k < k1; k++) R = fe_add(fe_mul(R, x), fe_load<P>(cv + (n - 1 - k) * 8));
     Fe<P> M = fe_pow_u64(x, L);
+    Fe<P> carry = fe_zero<P>();
+    if (s && t == 0) {  // only thread 0 starts from the carried-in value
+        Fe<P> xg = M;
+        for (unsigned w = 1; w < T; w <<= 1) xg = fe_sqr(xg);  // x^G, T a power of two
+        for (size_t sp = 0; sp < s; sp++) carry = fe_add(fe_mul(carry, xg), fe_load<P>(tot + (v * (S - 1) + sp) * 8));
+    }
+    Fe<P> R = t ? fe_zero<P>() : carry;
+    for (size_t k = k0; k < k1; k++) R = fe_add(fe_mul(R, x), fe_load<P>(cv + (n - 1 - k) * 8));
     auto put = [&](const Fe<P>& a) {
 #pragma unroll
         for (int w = 0; w < 8; w++) lds[w * T + t] = a.l[w];
@@ -335,16 +355,16 @@ __global__ void __launch_bounds__(kKateMaxThreads) k_kate_rows(const uint32_t* _
         for (int w = 0; w < 8; w++) a.l[w] = lds[w * T + from];
         return a;
     };
-    for (unsigned s = 1; s < T; s <<= 1) {
+    for (unsigned st = 1; st < T; st <<= 1) {
         put(R);
         __syncthreads();
-        if (t >= s) R = fe_add(R, fe_mul(M, get(t - s)));
+        if (t >= st) R = fe_add(R, fe_mul(M, get(t - st)));
         __syncthreads();
         M = fe_sqr(M);
     }
     put(R);
     __syncthreads();
-    Fe<P> r = t ? get(t - 1) : fe_zero<P>();
+    Fe<P> r = t ? get(t - 1) : carry;
     for (size_t k = k0; k < k1; k++) {
         r = fe_add(fe_mul(r, x), fe_load<P>(cv + (n - 1 - k) * 8));
         fe_store(qv + (m - 1 - k) * 8, r);
@@ -354,12 +374,29 @@ __global__ void __launch_bounds__(kKateMaxThreads) k_kate_rows(const uint32_t* _
 template <class P>
 static int kate_t(bzh_ctx* ctx, const uint32_t* d_c, size_t n, size_t batch, const uint32_t* d_xs, uint32_t* d_q) {
     if (n < 2 || !batch) return BZH_OK;
-    if (batch > 0x7fffffffu) return BZH_E_ARG;
-    // ~8 coefficients per thread and up: 64 ... 1024 threads
+    if (batch > 65535) return BZH_E_ARG;
+    const size_t m = n - 1;
+    // 256-thread workgroups (64 for tiny inputs), about 256 workgroups per launch: S = 256 / batch spans per polynomial,
+    // at least 4 coefficients per thread and at most 32 spans.  Per coefficient the kernel spends 2 multiplications on the
+    // recurrence and (3 log2(threads) + log2(L) + S) / L on the stitching, so short chains are for small batches only.
     unsigned threads = 64;
-    while (threads < (unsigned)kKateMaxThreads && (size_t)threads * 8 < n - 1) threads <<= 1;
+    while (threads < 256u && (size_t)threads * 4 < m) threads <<= 1;
+    size_t S = (256 + batch - 1) / batch;
+    if (S > 32) S = 32;
+    size_t L = (m + (size_t)threads * S - 1) / ((size_t)threads * S);
+    if (L < 4) L = 4;
+    S = (m + (size_t)threads * L - 1) / ((size_t)threads * L);
+    void* tot = nullptr;
+    if (S > 1) {
+        int rc = ws_ensure(ctx, 2, (S - 1) * batch * 32, &tot);
+        if (rc) return rc;
+    }
     ScopedTimer t(ctx, BZH_T_POLY);
-    hipLaunchKernelGGL((k_kate_rows<P>), dim3((unsigned)batch), dim3(threads), 0, ctx->stream, d_c, n, d_xs, d_q);
+    if (S > 1)
+        hipLaunchKernelGGL((k_kate_span_totals<P>), dim3((unsigned)(S - 1), (unsigned)batch), dim3(kVecThreads), 0, ctx->stream, d_c, n, d_xs,
+                           (size_t)threads * L, (uint32_t*)tot);
+    hipLaunchKernelGGL((k_kate_rows<P>), dim3((unsigned)S, (unsigned)batch), dim3(threads), 0, ctx->stream, d_c, n, d_xs, L,
+                       (const uint32_t*)tot, d_q);
     BZH_HIP_TRY(ctx, hipGetLastError());
     return BZH_OK;
 }

@@ -891,23 +891,11 @@ int Prover<C>::prove(const uint32_t* d_advice_in, const uint64_t* instances, siz
             uint32_t* nxt = k_b;
             size_t len = n;
             for (int r : pk.rot_sets[si]) {
-                // [x, x^-1] per proof, one inversion for the batch
-                std::vector<Fe<SF>> xv(2 * B), pre(B + 1);
-                pre[0] = fe_one<SF>();
-                for (size_t b = 0; b < B; b++) {
-                    xv[2 * b] = rot(b, r);
-                    pre[b + 1] = fe_is_zero(xv[2 * b]) ? pre[b] : fe_mul(pre[b], xv[2 * b]);
-                }
-                Fe<SF> inv = fe_inv(pre[B]);
-                for (size_t b = B; b-- > 0;) {
-                    xv[2 * b + 1] = fe_zero<SF>();
-                    if (fe_is_zero(xv[2 * b])) continue;
-                    xv[2 * b + 1] = fe_mul(inv, pre[b]);
-                    inv = fe_mul(inv, xv[2 * b]);
-                }
-                uint32_t* d_x = dalloc(2 * B);
+                std::vector<Fe<SF>> xv(B);
+                for (size_t b = 0; b < B; b++) xv[b] = rot(b, r);
+                uint32_t* d_x = dalloc(B);
                 if (!d_x) return BZH_E_OOM;
-                PV_TRY(upload(d_x, xv.data(), 2 * B));
+                PV_TRY(upload(d_x, xv.data(), B));
                 PV_TRY(poly_kate_division(ctx, field, cur, len, B, d_x, nxt));
                 std::swap(cur, nxt);
                 len--;

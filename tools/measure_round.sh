@@ -12,6 +12,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_default -o d -- 
 python3 $R/bench.py --no-cpu-baseline --concurrency 1 --steps 5 --warmup 2 > $O/proof_k14_b64c1_bench.json 2> /dev/null && echo b64c1 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_b64c1 -o d -- python3 $R/bench.py --no-cpu-baseline --concurrency 1 --steps 5 --warmup 2 > $O/proof_k14_b64c1_bench_under_rocprof.json 2> $O/prof_b64c1.err && echo prof b64c1 done
 python3 $R/bench.py --no-cpu-baseline --batch 1 --concurrency 1 --steps 10 --warmup 3 > $O/proof_k14_b1c1_bench.json 2> /dev/null && echo b1 done
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_b1c1 -o d -- python3 $R/bench.py --no-cpu-baseline --batch 1 --concurrency 1 --steps 10 --warmup 3 > $O/proof_k14_b1c1_bench_under_rocprof.json 2> $O/prof_b1c1.err && echo prof b1c1 done
 python3 $R/bench.py --no-cpu-baseline --workload proof_k11 --batch 1 --concurrency 1 --steps 10 --warmup 3 > $O/proof_k11_b1c1_bench.json 2> /dev/null && echo k11 b1 done
 python3 $R/bench.py --no-cpu-baseline --workload proof_k11 --batch 128 --concurrency 8 --steps 8 --warmup 2 > $O/proof_k11_b128c8_bench.json 2> /dev/null && echo k11 done
 python3 $R/bench.py --no-cpu-baseline --workload proof_k12 --batch 64 --concurrency 4 --steps 8 --warmup 2 > $O/proof_k12_b64c4_bench.json 2> /dev/null && echo k12 done
