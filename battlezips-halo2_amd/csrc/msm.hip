@@ -236,7 +236,8 @@ __global__ void __launch_bounds__(T) k_msm_accumulate(const uint32_t* __restrict
                                                                   uint4* __restrict__ partials, size_t row_len,
                                                                   size_t row_stride, size_t dup_from,
                                                                   unsigned long long* __restrict__ add_counter,
-                                                                  size_t vec_col_stride, size_t vec0) {
+                                                                  size_t vec_col_stride, size_t vec0, uint32_t xcd_vecs,
+                                                                  uint32_t xcd_chunks) {
     using P = typename C::Base;
     extern __shared__ __align__(16) uint32_t lds[];
     uint32_t* cnt = lds;  // index m in [0, M]; cnt[0] stays 0
@@ -247,7 +248,19 @@ __global__ void __launch_bounds__(T) k_msm_accumulate(const uint32_t* __restrict
     const int tid = threadIdx.x;
     // vector index fastest: workgroups dispatched together (and dealt round-robin to the XCDs) work on the SAME chunk of
     // different vectors, i.e. gather from the same 2 MB window of the base table, which then lives in every XCD's L2
-    const size_t b = blockIdx.x, w = blockIdx.y, ck = blockIdx.z, nchunks = gridDim.z;
+    size_t b = blockIdx.x, w = blockIdx.y, ck = blockIdx.z, nchunks = gridDim.z;
+    if (xcd_chunks) {
+        // XCD-aware order (1-D grid, window tables): workgroups go round-robin to the 8 XCDs by linear id, so id & 7 names the
+        // XCD; the (chunk, vector) pairs in chunk-major order are cut into 8 equal runs, one per XCD, so that the workgroups
+        // resident on an XCD gather from one or two ~2 MB windows of the table (its L2 holds 4 MB) instead of eight of them
+        const size_t lin = blockIdx.x, xcd = lin & 7, i = lin >> 3, total = (size_t)xcd_vecs * xcd_chunks, per = (total + 7) / 8;
+        const size_t item = xcd * per + i;
+        if (item >= total) return;  // padding of the runs (whole workgroup, before any barrier)
+        ck = item / xcd_vecs;
+        b = item - ck * xcd_vecs;
+        w = 0;
+        nchunks = xcd_chunks;
+    }
     const size_t c0 = ck * chunk;
     const int len = (int)min(chunk, n - c0);
     const uint16_t* dg = digits + (b * (size_t)nwin + w) * n + c0;
@@ -1314,12 +1327,15 @@ static int msm_run_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_sca
         {
             ScopedTimer t(ctx, BZH_T_MSM_ACCUMULATE);
             if (ctx->profiling) ctx->alg_bytes[BZH_T_MSM_ACCUMULATE] += (double)nb * (double)n * 32.0 + (double)n * 64.0;
-            const dim3 grid((unsigned)nb, (unsigned)acc_nwin, (unsigned)p.nchunks);
+            static const bool xcd_map = getenv("BZH_ACC_NO_XCD_MAP") == nullptr;
+            const bool xmap = xcd_map && acc_nwin == 1 && nb >= 8 && !bases->vec_col_stride;
+            const dim3 grid = xmap ? dim3((unsigned)(((nb * p.nchunks + 7) / 8) * 8)) : dim3((unsigned)nb, (unsigned)acc_nwin, (unsigned)p.nchunks);
+            const uint32_t xv = xmap ? (uint32_t)nb : 0u, xc = xmap ? (uint32_t)p.nchunks : 0u;
 #define BZH_LAUNCH_ACC(TT)                                                                                              \
     hipLaunchKernelGGL((k_msm_accumulate<C, TT>), grid, dim3(TT), acc_lds, ctx->stream, bases->d_xy,                      \
                        (const uint16_t*)d_digits, n_eff, acc_nwin, M_acc, p.chunk, (uint4*)d_buckets, d_partials, row_len, \
                        row_stride, pair_in ? n - 2 : (size_t)0, ctx->profiling ? ctx->d_add_counter : nullptr,            \
-                       bases->vec_col_stride, b0)
+                       bases->vec_col_stride, b0, xv, xc)
             if (acc_threads == 128) BZH_LAUNCH_ACC(128);
             else if (acc_threads == 512) BZH_LAUNCH_ACC(512);
             else BZH_LAUNCH_ACC(256);
