@@ -198,13 +198,15 @@ def test_msm_precomputed_2_16_matches_oracle(gpu_ctx, oracle_c):
     assert gpu_msm_compressed(bzh2, gpu_ctx, 0, bases, sc, precompute=0) == oracle_compressed(0, bases, sc)
 
 
-def test_msm_precomputed_many_vectors_chunk_presum(gpu_ctx, oracle_c):
-    """Throughput regime of the window-table MSM: 24 vectors of 2^14 + 2 scalars (an advice-commitment launch of a
+@pytest.mark.parametrize("nvec", [24, 13])
+def test_msm_precomputed_many_vectors_chunk_presum(gpu_ctx, oracle_c, nvec):
+    """Throughput regime of the window-table MSM: 24 (13) vectors of 2^14 + 2 scalars (an advice-commitment launch of a
     lockstep proof batch) cut into >= 256 chunk segments, whose bucket sets are summed per vector before the
-    running-sum reduction (k_msm_chunksum).  Skewed vectors included; every result against the C oracle."""
+    running-sum reduction (k_msm_chunksum); the accumulate workgroups run in the XCD-aware order (8 runs of (chunk, vector)
+    pairs; 13 vectors leave the runs ragged).  Skewed vectors included; every result against the C oracle."""
     import bzh2
-    rng = np.random.default_rng(141)
-    n, nvec = (1 << 14) + 2, 24
+    rng = np.random.default_rng(141 + nvec)
+    n = (1 << 14) + 2
     bases = walk_bases(0, n, seed=5)
     hb = gpu_ctx.upload_bases(0, bases).precompute(11)
     try:
