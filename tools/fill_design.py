@@ -76,10 +76,13 @@ Roofline of the dominant kernel `k_msm_accumulate` (HBM, as `north_star` asks), 
 the GPU, is kept beside it as `timed_region_average`): @ALG@ MB algorithmic per launch / @ACCMS@ ms = @ACCGB@ GB/s = **@FRAC@ of
 8 TB/s**; whole GPU over the timed region (`roofline.whole_gpu`): @WADD@ G mixed additions/s + @WMUL@ G quotient multiplications/s
 = @WFRAC@ of the chip's issue slots at the two yardsticks.  PMC traffic (`profiles/@TAG@_proof_k14_pmc_traffic.json`, separate
-FETCH_SIZE / WRITE_SIZE passes): `k_msm_accumulate` @TRAFFIC@ GB per launch ≈ @TRATIO@ × algorithmic.  The floor of a window-table MSM
-is 16 ×: every scalar becomes 24 digits and every digit gathers its own 64-byte point (1 536 B against the 96 B the
-algorithmic count sees) from a 25 MB table that does not fit the 4 MB L2 of an XCD; the rest is one bucket set per 32 768-item
-chunk written and re-read by the pre-sum.  The quotient fetches 14 × (§4).  Neither is the limiter: 117 GB/s of algorithmic
+FETCH_SIZE / WRITE_SIZE passes): `k_msm_accumulate` @TRAFFIC@ GB per launch ≈ @TRATIO@ × algorithmic (@TREAD@ GB fetched + @TWRITE@ GB
+written; round 2: 1.74 GB, this round before the XCD-aware order: 0.73 + 0.59).  Every scalar becomes 24 digits and every digit
+gathers its own 64-byte point (1 536 B against the 96 B the algorithmic count sees) from a 25 MB table; in plain grid order the
+512 resident workgroups gather from eight 2 MB windows of it per XCD and every gather misses the 4 MB L2.  **XCD-aware order**
+(§4): one run of (chunk, vector) pairs per XCD, one or two windows live per L2 — 61 % fewer bytes fetched at the same launch
+time (the kernel is issue-bound).  What remains is the writes: one 1 024-bucket XYZZ set per 32 768-item chunk and vector,
+re-read by the pre-sum.  The quotient fetches 14 × (§4).  Neither is the limiter: 117 GB/s of algorithmic
 bytes, ≈ 3 TB/s at the fabric.
 
 '''
@@ -97,7 +100,7 @@ def main():
         return sum(float(x["TotalDurationNs"]) for x in rows if name in x["Name"]) / 1e6 / nb
     ktable = ("`k_msm_accumulate` %.1f ms (%.0f %%) [59.7], the quotient `bzh_quotient_…` %.1f (%.0f %%) [36.5], `k_ntt_pass_wave` + `k_ntt_pass` %.1f [13.3], "
               "the collapse `k_collapse_generators` %.1f + `k_expand_rows_shared_inverse` %.1f [—], chunk pre-sum + reductions + final sums %.1f [13.5], "
-              "Kate division %.1f [6.1], staging copies `k_xfer16` %.1f; sum of all kernels %.0f ms [146]." % (
+              "Kate division %.1f [6.1 in round 2: §4], staging copies `k_xfer16` %.1f; sum of all kernels %.0f ms [146]." % (
                   per("k_msm_accumulate"), 100 * per("k_msm_accumulate") / tot, per("bzh_quotient"), 100 * per("bzh_quotient") / tot, per("k_ntt_pass"),
                   per("k_collapse_generators"), per("k_expand_rows"), per("k_msm_chunksum") + per("k_msm_reduce") + per("k_msm_finalize"),
                   per("k_kate"), per("k_xfer16"), tot))
@@ -121,6 +124,8 @@ def main():
         "@KTABLE@": ktable, "@ALG@": "%.1f" % (r["algorithmic_bytes_per_launch"] / 1e6), "@ACCMS@": "%.2f" % r["avg_launch_ms"],
         "@ACCGB@": "%.1f" % r["achieved"], "@FRAC@": "%.2f %%" % (100 * r["frac"]), "@WADD@": "%.2f" % w["G_mixed_additions_per_s"],
         "@WMUL@": "%.0f" % w["G_quotient_multiplications_per_s"], "@WFRAC@": "%.0f %%" % (100 * w["accumulate_plus_quotient_frac_of_alu_time"]),
+        "@TREAD@": "%.2f" % (sum(e["read_bytes_raw"] * e.get("launches", 1) for e in acc) / L / 1e9),
+        "@TWRITE@": "%.2f" % (sum(e["write_bytes"] * e.get("launches", 1) for e in acc) / L / 1e9),
         "@TRAFFIC@": "%.2f" % (T / 1e9), "@TRATIO@": "%.0f" % (T / r["algorithmic_bytes_per_launch"]), "@HBM@": "%s" % d["config"].get("hbm_in_use_GB"),
         "@TAG@": TAG,
     }
