@@ -85,3 +85,19 @@ def shot_circuits(Cm, seed, count):
         x, y = rng.randrange(10), rng.randrange(10)
         out.append(Cm.ShotCircuit(state, rng.randrange(O.FQ.p), Cm.shot_serialize([x], [y]), BinaryValue.from_u8(1 if (x, y) in used else 0)))
     return out
+
+
+def accelerated_oracle(fn):
+    """Decorator for tests whose oracle side (keys, create_proof, verify_proof of oracle/halo2_oracle.py) would spend tens of
+    seconds in big-int group arithmetic: run the test inside `accel.accelerated(THREADS)`, i.e. with the oracle's MSMs, NTTs,
+    Horner sums and generator folds handed to the C oracle.  tests/test_oracle_accel_cpu.py pins the accelerated oracle to the
+    big-int one byte for byte; every protocol decision stays in halo2_oracle."""
+    import functools
+
+    import accel
+
+    @functools.wraps(fn)
+    def run(*a, **kw):
+        with accel.accelerated(THREADS):
+            return fn(*a, **kw)
+    return run

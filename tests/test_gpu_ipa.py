@@ -12,6 +12,7 @@ import pytest
 
 import coracle as C
 import pasta as O
+from helpers.real_parity import accelerated_oracle
 
 pytestmark = pytest.mark.gpu
 
@@ -72,6 +73,7 @@ def test_ipa_open_bytes_match_oracle_and_verify(gpu_ctx, cid, k, precompute):
 
 
 @pytest.mark.parametrize("k,batch", [(3, 4), (6, 3)])
+@accelerated_oracle
 def test_ipa_open_batch_matches_per_proof_oracle(gpu_ctx, k, batch):
     """bzh_ipa_open_batch: independent openings in lockstep, each with its own polynomial, blind, point, randomness
     and transcript state, must emit exactly the bytes the oracle emits for that opening alone."""

@@ -11,6 +11,7 @@ import coracle as C
 import halo2_oracle as H
 import pasta as O
 import sample_circuit as S
+from helpers.real_parity import accelerated_oracle
 
 pytestmark = pytest.mark.gpu
 
@@ -27,6 +28,7 @@ def _adv_array(adv, n):
 
 
 @pytest.mark.parametrize("k,with_lookup,degree,batch", [(4, False, None, 1), (5, True, None, 3), (6, True, 9, 2)])
+@accelerated_oracle
 def test_native_prove_batch_matches_oracle(gpu_ctx, oracle_c, k, with_lookup, degree, batch):
     import bzh2
     from bzh2 import native as N, circuit_data as P
@@ -58,6 +60,7 @@ def test_native_prove_batch_matches_oracle(gpu_ctx, oracle_c, k, with_lookup, de
         pk.close()
 
 
+@accelerated_oracle
 def test_native_prover_battlezips_shaped_and_unsatisfied_witness(gpu_ctx, oracle_c):
     """The benchmark circuit (tests/helpers/synth.py) at k = 7 through the native entry point; a broken witness must come back
     as BZH_E_RANGE (surplus quotient coefficients) or as a proof the oracle verifier rejects."""
@@ -95,6 +98,7 @@ def test_native_prover_battlezips_shaped_and_unsatisfied_witness(gpu_ctx, oracle
 
 
 @pytest.mark.parametrize("k,with_lookup,degree", [(4, False, None), (5, True, None), (6, True, 9)])
+@accelerated_oracle
 def test_native_verify_batch_agrees_with_oracle_verifier(gpu_ctx, oracle_c, k, with_lookup, degree):
     """bzh_verify_batch (verify_proof, benches/board.rs:80-86): accepts exactly what the big-int oracle verifier accepts --
     valid proofs (made by the ORACLE prover, so prover and verifier here are independent), and rejects a wrong instance,
@@ -125,9 +129,7 @@ def test_native_verify_batch_agrees_with_oracle_verifier(gpu_ctx, oracle_c, k, w
         ipa_start = len(good) - 32 * (2 * k + 3)
         cases.append((inst, good[:ipa_start] + bytes(32) + good[ipa_start + 32:]))   # identity as the IPA's S
         got = pk.verify_batch([c[0] for c in cases], [c[1] for c in cases])
-        import accel as A
-        with A.accelerated(8):     # the oracle verifier's MSMs / Horner sums through the C oracle (pinned to the big-int code in
-            want = [H.verify_proof(keys, c[0], c[1], O.Blake2bTranscript(F)) for c in cases]   # tests/test_oracle_accel_cpu.py)
+        want = [H.verify_proof(keys, c[0], c[1], O.Blake2bTranscript(F)) for c in cases]
         assert got == want
         assert got[0] is True and not any(got[1:])
     finally:

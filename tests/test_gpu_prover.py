@@ -9,6 +9,7 @@ import pytest
 import halo2_oracle as H
 import pasta as O
 import sample_circuit as S
+from helpers.real_parity import accelerated_oracle
 
 pytestmark = pytest.mark.gpu
 
@@ -96,6 +97,7 @@ def test_device_resident_prover_bytes_match_oracle(stream_ctx, oracle_c, k, with
     assert H.verify_proof(keys, inst, got, O.Blake2bTranscript(F))
 
 
+@accelerated_oracle
 def test_battlezips_shaped_circuit_proof_matches_oracle(stream_ctx, oracle_c):
     """The benchmark circuit (tests/helpers/synth.py: 11 advice / 8 fixed / 13 permutation columns / degree 9 / one lookup /
     24 gates) at k = 7: device-resident proof == oracle proof, and the oracle verifier accepts it."""

@@ -81,7 +81,8 @@ def test_real_circuit_proofs_are_the_oracle_provers_bytes(gpu_ctx, oracle_c, kin
 def test_real_board_circuit_production_at_bench_sizes(gpu_ctx, oracle_c, k, batch):
     """src/circuits/board.rs:879-933 (`production`: keygen -> create_proof -> verify_proof of the real BoardCircuit) at the
     metric's larger sizes: a batch of distinct fleets proved with per-proof seeds (the bench's path), every proof accepted by
-    the native verifier, one by the oracle verifier, a tampered copy and a swapped instance rejected by both; at k = 17 the
+    the native verifier, one by the oracle verifier, a tampered copy and a swapped instance rejected by both (by the oracle at
+    k = 14 only); at k = 17 the
     first proof of the batch of 8 is additionally the golden oracle-prover proof byte for byte -- in the batch (generator
     collapse active) and alone."""
     from bzh2 import circuits as Cm
@@ -99,8 +100,9 @@ def test_real_board_circuit_production_at_bench_sizes(gpu_ctx, oracle_c, k, batc
         with A.accelerated(R.THREADS):
             keys = R.oracle_keys(lay.blob(), R.points_of(g_arr), w, u, verifier_only=True)
             assert H.verify_proof(keys, insts[1], proofs[1], O.Blake2bTranscript(O.FP))
-            assert not H.verify_proof(keys, insts[1], bad, O.Blake2bTranscript(O.FP))
-            assert not H.verify_proof(keys, insts[0], proofs[1], O.Blake2bTranscript(O.FP))
+            if k < 17:   # (the rejections are k-independent; at k = 17 each oracle verification costs ~8 s of host time)
+                assert not H.verify_proof(keys, insts[1], bad, O.Blake2bTranscript(O.FP))
+                assert not H.verify_proof(keys, insts[0], proofs[1], O.Blake2bTranscript(O.FP))
         gold = [e for e in json.load(open(GOLDEN)) if e["kind"] == "board" and e["k"] == k]
         if k == 17:
             assert gold, "tests/golden/real_proofs.json has no k = 17 entry"
