@@ -57,6 +57,33 @@ struct Prover {
     }
     // host Montgomery elements -> device
     int upload(uint32_t* dst, const Fe<SF>* src, size_t elems) { return h2d_small(ctx, dst, src, elems * 32); }
+    // an expression program's four host-side pieces -- constants | instructions | column pointers | column strides -- laid out
+    // 256-byte aligned in one arena block and sent with ONE staging copy (they were four: ~130 of a proof's ~145 small uploads)
+    struct ProgramArgs {
+        uint32_t* consts = nullptr;
+        char *prog = nullptr, *ptrs = nullptr, *strides = nullptr;
+    };
+    int upload_program(const void* cv, size_t cv_bytes, const void* ops, size_t op_bytes, const void* ptrs, const void* strides, size_t ncols,
+                       ProgramArgs& out) {
+        auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+        const size_t o_prog = al(cv_bytes), o_ptrs = o_prog + al(op_bytes), o_strides = o_ptrs + al(ncols * 8), total = o_strides + al(ncols * 8);
+        char* dev = (char*)arena.alloc(total);
+        if (!dev) return BZH_E_OOM;
+        char* slot = nullptr;
+        PV_TRY(h2d_stage(ctx, total, &slot));
+        memcpy(slot, cv, cv_bytes);
+        memcpy(slot + o_prog, ops, op_bytes);
+        if (ncols) {
+            memcpy(slot + o_ptrs, ptrs, ncols * 8);
+            memcpy(slot + o_strides, strides, ncols * 8);
+        }
+        PV_TRY(h2d_commit(ctx, dev, slot, total));
+        out.consts = (uint32_t*)dev;
+        out.prog = dev + o_prog;
+        out.ptrs = dev + o_ptrs;
+        out.strides = dev + o_strides;
+        return BZH_OK;
+    }
 
     Fe<SF> draw(size_t b) {
         if (seeded) {
@@ -225,16 +252,10 @@ struct Prover {
                     memcpy(&cv[(b * nc + i) * 8], c.val, 32);
                 }
             }
-        char* stage = (char*)arena.alloc(cv.size() * 4 + pg.ops.size() * sizeof(bzh_expr_op) + ncols * 16 + 1024);
-        if (!stage) return BZH_E_OOM;
-        uint32_t* d_consts = (uint32_t*)stage;
-        char* d_prog = stage + ((cv.size() * 4 + 255) & ~(size_t)255);
-        char* d_ptrs = d_prog + ((pg.ops.size() * sizeof(bzh_expr_op) + 255) & ~(size_t)255);
-        char* d_strides = d_ptrs + ((ncols * 8 + 255) & ~(size_t)255);
-        PV_TRY(h2d_small(ctx, d_consts, cv.data(), cv.size() * 4));
-        PV_TRY(h2d_small(ctx, d_prog, pg.ops.data(), pg.ops.size() * sizeof(bzh_expr_op)));
-        PV_TRY(h2d_small(ctx, d_ptrs, reg.ptr.data(), ncols * 8));
-        PV_TRY(h2d_small(ctx, d_strides, reg.stride.data(), ncols * 8));
+        ProgramArgs pa;
+        PV_TRY(upload_program(cv.data(), cv.size() * 4, pg.ops.data(), pg.ops.size() * sizeof(bzh_expr_op), reg.ptr.data(), reg.stride.data(), ncols, pa));
+        uint32_t* d_consts = pa.consts;
+        char *d_prog = pa.prog, *d_ptrs = pa.ptrs, *d_strides = pa.strides;
         int nslots = pg.result_slot + 1;
         for (auto& o : pg.ops) nslots = std::max(nslots, (int)o.dst + 1);  // operands only read slots written before
         return expr_eval(ctx, field, d_prog, (int)pg.ops.size(), (const uint32_t* const*)d_ptrs, (const size_t*)d_strides, d_consts,
@@ -274,16 +295,10 @@ struct Prover {
                     memcpy(&cv[(b * nc + i) * 8], c.val, 32);
                 }
             }
-        char* stage = (char*)arena.alloc(cv.size() * 4 + pg.ops.size() * sizeof(ExprOp2) + ncols * 16 + 1024);
-        if (!stage) return BZH_E_OOM;
-        uint32_t* d_consts = (uint32_t*)stage;
-        char* d_prog = stage + ((cv.size() * 4 + 255) & ~(size_t)255);
-        char* d_ptrs = d_prog + ((pg.ops.size() * sizeof(ExprOp2) + 255) & ~(size_t)255);
-        char* d_strides = d_ptrs + ((ncols * 8 + 255) & ~(size_t)255);
-        PV_TRY(h2d_small(ctx, d_consts, cv.data(), cv.size() * 4));
-        PV_TRY(h2d_small(ctx, d_prog, pg.ops.data(), pg.ops.size() * sizeof(ExprOp2)));
-        PV_TRY(h2d_small(ctx, d_ptrs, ptrs.data(), ncols * 8));
-        PV_TRY(h2d_small(ctx, d_strides, strides.data(), ncols * 8));
+        ProgramArgs pa;
+        PV_TRY(upload_program(cv.data(), cv.size() * 4, pg.ops.data(), pg.ops.size() * sizeof(ExprOp2), ptrs.data(), strides.data(), ncols, pa));
+        uint32_t* d_consts = pa.consts;
+        char *d_prog = pa.prog, *d_ptrs = pa.ptrs, *d_strides = pa.strides;
         if (ctx->profiling) {   // the quotient pass reads every extended column once and writes h: per-proof columns
             double cols_read = 0;   // count per proof, columns of the key once per launch
             for (size_t i = 0; i < reg.stride.size(); i++) cols_read += reg.stride[i] ? (double)B : 1.0;
@@ -882,6 +897,20 @@ int Prover<C>::prove(const uint32_t* d_advice_in, const uint64_t* instances, siz
         PV_TRY(zero(f_parts, B * nq * n));
         PV_TRY(upload(rs_dev, r_small.data(), r_small.size()));
         PV_TRY(copy2d(rcols, n, rs_dev, maxpts, maxpts, B * nq));
+        // the opening points of every division, [set][rotation][proof], in one upload
+        size_t nkate = 0;
+        for (size_t si = 0; si < nq; si++) nkate += pk.rot_sets[si].size();
+        uint32_t* d_xall = dalloc(std::max<size_t>(nkate, 1) * B);
+        if (!d_xall) return BZH_E_OOM;
+        {
+            std::vector<Fe<SF>> xv(nkate * B);
+            size_t at = 0;
+            for (size_t si = 0; si < nq; si++)
+                for (int r : pk.rot_sets[si])
+                    for (size_t b = 0; b < B; b++) xv[at++] = rot(b, r);
+            PV_TRY(upload(d_xall, xv.data(), xv.size()));
+        }
+        size_t kate_at = 0;
         for (size_t si = 0; si < nq; si++) {
             Cols reg;
             reg.add(key(K_MISC, M_Q), q_polys + si * n * 8, nq * n);
@@ -891,11 +920,8 @@ int Prover<C>::prove(const uint32_t* d_advice_in, const uint64_t* instances, siz
             uint32_t* nxt = k_b;
             size_t len = n;
             for (int r : pk.rot_sets[si]) {
-                std::vector<Fe<SF>> xv(B);
-                for (size_t b = 0; b < B; b++) xv[b] = rot(b, r);
-                uint32_t* d_x = dalloc(B);
-                if (!d_x) return BZH_E_OOM;
-                PV_TRY(upload(d_x, xv.data(), B));
+                (void)r;
+                const uint32_t* d_x = d_xall + (kate_at++) * B * 8;
                 PV_TRY(poly_kate_division(ctx, field, cur, len, B, d_x, nxt));
                 std::swap(cur, nxt);
                 len--;
