@@ -37,7 +37,7 @@ afterwards (untimed), every record of the last step encoded / decoded through `b
 | configs[3]: the fixed batch of 256 Board (k = 14) + 2 560 Shot (k = 11), one GPU | @MIXEDFULL@ | `@TAG@_mixed_full_bench.json`; a quarter of it per step: @MIXED@ |
 | `verify_proof`, BoardCircuit k = 14, batches of 64 | @VERIFY@ verifications/s | `@TAG@_verify_k14_b64_bench.json` |
 | C++ client `examples/shot_prover.cpp`, ShotCircuit, one thread, host buffers (PCIe-inclusive), `getrandom` seeds | @EXAMPLE@ (batch 64) | `@TAG@_example_cpp_client.txt` |
-| CPU baseline (C oracle, 16 cores, whole proof) | @CPU@ | @CPUNOTE@ (this box; 0.39–0.54 over the round's boxes) |
+| CPU baseline (C oracle, 16 cores, whole proof) | @CPU@ | @CPUNOTE@ (this box; every stage timed in full — the quotient over all 2^17 rows, all 14 IPA rounds; 0.65–0.70 over the round's boxes) |
 | microbenches (config 5), Vesta / Pallas / BN254: MSM 2^24 | @MSM24@ ms | `@TAG@_msm24_{vesta,pallas,bn254}_bench.json` |
 | NTT 2^22 over Fp / Fq / BN254 Fr | @NTT22@ ms | `@TAG@_ntt22_*_bench.json`; round 2 (Fp): 0.61 |
 
