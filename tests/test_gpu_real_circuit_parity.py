@@ -119,3 +119,29 @@ def test_real_board_circuit_production_at_bench_sizes(gpu_ctx, oracle_c, k, batc
         pk.close()
         prm.close()
         lay.close()
+
+
+@pytest.mark.parametrize("kind,k,batch", [("shot", 11, 5), ("shot", 11, 9), ("board", 12, 13)])
+def test_a_proof_does_not_depend_on_the_batch_it_was_made_in(gpu_ctx, oracle_c, kind, k, batch):
+    """Lockstep batching is an implementation detail (benches/board.rs proves one circuit per create_proof call): proof b of a
+    batch must be the proof the same witness and randomness give alone.  Odd batch sizes on purpose -- 9 and 13 vectors put the
+    accumulate kernel's XCD runs, the chunk pre-sum, the generator collapse (batch >= 8) and the per-proof tables on ragged
+    shapes; 5 stays below the collapse threshold.  Seeded path (the bench's) and explicit-stream path."""
+    from bzh2 import circuits as Cm
+    lay, prm, pk = _setup(gpu_ctx, kind, k)
+    try:
+        circuits = (R.shot_circuits if kind == "shot" else R.board_circuits)(Cm, 31 * k + batch, batch)
+        adv, insts = lay.synthesize(circuits)
+        seeds = [R.rng_stream("inv-%s-%d-%d" % (kind, batch, b), 32) for b in range(batch)]
+        together = pk.prove_batch(adv, insts, None, seeds=seeds)
+        assert len(set(together)) == batch and pk.verify_batch(insts, together) == [True] * batch
+        for b in (0, batch // 2, batch - 1):
+            assert pk.prove_batch(adv[b:b + 1], insts[b:b + 1], None, seeds=seeds[b:b + 1])[0] == together[b], b
+        streams = [R.rng_stream("inv-stream-%s-%d-%d" % (kind, batch, b), pk.rng_bytes) for b in range(batch)]
+        together = pk.prove_batch(adv, insts, streams)
+        half = batch // 2
+        assert pk.prove_batch(adv[:half], insts[:half], streams[:half]) + pk.prove_batch(adv[half:], insts[half:], streams[half:]) == together
+    finally:
+        pk.close()
+        prm.close()
+        lay.close()
