@@ -890,43 +890,57 @@ int Prover<C>::prove(const uint32_t* d_advice_in, const uint64_t* instances, siz
         uint32_t* rcols = dalloc(B * nq * n);
         uint32_t* rs_dev = dalloc(B * nq * maxpts);
         uint32_t* f_parts = dalloc(B * nq * n);
-        uint32_t* k_a = dalloc(B * n);
-        uint32_t* k_b = dalloc(B * n);
+        uint32_t* k_a = dalloc(B * nq * n);
+        uint32_t* k_b = dalloc(B * nq * n);
         if (!rcols || !rs_dev || !f_parts || !k_a || !k_b) return BZH_E_OOM;
         PV_TRY(zero(rcols, B * nq * n));
         PV_TRY(zero(f_parts, B * nq * n));
         PV_TRY(upload(rs_dev, r_small.data(), r_small.size()));
         PV_TRY(copy2d(rcols, n, rs_dev, maxpts, maxpts, B * nq));
-        // the opening points of every division, [set][rotation][proof], in one upload
+        // (q_si - r_si) / prod_(r in set si) (X - x w^r): one division per point, chained within a set, independent between sets.
+        // The sets are ordered by the number of their points (most first) and step t divides every set that still has a t-th
+        // point in ONE launch: all of them hold n - t coefficients at that step and they are a prefix of the order, so the
+        // vectors [position][proof] stay densely packed from step to step.  (Was one launch chain per set: 16 divisions -> 4.)
+        std::vector<size_t> order(nq);
+        for (size_t si = 0; si < nq; si++) order[si] = si;
+        std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return pk.rot_sets[x].size() > pk.rot_sets[y].size(); });
+        const size_t steps = nq ? pk.rot_sets[order[0]].size() : 0;
         size_t nkate = 0;
         for (size_t si = 0; si < nq; si++) nkate += pk.rot_sets[si].size();
         uint32_t* d_xall = dalloc(std::max<size_t>(nkate, 1) * B);
         if (!d_xall) return BZH_E_OOM;
-        {
+        {   // the opening points, [step][position][proof], in one upload
             std::vector<Fe<SF>> xv(nkate * B);
             size_t at = 0;
-            for (size_t si = 0; si < nq; si++)
-                for (int r : pk.rot_sets[si])
-                    for (size_t b = 0; b < B; b++) xv[at++] = rot(b, r);
+            for (size_t t = 0; t < steps; t++)
+                for (size_t pos = 0; pos < nq && pk.rot_sets[order[pos]].size() > t; pos++)
+                    for (size_t b = 0; b < B; b++) xv[at++] = rot(b, pk.rot_sets[order[pos]][t]);
             PV_TRY(upload(d_xall, xv.data(), xv.size()));
         }
-        size_t kate_at = 0;
-        for (size_t si = 0; si < nq; si++) {
+        for (size_t pos = 0; pos < nq; pos++) {
+            const size_t si = order[pos];
             Cols reg;
             reg.add(key(K_MISC, M_Q), q_polys + si * n * 8, nq * n);
             reg.add(key(K_MISC, M_R), rcols + si * n * 8, nq * n);
-            PV_TRY(run(key(42, 0), [&](EPool& ep) { return ep.sub(ep.query(0), ep.query(1)); }, reg, n, k_a));
+            PV_TRY(run(key(42, 0), [&](EPool& ep) { return ep.sub(ep.query(0), ep.query(1)); }, reg, n, k_a + pos * B * n * 8));
+        }
+        {
             uint32_t* cur = k_a;
             uint32_t* nxt = k_b;
-            size_t len = n;
-            for (int r : pk.rot_sets[si]) {
-                (void)r;
-                const uint32_t* d_x = d_xall + (kate_at++) * B * 8;
-                PV_TRY(poly_kate_division(ctx, field, cur, len, B, d_x, nxt));
+            size_t len = n, x_at = 0;
+            for (size_t t = 0; t < steps; t++) {
+                size_t active = 0;
+                while (active < nq && pk.rot_sets[order[active]].size() > t) active++;
+                PV_TRY(poly_kate_division(ctx, field, cur, len, active * B, d_xall + x_at * 8, nxt));
+                x_at += active * B;
                 std::swap(cur, nxt);
                 len--;
+                for (size_t pos = 0; pos < active; pos++)   // the sets whose last point this was
+                    if (pk.rot_sets[order[pos]].size() == t + 1)
+                        PV_TRY(copy2d(f_parts + order[pos] * n * 8, nq * n, cur + pos * B * len * 8, len, len, B));
             }
-            PV_TRY(copy2d(f_parts + si * n * 8, nq * n, cur, len, len, B));
+            for (size_t pos = 0; pos < nq; pos++)   // a set without points (not produced by the key builder): q - r itself
+                if (pk.rot_sets[order[pos]].empty()) PV_TRY(copy2d(f_parts + order[pos] * n * 8, nq * n, k_a + pos * B * n * 8, n, n, B));
         }
         mark("multiopen_q_kate");
         // f = sum_si x2^(..) f_si (Horner), commit, x3, q evaluations, x4, the opened polynomial
