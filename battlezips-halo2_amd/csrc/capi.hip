@@ -184,13 +184,40 @@ static int permute_pair_host(const uint64_t* input, const uint64_t* table, size_
             store_host<PP>(t[i].l, load_host<PP>(table + 4 * i, form), BZH_FORM_CANONICAL);
         }
     }
+    // values below 2^64 (range tables, compressed small columns -- the reference's lookups): sort the low limbs as integers
+    auto sort_keys = [](std::vector<Key>& v) {
+        bool small = true;
+        for (const Key& k : v)
+            if (k.l[1] | k.l[2] | k.l[3]) {
+                small = false;
+                break;
+            }
+        if (!small) {
+            std::sort(v.begin(), v.end());
+            return;
+        }
+        uint64_t mx = 0;
+        for (const Key& k : v) mx = std::max(mx, k.l[0]);
+        if (mx < 65536 && v.size() >= 256) {   // a histogram does it (10-bit range table: 1 024 distinct values)
+            std::vector<uint32_t> cnt(mx + 1, 0);
+            for (const Key& k : v) cnt[k.l[0]]++;
+            size_t at = 0;
+            for (uint64_t val = 0; val <= mx; val++)
+                for (uint32_t c = cnt[val]; c; c--) v[at++].l[0] = val;
+            return;
+        }
+        std::vector<uint64_t> lo(v.size());
+        for (size_t i = 0; i < v.size(); i++) lo[i] = v[i].l[0];
+        std::sort(lo.begin(), lo.end());
+        for (size_t i = 0; i < v.size(); i++) v[i].l[0] = lo[i];
+    };
     if (usable >= 4096) {  // the two sorts are independent: a second thread takes the table
-        std::thread other([&]() { std::sort(t.begin(), t.end()); });
-        std::sort(a.begin(), a.end());
+        std::thread other([&]() { sort_keys(t); });
+        sort_keys(a);
         other.join();
     } else {
-        std::sort(a.begin(), a.end());
-        std::sort(t.begin(), t.end());
+        sort_keys(a);
+        sort_keys(t);
     }
     // leftover multiset = table minus one copy of every distinct input value
     std::vector<Key> s(usable);

@@ -43,3 +43,20 @@ def test_input_outside_table_is_an_error(bzh2_lib):
     with pytest.raises(bzh2_lib.BzhError) as e:
         bzh2_lib.permute_expression_pair(0, C.ints_to_array([1, 2, 99]), C.ints_to_array([1, 2, 3]), 3)
     assert e.value.status == bzh2_lib.E_RANGE
+
+
+@pytest.mark.parametrize("bits", [10, 20])
+def test_permute_at_the_reference_lookup_shape(bzh2_lib, bits):
+    """The shape the BoardCircuit's lookup has at k = 14: 16 378 usable rows, a 10-bit range table repeated down the column,
+    an input column that is zero outside the 2 399 used rows (values below 2^16 take the histogram path of the host sort,
+    below 2^64 the integer sort; both against the oracle's restatement)."""
+    F = O.FP
+    usable = 16378
+    rng = random.Random(77 + bits)
+    table = [i % (1 << bits) for i in range(usable)]
+    inp = [0] * usable
+    for i in range(2399):
+        inp[i] = rng.randrange(min(1 << bits, usable))
+    a, s = O.permute_expression_pair(inp, table, usable, F)
+    ga, gs = bzh2_lib.permute_expression_pair(0, C.ints_to_array(inp + [0] * 6), C.ints_to_array(table + [0] * 6), usable)
+    assert C.array_to_ints(ga)[:usable] == a and C.array_to_ints(gs)[:usable] == s
