@@ -498,17 +498,30 @@ int Prover<C>::prove(const uint32_t* d_advice_in, const uint64_t* instances, siz
     uint32_t* zs = dalloc(B * std::max(nz, 1) * n);
     uint32_t* z_polys = dalloc(B * std::max(nz, 1) * n);
     uint32_t* z_cosets = dalloc(B * std::max(nz, 1) * en);
-    uint32_t* den = dalloc(B * n);
-    uint32_t* zt = dalloc(B * n);
-    if (!zs || !z_polys || !z_cosets || !den || !zt) return BZH_E_OOM;
+    // numerators and denominators of ALL grand products side by side, [product][proof][row]: one batch inversion, one
+    // element-wise product and one scan for the lot (they were per product; the permutation sets are chained only through a
+    // scalar carried from one set's last row into the next, applied afterwards)
+    uint32_t* den_all = dalloc(B * std::max(nz, 1) * n);
+    uint32_t* zt_all = dalloc(B * std::max(nz, 1) * n);
+    if (!zs || !z_polys || !z_cosets || !den_all || !zt_all) return BZH_E_OOM;
+    uint32_t* den = den_all;
+    uint32_t* zt = zt_all;
+    auto product_slot = [&](int slot) {
+        den = den_all + (size_t)slot * B * n * 8;
+        zt = zt_all + (size_t)slot * B * n * 8;
+    };
     std::vector<Fe<SF>> z_blinds(B * std::max(nz, 1));
-    auto finish_product = [&](int slot, int prev_slot) -> int {
+    auto invert_and_scan_all = [&]() -> int {
         mark("  fp:exprs");
-        PV_TRY(poly_batch_invert(ctx, field, den, B * n));
+        PV_TRY(poly_batch_invert(ctx, field, den_all, (size_t)nz * B * n));
         mark("  fp:invert");
-        PV_TRY(poly_vec_mul(ctx, field, zt, den, B * n));
-        PV_TRY(poly_prefix_product(ctx, field, zt, n, B));
+        PV_TRY(poly_vec_mul(ctx, field, zt_all, den_all, (size_t)nz * B * n));
+        PV_TRY(poly_prefix_product(ctx, field, zt_all, n, (size_t)nz * B));
         mark("  fp:mul+scan");
+        return BZH_OK;
+    };
+    auto finish_product = [&](int slot, int prev_slot) -> int {
+        product_slot(slot);
         if (prev_slot >= 0)
             hipLaunchKernelGGL((k_scale_rows<SF>), dim3((unsigned)((n + 255) / 256), (unsigned)B), dim3(256), 0, st, zt, n,
                                zs + ((size_t)prev_slot * n + usable) * 8, (size_t)nz * n);
@@ -526,6 +539,7 @@ int Prover<C>::prove(const uint32_t* d_advice_in, const uint64_t* instances, siz
     };
     for (int i = 0; i < nsets; i++) {
         const size_t c0 = (size_t)i * pk.chunk_len, c1 = std::min(m, c0 + pk.chunk_len);
+        product_slot(i);
         Cols reg;
         for (size_t gj = c0; gj < c1; gj++) {
             lag_col(reg, pk.perm_columns[gj]);
@@ -544,10 +558,10 @@ int Prover<C>::prove(const uint32_t* d_advice_in, const uint64_t* instances, siz
                 return acc;
             }, reg, n, which == 0 ? den : zt));
         }
-        PV_TRY(finish_product(i, i ? i - 1 : -1));
         mark(" gp:perm_set");
     }
     for (int li = 0; li < nl; li++) {
+        product_slot(nsets + li);
         Cols reg;
         reg.add(key(K_MISC, M_AC), lk[li].a_c, n);
         reg.add(key(K_MISC, M_SC), lk[li].s_c, n);
@@ -559,10 +573,13 @@ int Prover<C>::prove(const uint32_t* d_advice_in, const uint64_t* instances, siz
         PV_TRY(run(key(33, li), [&](EPool& ep) {
             return ep.mul(ep.add(ep.query(2), ep.sym(SY_BETA)), ep.add(ep.query(3), ep.sym(SY_GAMMA)));
         }, reg, n, den));
-        PV_TRY(finish_product(nsets + li, -1));
         mark(" gp:lookup_product");
     }
     if (nz) {
+        PV_TRY(invert_and_scan_all());
+        // blinding rows and blinds in the order the products are made upstream: permutation sets, then lookups
+        for (int i = 0; i < nsets; i++) PV_TRY(finish_product(i, i ? i - 1 : -1));
+        for (int li = 0; li < nl; li++) PV_TRY(finish_product(nsets + li, -1));
         PV_TRY(to_coeff(z_polys, zs, B * nz));
         if (pk.srs_lagrange) PV_TRY(commit(zs, n, B * nz, z_blinds, xy, true, (long)usable - 1));
         else PV_TRY(commit(z_polys, n, B * nz, z_blinds, xy));
