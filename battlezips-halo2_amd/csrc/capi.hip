@@ -185,13 +185,13 @@ static int permute_pair_host(const uint64_t* input, const uint64_t* table, size_
         }
     }
     // values below 2^64 (range tables, compressed small columns -- the reference's lookups): sort the low limbs as integers
-    auto sort_keys = [](std::vector<Key>& v) {
-        bool small = true;
+    auto is_small = [](const std::vector<Key>& v) {
         for (const Key& k : v)
-            if (k.l[1] | k.l[2] | k.l[3]) {
-                small = false;
-                break;
-            }
+            if (k.l[1] | k.l[2] | k.l[3]) return false;
+        return true;
+    };
+    const bool small_a = is_small(a), small_t = is_small(t);
+    auto sort_keys = [](std::vector<Key>& v, bool small) {
         if (!small) {
             std::sort(v.begin(), v.end());
             return;
@@ -211,13 +211,13 @@ static int permute_pair_host(const uint64_t* input, const uint64_t* table, size_
         std::sort(lo.begin(), lo.end());
         for (size_t i = 0; i < v.size(); i++) v[i].l[0] = lo[i];
     };
-    if (usable >= 4096) {  // the two sorts are independent: a second thread takes the table
-        std::thread other([&]() { sort_keys(t); });
-        sort_keys(a);
+    if (usable >= 4096 && !(small_a && small_t)) {  // the two sorts are independent: a second thread takes the table
+        std::thread other([&]() { sort_keys(t, small_t); });
+        sort_keys(a, small_a);
         other.join();
-    } else {
-        sort_keys(a);
-        sort_keys(t);
+    } else {   // (integer / histogram sorts take less than starting a thread does)
+        sort_keys(a, small_a);
+        sort_keys(t, small_t);
     }
     // leftover multiset = table minus one copy of every distinct input value
     std::vector<Key> s(usable);

@@ -454,12 +454,13 @@ int Prover<C>::prove(const uint32_t* d_advice_in, const uint64_t* instances, siz
             const size_t nthreads = std::min<size_t>({B, (size_t)std::max(1u, std::thread::hardware_concurrency()), (size_t)8});
             std::vector<int> rcs(B, BZH_OK);
             std::vector<std::thread> th;
-            for (size_t t = 0; t < nthreads; t++)
-                th.emplace_back([&, t]() {
-                    for (size_t b = t; b < B; b += nthreads)
-                        rcs[b] = bzh_permute_expression_pair(field, &ah[b * n * 4], &sh[b * n * 4], usable, BZH_FORM_CANONICAL,
-                                                             as + (b * 2) * n * 4, as + (b * 2 + 1) * n * 4);
-                });
+            auto work = [&](size_t t) {
+                for (size_t b = t; b < B; b += nthreads)
+                    rcs[b] = bzh_permute_expression_pair(field, &ah[b * n * 4], &sh[b * n * 4], usable, BZH_FORM_CANONICAL,
+                                                         as + (b * 2) * n * 4, as + (b * 2 + 1) * n * 4);
+            };
+            for (size_t t = 1; t < nthreads; t++) th.emplace_back(work, t);
+            work(0);   // the calling thread takes a share (a single proof starts no thread at all)
             for (auto& t : th) t.join();
             for (int rc : rcs)
                 if (rc) return rc;
