@@ -27,7 +27,7 @@ afterwards (untimed), every record of the last step encoded / decoded through `b
 
 | configuration | proofs/s | note |
 |---|---|---|
-| BoardCircuit k = 14, 64 × 4 (default) | **@DEFAULT@** | `profiles/@TAG@_proof_k14_default_bench.json`; round 2: 508 |
+| BoardCircuit k = 14, 64 × 4 (default) | **@DEFAULT@** | `profiles/@TAG@_proof_k14_default_bench.json`; round 2: 508.  Boxes of the pool differ by ± 2 %: 602–617 over this round's runs of the final code |
 | this round's steps on that configuration: round-2 code / + in-wave NTT, shared key, builtin quotient kernel / + generator collapse / + grand products shifted | 508 / 511 / 571–576 / 578–587 | `BZH_IPA_COLLAPSE=0`: 509; `BZH_NO_COMMIT_SHIFT=1`: 572 (same box, same run) |
 | BoardCircuit k = 14, 64 × 1 (one batch in flight) | @B64C1@ | @B64C1MS@ ms per batch of 64, kernel time @KSUM@ ms of it (`@TAG@_proof_k14_b64c1_*`); round 2: 426 |
 | BoardCircuit k = 14, one proof at a time (`--batch 1 --concurrency 1`) | @B1C1@ | **@B1C1MS@ ms per proof**, round 2: 16.1 (`@TAG@_proof_k14_b1c1_bench.json`) |
@@ -67,9 +67,15 @@ planner cuts a vector into up to 16 × the minimal number of chunks: `msm_reduce
 3.5 → 2.8 ms per proof.  (The first version chose the operand by `lane == 0 ? … :` chains, which the compiler turned into
 a table in scratch memory — 64 scratch round trips per addition and no gain; lane masks fixed that.)  Also tried: the chunk
 pre-sum + one fused reduction for single vectors (same chain length, no gain); the generator collapse (its per-lane chain of
-≈ 900 additions is 4 ms: taken from batch 8 on only).  What remains is ≈ 30 host round trips (transcript challenges) and the
-22 × ≈ 130 µs accumulate launches; one proof is ≈ 140 × the 16-core CPU port, and the batch is where this hardware is used:
-one proof every 1.7 ms.
+≈ 900 additions is 4 ms: taken from batch 8 on only).  Later in the round, from the stage trace of one proof
+(`BZH_PROVE_TRACE=1`): the three grand products share ONE batch inversion + product + scan (their three 0.25 ms Fermat chains
+became one: −0.9 ms), the multiopen's 16 Kate divisions run as 4 step-wise launches over all query sets (−0.7 ms), the host's
+field multiplication went to 64-bit limbs (8.7 µs instead of 28.7 per Jacobian → affine inversion, ≈ 45 per proof: −0.4 ms) and
+the lookup's host sort to an integer / histogram sort (−0.15 ms): 13.4 → 11.6 ms.  What remains: the opening is 5.1 ms of it —
+14 rounds of ≈ 365 µs that do not shrink with the round (without the collapse every round is a full-width MSM over the fixed
+table: accumulate ≈ 105 + reduce ≈ 100 + final sum ≈ 38 µs, five ≈ 11 µs dependent-launch gaps, ≈ 45 µs of host round trip) —
+then the quotient + its commitment 1.8, the lookup 1.0, the grand products 1.3.  One proof is ≈ 120 × the 16-core CPU port, and
+the batch is where this hardware is used: one proof every 1.6 ms.
 
 Roofline of the dominant kernel `k_msm_accumulate` (HBM, as `north_star` asks), from the one-batch-in-flight durations
 (`roofline.basis` in the bench line; the timed region's own per-launch average, stretched by the three other batches sharing
