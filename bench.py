@@ -144,6 +144,9 @@ def parse():
                     choices=["board_k14", "board_k12", "shot_k11", "board_k17", "shot_k11_batch", "msm24", "msm20", "ntt22",
                              "proof_k11", "proof_k12", "proof_k14", "proof_k17", "verify_k11", "verify_k14", "mixed_board_shot"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timers", action="store_true",
+                    help="latency runs: the timed region runs without the library's HIP event records around its kernel classes (two "
+                         "extra, untimed steps afterwards fill kernel_ms and the roofline instead)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + several ranks on one GPU rehearses the multi-rank path on a single-GPU box (ranks share device "
                          "local_rank %% device_count); the driver's multi-GPU runs use nccl (RCCL)")
@@ -748,7 +751,7 @@ def main():
     all_ctx = [ctx] + [w[1].ctx for w in getattr(wl, "workers", []) if w[0] is not None]
     all_ctx = list({id(c): c for c in all_ctx}.values())
     for c in all_ctx:
-        c.profile(True)
+        c.profile(not args.no_kernel_timers)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         wl.step()
@@ -770,12 +773,27 @@ def main():
             assert len({(r.kind, r.index) for r in decoded}) == len(decoded), "duplicate (kind, index) among the gathered records"
         if args.records_out:
             np.save(args.records_out, recs)
+    profiled_steps = args.steps
+    if args.no_kernel_timers:   # the kernel classes' timings from two extra steps (untimed), scaled to the timed region's step count
+        for c in all_ctx:
+            c.profile(True)
+        profiled_steps = 2
+        for _ in range(profiled_steps):
+            wl.step()
+        barrier()
     timings = ctx.timings()
     msm_adds = sum(c.msm_additions() for c in all_ctx)     # bucket additions actually made in the timed region (all contexts)
     for c in all_ctx[1:]:  # proofs in flight on their own ctx + stream: sum their kernel classes into the report
         for kname, v in c.timings().items():
             for f in v:
                 timings[kname][f] += v[f]
+    if profiled_steps != args.steps:   # totals as if measured over the timed region's steps (per-launch figures are unaffected)
+        f = args.steps / profiled_steps
+        msm_adds = int(msm_adds * f)
+        for v in timings.values():
+            v["ms"] *= f
+            v["launches"] = int(round(v["launches"] * f))
+            v["algorithmic_bytes"] *= f
     for c in all_ctx:
         c.profile(False)
     # The same kernels with ONE batch in flight (two extra, untimed steps on the first context): with several batches
@@ -892,6 +910,8 @@ def main():
                          "algorithmic_bytes_per_launch": alg, "avg_launch_ms": dom_ms, "basis": roofline_basis,
                          "timed_region_average": timed_region},
             "kernel_ms": {kname: v for kname, v in timings.items() if v["launches"]},
+            "kernel_timers": ("HIP event records around every kernel class inside the timed region" if not args.no_kernel_timers else
+                              "none inside the timed region; kernel_ms and roofline from 2 extra untimed steps, scaled to the step count"),
         }
         line["config"]["host_threads_pinned_to_numa_node"] = numa_node
         if (is_full or is_verify or is_mixed) and acc["ms"] > 0:
