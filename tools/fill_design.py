@@ -71,7 +71,11 @@ pre-sum + one fused reduction for single vectors (same chain length, no gain); t
 (`BZH_PROVE_TRACE=1`): the three grand products share ONE batch inversion + product + scan (their three 0.25 ms Fermat chains
 became one: −0.9 ms), the multiopen's 16 Kate divisions run as 4 step-wise launches over all query sets (−0.7 ms), the host's
 field multiplication went to 64-bit limbs (8.7 µs instead of 28.7 per Jacobian → affine inversion, ≈ 45 per proof: −0.4 ms) and
-the lookup's host sort to an integer / histogram sort (−0.15 ms): 13.4 → 11.6 ms.  What remains: the opening is 5.1 ms of it —
+the lookup's host sort to an integer / histogram sort (−0.15 ms): 13.4 → 11.6 ms with the bench's kernel-class timers on, and
+**10.2 ms without them** (`--no-kernel-timers`: the library's HIP event records around every kernel class — what `kernel_ms` and the
+roofline are made of — are stream commands too and cost a single proof ≈ 1.3 ms; the one-at-a-time lines above are measured
+without them, `kernel_ms` there comes from two extra untimed steps; the batch lines keep them: +0.5 %).  What remains: the opening
+is 5.1 ms of it —
 14 rounds of ≈ 365 µs that do not shrink with the round (without the collapse every round is a full-width MSM over the fixed
 table: accumulate ≈ 105 + reduce ≈ 100 + final sum ≈ 38 µs, five ≈ 11 µs dependent-launch gaps, ≈ 45 µs of host round trip) —
 then the quotient + its commitment 1.8, the lookup 1.0, the grand products 1.3.  One proof is ≈ 120 × the 16-core CPU port, and
