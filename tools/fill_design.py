@@ -41,6 +41,9 @@ afterwards (untimed), every record of the last step encoded / decoded through `b
 | microbenches (config 5), Vesta / Pallas / BN254: MSM 2^24 | @MSM24@ ms | `@TAG@_msm24_{vesta,pallas,bn254}_bench.json` |
 | NTT 2^22 over Fp / Fq / BN254 Fr | @NTT22@ ms | `@TAG@_ntt22_*_bench.json`; round 2 (Fp): 0.61 |
 
+(One-at-a-time figures: the product path, `--no-kernel-timers`.  With the bench's event records around every kernel class, as
+round 2 measured its 16.1 / 12.7 / 11.0 / 43 ms: 11.6 / 8.4 / 7.6 / 33 ms.)
+
 Kernel time per batch of 64, one stream (`profiles/@TAG@_proof_k14_b64c1_kernel_stats.csv`, 7 batches; round 2 in brackets):
 @KTABLE@
 With 4 batches in flight the VALU-bound kernels keep their rate and the latency-bound ones (reductions, collapse chains) fill
