@@ -296,7 +296,7 @@ int poly_eval(bzh_ctx* ctx, int field, const uint32_t* coeffs, size_t n, size_t 
 
 // ---------------------------------------------------------------------------
 // kate_division: quotient of p(X) by (X - x).  With d_t = c_(n-1-t) the quotient obeys the Horner recurrence
-// r_k = x r_(k-1) + d_k, q_(n-2-k) = r_k (the remainder r_(n-1) = p(x) is dropped).  One workgroup per polynomial: every
+// r_k = x r_(k-1) + d_k, q_(n-2-k) = r_k (the remainder r_(n-1) = p(x) is dropped).  One workgroup per polynomial span: every
 // thread runs the recurrence over its own contiguous segment of L indices from zero (one multiplication per element),
 // the segment results are combined by a scan of R_t = x^L R_(t-1) + loc_t through LDS (log2(threads) steps), and a
 // second walk over the segment from the carried-in value writes the quotient -- two multiplications per coefficient and no
