@@ -59,7 +59,7 @@ polynomial, f, S, one lookup product, 4 opening rounds) + the collapse: no furth
 protocol's messages.  The remaining levers are arithmetic-level (§7).
 
 **Single proof** (BASELINE configs[0]/[1] as written): **@B1C1MS@ ms at k = 14, @K12B1@ ms at k = 12, @K11B1@ ms at k = 11** (round 2:
-16.1 / 12.7 / 11.0).  `profiles/@TAG@_proof_k14_b1c1_kernel_stats.csv` (≈ 555 launches per proof): a single proof is 22 MSM
+16.1 / 12.7 / 11.0).  `profiles/@TAG@_proof_k14_b1c1_kernel_stats.csv` (≈ 390 launches per proof; round 2: ≈ 555): a single proof is 22 MSM
 launch chains (digits → accumulate → reduce → final sum → host), and the reductions and final sums are dependent chains of
 ≈ 20 XYZZ additions on ONE wave — a wave64 issues one VALU instruction per 4 cycles whatever its lanes hold, so a 3 700-slot
 addition takes 6–8 µs.  Round 3's **latency mode**: when a launch has fewer reduction waves than the chip has SIMDs the
