@@ -480,14 +480,15 @@ class Transcript:
 
 # ---- IPA opening --------------------------------------------------------------------------------
 EXPORTS += ["bzh_ipa_open", "bzh_ipa_open_batch", "bzh_ipa_verify"]
-EXPORTS += ["bzh_pk_create", "bzh_pk_free", "bzh_pk_set_lagrange", "bzh_pk_quotient_stats", "bzh_pk_quotient_source", "bzh_pk_set_quotient_module", "bzh_pk_info", "bzh_prove_batch", "bzh_prove_batch_seeded", "bzh_rng_expand", "bzh_verify_batch"]
+EXPORTS += ["bzh_pk_create", "bzh_pk_free", "bzh_pk_set_lagrange", "bzh_pk_quotient_stats", "bzh_pk_quotient_source", "bzh_pk_set_quotient_module", "bzh_pk_info", "bzh_prove_batch", "bzh_prove_batch_seeded", "bzh_rng_expand", "bzh_verify_batch",
+            "bzh_vk_digest", "bzh_pk_vk_repr"]
 # Params::new (bzh2/params.py)
 EXPORTS += ["bzh_hash_to_curve", "bzh_params_generators", "bzh_group_ifft", "bzh_params_create", "bzh_params_free", "bzh_params_bases",
             "bzh_params_points"]
 # circuit front end (bzh2/circuits.py)
 EXPORTS += ["bzh_circuit_create", "bzh_circuit_free", "bzh_circuit_last_error", "bzh_circuit_blob", "bzh_circuit_describe",
             "bzh_circuit_info", "bzh_synthesize_shot", "bzh_synthesize_board", "bzh_synthesize_bitify_test", "bzh_board_witness",
-            "bzh_shot_serialize", "bzh_pedersen_commit_host", "bzh_fixed_base_tables"]
+            "bzh_shot_serialize", "bzh_pedersen_commit_host", "bzh_fixed_base_tables", "bzh_circuit_set_vk_repr", "bzh_circuit_vk_repr"]
 E_VERIFY = -6
 
 

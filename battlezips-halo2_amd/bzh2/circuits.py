@@ -42,6 +42,9 @@ def _bind():
     L.bzh_shot_serialize.argtypes = [_VP, _VP, ctypes.c_size_t, _VP]
     L.bzh_pedersen_commit_host.argtypes = [_VP, _VP, _VP]
     L.bzh_fixed_base_tables.argtypes = [ctypes.c_int, _VP, _VP, _VP]
+    L.bzh_circuit_set_vk_repr.argtypes = [_VP, ctypes.c_char_p]
+    L.bzh_circuit_vk_repr.argtypes = [_VP, _VP, ctypes.POINTER(ctypes.c_int)]
+    L.bzh_vk_digest.argtypes = [ctypes.c_char_p, ctypes.c_size_t, _VP]
     L._bzh_circuits_bound = True
     return L
 
@@ -95,6 +98,19 @@ class CircuitLayout:
         _check(L.bzh_circuit_blob(self.handle, buf, n.value, ctypes.byref(n)), "bzh_circuit_blob")
         return bytes(buf)
 
+    def set_vk_repr(self, vk_repr: int | bytes):
+        """install the verifying-key digest upstream's create_proof / verify_proof absorb first (vk.hash_into): an input of the
+        boundary (include/bzh2.h "THE VERIFYING-KEY DIGEST").  Call before blob() / NativeProvingKey."""
+        raw = vk_repr if isinstance(vk_repr, (bytes, bytearray)) else int(vk_repr).to_bytes(32, "little")
+        assert len(raw) == 32
+        _check(_bind().bzh_circuit_set_vk_repr(self.handle, bytes(raw)), "bzh_circuit_set_vk_repr")
+
+    def vk_repr(self):
+        """(digest as an int, is_placeholder)"""
+        out, ph = (ctypes.c_uint8 * 32)(), ctypes.c_int()
+        _check(_bind().bzh_circuit_vk_repr(self.handle, out, ctypes.byref(ph)), "bzh_circuit_vk_repr")
+        return int.from_bytes(bytes(out), "little"), bool(ph.value)
+
     def describe(self) -> dict:
         L = _bind()
         n = ctypes.c_size_t()
@@ -140,6 +156,14 @@ class CircuitLayout:
         v, b = int_to_limbs(value), int_to_limbs(binary.value)
         _check(_bind().bzh_synthesize_bitify_test(self.handle, _VP(v.ctypes.data), _VP(b.ctypes.data), _VP(adv.ctypes.data)), "bzh_synthesize_bitify_test")
         return adv
+
+
+def vk_digest(pinned_debug: str | bytes) -> int:
+    """VerifyingKey::hash_into's scalar from the text of format!("{:?}", vk.pinned()) (bzh_vk_digest)"""
+    raw = pinned_debug.encode() if isinstance(pinned_debug, str) else bytes(pinned_debug)
+    out = (ctypes.c_uint8 * 32)()
+    _check(_bind().bzh_vk_digest(raw, len(raw), out), "bzh_vk_digest")
+    return int.from_bytes(bytes(out), "little")
 
 
 def board_witness(ships, options=None):

@@ -30,6 +30,7 @@ def _bind():
     L.bzh_prove_batch_seeded.argtypes = [_VP, _VP, ctypes.c_size_t, _VP, ctypes.c_int, ctypes.c_int, _VP, ctypes.c_size_t, ctypes.c_char_p,
                                          _VP, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
     L.bzh_rng_expand.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_size_t, _VP]
+    L.bzh_pk_vk_repr.argtypes = [_VP, _VP, ctypes.POINTER(ctypes.c_int)]
     L._bzh_native_bound = True
     return L
 
@@ -132,6 +133,12 @@ class NativeProvingKey:
         self.rng_bytes, self.max_proof_bytes, self.num_advice, self.n, self.usable_rows = rb.value, mp.value, na.value, nr.value, ur.value
         if params is not None:
             self.set_lagrange(params.bases_lagrange)
+
+    def vk_repr(self):
+        """(the verifying-key digest this key absorbs first, whether it is still the library's placeholder)"""
+        out, ph = (ctypes.c_uint8 * 32)(), ctypes.c_int()
+        self.ctx._check(_bind().bzh_pk_vk_repr(self.handle, out, ctypes.byref(ph)), "bzh_pk_vk_repr")
+        return int.from_bytes(bytes(out), "little"), bool(ph.value)
 
     def quotient_stats(self) -> dict:
         L = _bind()

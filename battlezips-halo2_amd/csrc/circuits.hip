@@ -16,6 +16,7 @@
 #include <sstream>
 #include <thread>
 
+#include "blake2b.hpp"
 #include "circuit/chips.hpp"
 #include "ctx.hpp"
 
@@ -164,6 +165,7 @@ struct bzh_circuit {
     std::vector<uint8_t> blob;
     std::string describe;
     int num_instance_rows = 0;
+    bool vk_placeholder = true;        // the blob's vk_repr field is still BZH_VK_REPR_PLACEHOLDER (bzh_circuit_set_vk_repr not called)
 };
 
 namespace {
@@ -253,7 +255,10 @@ static void build_blob_and_describe(bzh_circuit& c) {
     w.u32((uint32_t)cs.num_fixed);
     w.u32((uint32_t)cs.num_instance);
     w.u32((uint32_t)cs.degree());
-    uint8_t vk_repr[32] = {0x34, 0x12};  // opaque: upstream hashes the vk's Debug string
+    // the verifying-key digest create_proof absorbs first (upstream: vk.hash_into).  It is an INPUT of the boundary
+    // (bzh_circuit_set_vk_repr, include/bzh2.h): a placeholder until the caller hands over the reference-side value.
+    uint8_t vk_repr[32] = {BZH_VK_REPR_PLACEHOLDER & 0xff, BZH_VK_REPR_PLACEHOLDER >> 8};
+    if (w.b.size() != BZH_CIRCUIT_BLOB_VK_REPR_OFFSET) throw std::logic_error("blob header layout");
     w.b.insert(w.b.end(), vk_repr, vk_repr + 32);
     uint32_t npolys = 0;
     for (auto& g : cs.gates) npolys += (uint32_t)g.polys.size();
@@ -500,6 +505,43 @@ int bzh_circuit_info(const bzh_circuit* c, uint32_t* num_advice, uint32_t* num_i
     if (rows_used) *rows_used = (uint32_t)c->rows_used;
     if (num_gates) *num_gates = (uint32_t)c->cs.gates.size();
     if (num_regions) *num_regions = (uint32_t)c->keygen.regions.size();
+    return BZH_OK;
+}
+
+/* the verifying-key digest: halo2_proofs 0.2.0 plonk.rs VerifyingKey::hash_into (UPSTREAM) -- Blake2b-512, personal
+ * "Halo2-Verify-Key", over (len as u64 LE) || format!("{:?}", vk.pinned()), reduced with from_bytes_wide */
+int bzh_vk_digest(const char* pinned_debug, size_t len, uint8_t* out_repr) {
+    if ((!pinned_debug && len) || !out_repr) return BZH_E_ARG;
+    bzh::Blake2b h;
+    h.init(64, (const uint8_t*)"Halo2-Verify-Key");
+    const uint64_t l64 = (uint64_t)len;
+    uint8_t lb[8];
+    for (int i = 0; i < 8; i++) lb[i] = (uint8_t)(l64 >> (8 * i));
+    h.update(lb, 8);
+    h.update((const uint8_t*)pinned_debug, len);
+    uint8_t d[64];
+    h.finalize(d);
+    uint64_t w[8];
+    memcpy(w, d, 64);
+    // from_bytes_wide: the 512-bit little-endian integer mod p = lo + hi * 2^256
+    const Fp lo = Fp::from_raw_reduce({w[0], w[1], w[2], w[3]}), hi = Fp::from_raw_reduce({w[4], w[5], w[6], w[7]});
+    const Fp v = lo + Fp::mul(hi, Fp::r2());   // r2() read as a Montgomery value is R = 2^256
+    v.to_repr(out_repr);
+    return BZH_OK;
+}
+int bzh_circuit_set_vk_repr(bzh_circuit* c, const uint8_t* repr) {
+    if (!c || !repr) return BZH_E_ARG;
+    Fp v;
+    if (!Fp::from_repr(repr, &v)) return BZH_E_RANGE;   // Fp::from_repr(..) is None upstream
+    if (c->blob.size() < BZH_CIRCUIT_BLOB_VK_REPR_OFFSET + 32) return BZH_E_ARG;
+    memcpy(c->blob.data() + BZH_CIRCUIT_BLOB_VK_REPR_OFFSET, repr, 32);
+    c->vk_placeholder = false;
+    return BZH_OK;
+}
+int bzh_circuit_vk_repr(const bzh_circuit* c, uint8_t* out_repr, int* is_placeholder) {
+    if (!c || c->blob.size() < BZH_CIRCUIT_BLOB_VK_REPR_OFFSET + 32) return BZH_E_ARG;
+    if (out_repr) memcpy(out_repr, c->blob.data() + BZH_CIRCUIT_BLOB_VK_REPR_OFFSET, 32);
+    if (is_placeholder) *is_placeholder = c->vk_placeholder ? 1 : 0;
     return BZH_OK;
 }
 

@@ -211,6 +211,13 @@ int bzh_pk_info(const bzh_pk* pk, size_t* rng_bytes_per_proof, size_t* max_proof
     return BZH_OK;
 }
 
+int bzh_pk_vk_repr(const bzh_pk* pk, uint8_t* out_repr32, int* is_placeholder) {
+    if (!pk) return BZH_E_ARG;
+    if (out_repr32) memcpy(out_repr32, pk->vk_repr, 32);
+    if (is_placeholder) *is_placeholder = (pk->vk_repr[0] == BZH_VK_REPR_PLACEHOLDER && !pk->vk_repr[1] && !pk->vk_repr[2] && !pk->vk_repr[3]) ? 1 : 0;
+    return BZH_OK;
+}
+
 int bzh_verify_batch(bzh_ctx* ctx, bzh_pk* pk, size_t batch, const uint64_t* instances, size_t instance_rows, const uint8_t* proofs,
                      size_t proof_stride, const size_t* proof_lens, const uint64_t* g0_u_w, int* results) {
     if (!ctx || !pk || !batch || batch > 4096 || !proofs || !proof_lens || !g0_u_w || !results) return BZH_E_ARG;

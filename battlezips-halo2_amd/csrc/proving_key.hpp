@@ -448,6 +448,16 @@ static int pk_parse_t(const uint8_t* blob, size_t len, bzh_pk& pk, ParsedKey<typ
     const int min_degree = (int)r.u32();
     const uint8_t* vk = r.bytes(32);
     if (!r.ok || pk.k < 1 || pk.k > 24 || pk.na > 4096 || pk.nf > 4096 || pk.ni > 4096) return BZH_E_ARG;
+    {   // the vk digest is a scalar of the circuit field (upstream: C::Scalar::from_bytes_wide): refuse a non-canonical one
+        uint32_t w[8];
+        memcpy(w, vk, 32);
+        bool lt = false;
+        for (int i = 7; i >= 0 && !lt; i--) {
+            if (w[i] > SF::mod(i)) return BZH_E_RANGE;
+            lt = w[i] < SF::mod(i);
+        }
+        if (!lt) return BZH_E_RANGE;
+    }
     memcpy(pk.vk_repr, vk, 32);
     pk.n = (size_t)1 << pk.k;
     const uint32_t ngates = r.u32();

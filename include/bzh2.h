@@ -282,6 +282,27 @@ int bzh_ipa_verify(bzh_ctx* ctx, const bzh_bases* bases, const uint64_t* commitm
  *                  ONE key concurrently, each through its own ctx -- the per-call workspace lives with the (key, ctx) pair
  *                  inside the library.  Calls through one ctx are serialised as everywhere else. */
 typedef struct bzh_pk bzh_pk;
+/* THE VERIFYING-KEY DIGEST.  The first thing upstream's create_proof and verify_proof absorb is pk.get_vk().hash_into(transcript)
+ * (halo2_proofs 0.2.0 plonk.rs, UPSTREAM; the keys come from keygen_vk / keygen_pk at benches/shot.rs:59-61,
+ * benches/board.rs:52-54,80-86, src/circuits/shot.rs:915-940, src/circuits/board.rs:907-932): one scalar,
+ *     Fp::from_bytes_wide( Blake2b-512(personal = "Halo2-Verify-Key", (s.len() as u64).to_le_bytes() || s) ),
+ *     s = format!("{:?}", vk.pinned())
+ * -- a digest of Rust's Debug text of the pinned key (moduli, domain, every gate's expression tree as upstream's
+ * Expression enum prints it, query lists, fixed + permutation commitments).  That text cannot be produced outside the
+ * crate (the tree SHAPES of halo2_gadgets' 19 gates are upstream source, absent here: SURVEY F2), so the digest is an
+ * INPUT of this boundary, not something the library derives:
+ *   - a circuit blob carries it as 32 canonical little-endian bytes at BZH_CIRCUIT_BLOB_VK_REPR_OFFSET;
+ *   - bzh_circuit_create fills in BZH_VK_REPR_PLACEHOLDER (0x1234); proofs made with it verify here (bzh_verify_batch
+ *     absorbs the same value) but are REJECTED by the reference's verify_proof, and vice versa;
+ *   - bzh_circuit_set_vk_repr installs the real one before bzh_circuit_blob / bzh_pk_create; the Rust-side shim obtains it
+ *     once per key (INTEGRATION.md "The verifying-key digest": a 6-line capture transcript around vk.hash_into), or hands
+ *     the Debug text to bzh_vk_digest;
+ *   - bzh_circuit_vk_repr / bzh_pk_vk_repr report what a circuit / key carries, and whether it is still the placeholder.
+ * BZH_E_RANGE: a repr that is not a canonical Fp element (Fp::from_repr(..) is None upstream). */
+#define BZH_CIRCUIT_BLOB_VK_REPR_OFFSET 24
+#define BZH_VK_REPR_PLACEHOLDER 0x1234
+int bzh_vk_digest(const char* pinned_debug, size_t len, uint8_t* out_repr32);
+int bzh_pk_vk_repr(const bzh_pk* pk, uint8_t* out_repr32, int* is_placeholder);
 int bzh_pk_create(bzh_ctx* ctx, const bzh_bases* srs, const uint8_t* circuit, size_t circuit_len, bzh_pk** out);
 int bzh_pk_free(bzh_ctx* ctx, bzh_pk* pk);
 /* Params::commit_lagrange: with the table (g_lagrange | u | w) of bzh_params_create set, the instance, advice, permuted-lookup and
@@ -412,6 +433,10 @@ int bzh_circuit_blob(const bzh_circuit* c, uint8_t* out, size_t cap, size_t* len
 int bzh_circuit_describe(const bzh_circuit* c, char* out, size_t cap, size_t* len);
 int bzh_circuit_info(const bzh_circuit* c, uint32_t* num_advice, uint32_t* num_instance_rows, uint32_t* n_rows, uint32_t* rows_used,
                      uint32_t* num_gates, uint32_t* num_regions);
+/* the verifying-key digest of the blob this circuit hands out (see "THE VERIFYING-KEY DIGEST" above): set it BEFORE
+ * bzh_circuit_blob / bzh_pk_create; *is_placeholder = 1 until it has been set */
+int bzh_circuit_set_vk_repr(bzh_circuit* c, const uint8_t* repr32);
+int bzh_circuit_vk_repr(const bzh_circuit* c, uint8_t* out_repr32, int* is_placeholder);
 int bzh_synthesize_shot(bzh_ctx* ctx, const bzh_circuit* c, size_t batch, const uint64_t* boards, const uint64_t* trapdoors, const uint64_t* shots,
                         const uint64_t* hits, uint64_t* advice, int form, int mem, uint64_t* instances, unsigned threads);
 int bzh_synthesize_board(bzh_ctx* ctx, const bzh_circuit* c, size_t batch, const uint64_t* ship_commitments, const uint64_t* boards,

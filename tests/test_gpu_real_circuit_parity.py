@@ -26,11 +26,11 @@ pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "real_proofs.json")
 
 
-def _setup(ctx, kind, k):
+def _setup(ctx, kind, k, window_bits=0):
     import bzh2
     from bzh2 import circuits as Cm, native as N, params as Pm
     lay = Cm.CircuitLayout(Cm.SHOT if kind == "shot" else Cm.BOARD, k)
-    prm = Pm.Params(ctx, k)
+    prm = Pm.Params(ctx, k, window_bits=window_bits)
     pk = N.NativeProvingKey(ctx, lay.blob(), bzh2.CURVE_VESTA, params=prm)
     return lay, prm, pk
 
@@ -73,6 +73,90 @@ def test_real_circuit_proofs_are_the_oracle_provers_bytes(gpu_ctx, oracle_c, kin
         assert pk.verify_batch(insts, interp) == [True] * count
     finally:
         pk.close()
+        prm.close()
+        lay.close()
+
+
+@pytest.mark.parametrize("kind,k", [("shot", 11), ("board", 14), ("board", 17)])
+def test_single_proof_on_the_latency_configuration_is_the_oracle_provers_bytes(gpu_ctx, oracle_c, kind, k):
+    """BASELINE configs[0] / configs[1] exactly as `bench.py --batch 1` runs them (bench.py: `wb = window_bits or (8 if batch == 1
+    else 0)`): ONE circuit per create_proof call, as benches/shot.rs:64-71 and benches/board.rs:57-71 do, on
+    Params(window_bits=8) -- the 32-row SRS window table -- so that every MSM of the proof goes through the latency kernels
+    (k_msm_reduce_quad[_wg], k_msm_finalize_quad: four lanes per XYZZ addition) and the opening runs all k rounds on the full
+    table (no generator collapse below batch 8).  ShotCircuit k = 11 and BoardCircuit k = 14 against the live oracle prover,
+    BoardCircuit k = 17 against the committed golden oracle-prover proof; interpreter and builtin quotient kernel each."""
+    from bzh2 import circuits as Cm
+    lay, prm, pk = _setup(gpu_ctx, kind, k, window_bits=8)
+    try:
+        seed = 1700 + k if k == 17 else 100 * k + 7
+        circuits = (R.shot_circuits if kind == "shot" else R.board_circuits)(Cm, seed, 1)
+        adv, insts = lay.synthesize(circuits)
+        gold = [e for e in json.load(open(GOLDEN)) if e["kind"] == kind and e["k"] == k]
+        tag = gold[0]["tag"] if k == 17 else "latency-%s-%d" % (kind, k)
+        streams = [R.rng_stream(tag, pk.rng_bytes)]
+        interp, compiled = _both_evaluators(pk, adv, insts, streams)
+        if k == 17:
+            assert gold and gold[0]["seed"] == seed
+            want = bytes.fromhex(gold[0]["proof_hex"])
+        else:
+            g_arr, _, w, u, _ = prm.points(want_lagrange=False)
+            with A.accelerated(R.THREADS):
+                want = R.oracle_prove(R.oracle_keys(lay.blob(), R.points_of(g_arr), w, u), adv[0], insts[0], streams[0])
+        assert interp[0] == want, "interpreter quotient, 8-bit table, batch 1: differs from the oracle prover's bytes"
+        assert compiled[0] == want, "builtin quotient, 8-bit table, batch 1: differs from the oracle prover's bytes"
+        assert pk.verify_batch(insts, compiled) == [True]
+        # the seeded form is what the bench drives: it must equal the explicit-stream proof of the expanded seed
+        from bzh2 import native as N
+        seed32 = R.rng_stream("latency-seed-%s-%d" % (kind, k), 32)
+        seeded = pk.prove_batch(adv, insts, None, seeds=[seed32])
+        assert seeded == pk.prove_batch(adv, insts, [N.rng_expand(seed32, 0, pk.rng_bytes // 64)])
+    finally:
+        pk.close()
+        prm.close()
+        lay.close()
+
+
+@pytest.mark.parametrize("kind,k", [("shot", 11), ("board", 12)])
+def test_the_verifying_key_digest_is_an_input_of_the_boundary(gpu_ctx, oracle_c, kind, k):
+    """Upstream absorbs pk.get_vk().hash_into(transcript) before anything else (keys: benches/shot.rs:59-61, benches/board.rs:52-54,
+    src/circuits/shot.rs:915-940, src/circuits/board.rs:907-932).  Two digests installed with bzh_circuit_set_vk_repr -> two keys
+    whose proofs of the SAME witness and randomness differ; each proof is accepted by the native and by the oracle verifier under
+    its own digest and rejected under the other (and under the placeholder); each equals the oracle PROVER's bytes for its digest."""
+    from bzh2 import circuits as Cm, native as N, params as Pm
+    import bzh2
+    lay = Cm.CircuitLayout(Cm.SHOT if kind == "shot" else Cm.BOARD, k)
+    prm = Pm.Params(gpu_ctx, k)
+    digests = [Cm.vk_digest("PinnedVerificationKey { one: %s }" % kind), Cm.vk_digest("PinnedVerificationKey { two: %s }" % kind)]
+    pks, blobs = [], []
+    try:
+        placeholder_blob = lay.blob()
+        for d in digests:
+            lay.set_vk_repr(d)
+            blobs.append(lay.blob())
+            pks.append(N.NativeProvingKey(gpu_ctx, blobs[-1], bzh2.CURVE_VESTA, params=prm))
+            assert pks[-1].vk_repr() == (d, False)
+        pk0 = N.NativeProvingKey(gpu_ctx, placeholder_blob, bzh2.CURVE_VESTA, params=prm)
+        pks.append(pk0)
+        assert pk0.vk_repr() == (0x1234, True)
+        circuits = (R.shot_circuits if kind == "shot" else R.board_circuits)(Cm, 4242 + k, 1)
+        adv, insts = lay.synthesize(circuits)
+        streams = [R.rng_stream("vk-digest-%s" % kind, pks[0].rng_bytes)]
+        proofs = [pk.prove_batch(adv, insts, streams)[0] for pk in pks]
+        assert len(set(proofs)) == 3, "the digest must reach the transcript"
+        for i, pk in enumerate(pks):
+            assert pk.verify_batch(insts * 3, proofs) == [j == i for j in range(3)]
+        g_arr, _, w, u, _ = prm.points(want_lagrange=False)
+        with A.accelerated(R.THREADS):
+            for i in range(2):
+                keys = R.oracle_keys(blobs[i], R.points_of(g_arr), w, u)
+                assert keys.vk_repr == digests[i]
+                assert R.oracle_prove(keys, adv[0], insts[0], streams[0]) == proofs[i]
+                assert H.verify_proof(keys, insts[0], proofs[i], O.Blake2bTranscript(O.FP))
+                assert not H.verify_proof(keys, insts[0], proofs[1 - i], O.Blake2bTranscript(O.FP))
+                assert not H.verify_proof(keys, insts[0], proofs[2], O.Blake2bTranscript(O.FP))
+    finally:
+        for pk in pks:
+            pk.close()
         prm.close()
         lay.close()
 
