@@ -208,8 +208,10 @@ class NativeProvingKey:
                         "bzh_pk_set_lagrange")
 
     def close(self):
+        """bzh_pk_free.  Refused (BzhError, the key stays open) while a prove / verify call on the key is still running on
+        another ctx: the key's workspaces and code belong to every ctx that uses it."""
         if self.handle is not None:
-            _bind().bzh_pk_free(self.ctx.handle, self.handle)
+            self.ctx._check(_bind().bzh_pk_free(self.ctx.handle, self.handle), "bzh_pk_free")
             self.handle = None
             if self._own_bases:
                 self.bases.free()

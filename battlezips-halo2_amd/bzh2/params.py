@@ -80,12 +80,22 @@ class Params:
                                   _VP(w.ctypes.data), _VP(u.ctypes.data), ctypes.byref(fc))
         return g, gl, (limbs_to_int(w[:4]), limbs_to_int(w[4:])), (limbs_to_int(u[:4]), limbs_to_int(u[4:])), bool(fc.value)
 
-    def close(self):
-        """bzh_params_free.  Proving keys borrow the tables: closing the Params under a live key would leave it reading freed
-        window tables, so that ordering is refused."""
+    def close(self, strict: bool = False):
+        """bzh_params_free.  Proving keys borrow the tables: freeing them under a live key would leave it reading freed window
+        tables.  close() is what cleanup paths (`finally:`) call, so by default the keys still open on these Params are closed
+        first, with a warning -- raising here would mask the exception that skipped their close() and leak the device tables.
+        strict=True keeps the hard error for callers that want the ordering enforced."""
         if self.handle is not None:
-            if any(r() is not None and r().handle is not None for r in self._borrowers):
-                raise RuntimeError("Params.close(): a NativeProvingKey built on these Params is still open; close the key first")
+            live = [r() for r in self._borrowers if r() is not None and r().handle is not None]
+            self._borrowers = []          # dead references are dropped either way
+            if live and strict:
+                self._borrowers = [__import__("weakref").ref(k) for k in live]
+                raise RuntimeError("Params.close(strict=True): a NativeProvingKey built on these Params is still open; close the key first")
+            if live:
+                import warnings
+                warnings.warn("Params.close(): closing %d NativeProvingKey(s) still open on these Params first" % len(live), ResourceWarning, stacklevel=2)
+                for key in live:
+                    key.close()
             _bind().bzh_params_free(self.ctx.handle, self.handle)
             self.handle = None
             self.bases.handle = None            # the tables went with the params

@@ -38,6 +38,10 @@ static Aff aff_from_limbs(const uint64_t* l) {
 }
 
 // ---- fixed-base tables: derived once per process (Z search), cached on disk next to the library -------------------
+// A cached file is re-validated on load against the window points derived from the generator (u^2 = y + z, z - y a
+// non-square: the two properties the reference's `z` tests assert, board_commit_{v,r}.rs:2950-2960); that z is the SMALLEST
+// such value is what tests/test_params_cpu.py checks against all 170 Z / 1 360 U values of the reference through
+// bzh_fixed_base_tables -- the cache is never tracked in git (the build writes it to <library dir>/.bzh2_cache too).
 static std::string cache_dir() {
     const char* env = getenv("BZH_CACHE_DIR");
     if (env && *env) return env;
@@ -67,6 +71,7 @@ static bool load_zu(const std::string& path, const Aff& gen, FixedBase& fb) {
         for (int k = 0; k < ECC_H; k++) {
             if (!Fp::from_limbs(&buf[8 + NW + ((size_t)w * ECC_H + k) * 4], &fb.u[w][k])) return false;
             if (fb.u[w][k].sqr() != fb.points[w][k].y + Fp::from_u64(fb.z[w])) return false;   // u^2 = y + z
+            if ((Fp::from_u64(fb.z[w]) - fb.points[w][k].y).jacobi() >= 0) return false;        // z - y must not be a square
         }
     }
     return true;

@@ -65,11 +65,33 @@ int bzh_pk_create(bzh_ctx* ctx, const bzh_bases* srs, const uint8_t* circuit, si
     return BZH_E_ARG;  // BN254 has no cube root of unity in Fr's multiplicative generator convention used here
 }
 
+namespace {
+// one prove / verify call on a key: counted for the whole call, so that bzh_pk_set_quotient_module / bzh_pk_free can refuse
+struct KeyCall {
+    bzh_pk* pk;
+    explicit KeyCall(bzh_pk* p) : pk(p) {
+        std::lock_guard<std::mutex> lk(pk->mu);
+        pk->calls_in_flight++;
+    }
+    ~KeyCall() {
+        std::lock_guard<std::mutex> lk(pk->mu);
+        pk->calls_in_flight--;
+    }
+};
+}  // namespace
+
 int bzh_pk_free(bzh_ctx* ctx, bzh_pk* pk) {
     if (!ctx || !pk) return BZH_E_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
+    {
+        std::lock_guard<std::mutex> lkp(pk->mu);
+        if (pk->calls_in_flight) {   // another ctx is proving / verifying on this key: its arena and code would vanish under it
+            ctx->last_error = "bzh_pk_free: a bzh_prove_batch / bzh_verify_batch call on this key is still running";
+            return BZH_E_ARG;
+        }
+    }
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipDeviceSynchronize();   // every ctx's stream: the arenas below belong to all of them
     if (pk->dev) (void)hipFree(pk->dev);
     if (pk->hoist) (void)hipFree(pk->hoist);
     if (pk->q_module) (void)hipModuleUnload(pk->q_module);
@@ -166,8 +188,12 @@ int bzh_pk_set_quotient_module(bzh_ctx* ctx, bzh_pk* pk, const void* code_object
     std::lock_guard<std::mutex> lk(ctx->mu);
     std::lock_guard<std::mutex> lkp(pk->mu);
     BZH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (pk->calls_in_flight) {   // a call on another ctx may hold q_fn and be about to launch it
+        ctx->last_error = "bzh_pk_set_quotient_module: a bzh_prove_batch / bzh_verify_batch call on this key is still running";
+        return BZH_E_ARG;
+    }
     if (pk->q_module) {
-        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipDeviceSynchronize();   // launches of the old code object queued on ANY ctx's stream
         (void)hipModuleUnload(pk->q_module);
         pk->q_module = nullptr;
         pk->q_fn = nullptr;
@@ -225,6 +251,7 @@ int bzh_verify_batch(bzh_ctx* ctx, bzh_pk* pk, size_t batch, const uint64_t* ins
     for (size_t b = 0; b < batch; b++)
         if (proof_lens[b] > proof_stride) return BZH_E_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
+    KeyCall in_flight(pk);
     BZH_HIP_TRY(ctx, hipSetDevice(ctx->device));
     // The commitments of the key and G'_0 are computed against pk->srs: the three points the caller passes must be the
     // same SRS's, or every valid proof would be rejected without an error.  Row 0 of the window table is the raw SRS.
@@ -271,6 +298,7 @@ static int prove_batch_entry(bzh_ctx* ctx, bzh_pk* pk, size_t batch, const uint6
         return BZH_E_ARG;
     if (mem == BZH_MEM_DEVICE && form != BZH_FORM_MONTGOMERY) return BZH_E_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
+    KeyCall in_flight(pk);   // until the proofs are in the caller's buffers (prove_batch_t synchronises the stream before it returns)
     BZH_HIP_TRY(ctx, hipSetDevice(ctx->device));
     const uint32_t* d_adv = (const uint32_t*)advice;
     void* staged = nullptr;

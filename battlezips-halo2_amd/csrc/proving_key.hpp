@@ -54,6 +54,10 @@ struct bzh_pk {
     // per-call workspaces: one grow-only arena per ctx that has used the key (several worker streams share ONE key)
     std::map<const bzh_ctx*, std::unique_ptr<bzh::Arena>> arenas;
     size_t rng_bytes = 0;
+    // bzh_prove_batch / bzh_verify_batch calls running on this key right now, over all ctxs (guarded by `mu`):
+    // bzh_pk_set_quotient_module and bzh_pk_free refuse while it is non-zero -- they unload code / free arenas that a
+    // call on ANOTHER ctx may be launching from
+    int calls_in_flight = 0;
     // verifying key: commitments to the fixed and permutation polynomials (computed at the first verification)
     bool vk_ready = false;
     std::vector<uint64_t> fixed_commitments, sigma_commitments;  // affine canonical x || y

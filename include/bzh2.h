@@ -280,7 +280,11 @@ int bzh_ipa_verify(bzh_ctx* ctx, const bzh_bases* bases, const uint64_t* commitm
  *                  (surplus quotient coefficients) or a lookup input is not in its table.
  *                  A key is shared, read-only state (upstream's &ProvingKey): several host threads may prove / verify on
  *                  ONE key concurrently, each through its own ctx -- the per-call workspace lives with the (key, ctx) pair
- *                  inside the library.  Calls through one ctx are serialised as everywhere else. */
+ *                  inside the library.  Calls through one ctx are serialised as everywhere else.
+ *                  bzh_pk_free and bzh_pk_set_quotient_module change what those calls run on (workspaces of every ctx, the
+ *                  loaded code object): both return BZH_E_ARG, leaving the key as it was, while a bzh_prove_batch /
+ *                  bzh_verify_batch on the key is still running on any ctx, and synchronise the whole device before they
+ *                  release anything.  Join the proving threads first. */
 typedef struct bzh_pk bzh_pk;
 /* THE VERIFYING-KEY DIGEST.  The first thing upstream's create_proof and verify_proof absorb is pk.get_vk().hash_into(transcript)
  * (halo2_proofs 0.2.0 plonk.rs, UPSTREAM; the keys come from keygen_vk / keygen_pk at benches/shot.rs:59-61,

@@ -59,3 +59,87 @@ def test_threads_share_one_key_and_get_the_private_keys_proofs(gpu_ctx):
             c.close()
         prm.close()
         lay.close()
+
+
+def test_module_swap_and_free_are_refused_while_another_ctx_proves_on_the_key(gpu_ctx):
+    """bzh_pk_set_quotient_module unloads a code object and bzh_pk_free releases every ctx's workspace: both refuse (BZH_E_ARG,
+    key untouched) while a bzh_prove_batch on the key is still running on another ctx -- a launch of the unloaded code or a
+    kernel on a freed arena would fault the GPU.  Thread A proves a batch; the main thread keeps asking for both through its
+    own ctx until A is done: every answer during the call is a refusal, A's proofs are the expected bytes, and both requests
+    succeed afterwards."""
+    import time
+    import bzh2
+    from bzh2 import BzhError, circuits as Cm, native as N, params as Pm
+    lay = Cm.CircuitLayout(Cm.BOARD, 12)
+    prm = Pm.Params(gpu_ctx, 12)
+    other = bzh2.Context(0)
+    try:
+        pk = N.NativeProvingKey(gpu_ctx, lay.blob(), bzh2.CURVE_VESTA, params=prm)
+        circuits = R.board_circuits(Cm, 77, 16)
+        adv, insts = lay.synthesize(circuits)
+        seeds = [R.rng_stream("busy-%d" % b, 32) for b in range(16)]
+        want = pk.prove_batch(adv, insts, None, seeds=seeds, ctx=other)      # warm: caches filled, workspace grown
+        state = {"running": False, "done": False, "proofs": None, "error": None}
+
+        def prove():
+            try:
+                state["running"] = True
+                state["proofs"] = pk.prove_batch(adv, insts, None, seeds=seeds, ctx=other)
+            except BaseException as e:  # noqa: BLE001
+                state["error"] = e
+            finally:
+                state["done"] = True
+        th = threading.Thread(target=prove)
+        th.start()
+        while not state["running"]:
+            time.sleep(0)
+        time.sleep(0.002)      # let the call take the key (it runs for tens of milliseconds)
+        refused = {"module": 0, "free": 0}
+        while not state["done"]:
+            for what, call in (("module", lambda: pk.set_quotient_module(None)), ("free", pk.close)):
+                try:
+                    call()
+                    th.join(timeout=1.0)     # allowed only once the call has left the library (its thread ends right after)
+                    if th.is_alive():
+                        state["error"] = AssertionError("%s went through while a proof was running" % what)
+                except BzhError as e:
+                    assert e.status == -1
+                    refused[what] += 1
+            if pk.handle is None:
+                break
+        th.join()
+        assert state["error"] is None, state["error"]
+        assert refused["module"] >= 1 and refused["free"] >= 1, refused
+        assert state["proofs"] == want
+        if pk.handle is not None:
+            pk.set_quotient_module(None)      # idle key: allowed (returns to the builtin kernel)
+            assert pk.prove_batch(adv[:2], insts[:2], None, seeds=seeds[:2]) == want[:2]
+            pk.close()
+        assert pk.handle is None
+    finally:
+        other.close()
+        prm.close()
+        lay.close()
+
+
+def test_params_close_in_a_cleanup_path_closes_borrowing_keys_first(gpu_ctx):
+    """Params.close() is what `finally:` blocks call: with a key still open on the tables it closes the key first (warning)
+    instead of raising over the original failure; strict=True keeps the hard error."""
+    import warnings
+    import bzh2
+    from bzh2 import circuits as Cm, native as N, params as Pm
+    lay = Cm.CircuitLayout(Cm.SHOT, 11)
+    prm = Pm.Params(gpu_ctx, 11)
+    try:
+        pk = N.NativeProvingKey(gpu_ctx, lay.blob(), bzh2.CURVE_VESTA, params=prm)
+        with pytest.raises(RuntimeError):
+            prm.close(strict=True)
+        assert prm.handle is not None and pk.handle is not None
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            prm.close()
+        assert pk.handle is None and prm.handle is None
+        assert any(issubclass(x.category, ResourceWarning) for x in w)
+    finally:
+        prm.close()
+        lay.close()
