@@ -26,6 +26,7 @@ struct RegionInfo {  // what dev::MockProver keeps per region (failure locations
     std::set<Column> columns;
     bool has_rows = false;
     size_t row_lo = 0, row_hi = 0;
+    std::vector<std::pair<int, size_t>> advice_cells;   // (advice column, absolute row) of every assign_advice, in order
     void extend(Column c, size_t row) {
         columns.insert(c);
         if (!has_rows) {
@@ -79,7 +80,7 @@ struct Assembly {
     }
     void enter_region(const std::string& name) {
         if (keep_fixed) {
-            regions.push_back(RegionInfo{name, {}, false, 0, 0});
+            regions.push_back(RegionInfo{name, {}, false, 0, 0, {}});
             current_region = (int)regions.size() - 1;
         }
     }
@@ -90,7 +91,10 @@ struct Assembly {
     }
     void assign_advice(Column c, size_t row, const Fp& v) {
         check_row(row);
-        if (keep_fixed && current_region >= 0) regions[current_region].extend(c, row);
+        if (keep_fixed && current_region >= 0) {
+            regions[current_region].extend(c, row);
+            regions[current_region].advice_cells.push_back({c.index, row});
+        }
         if (!keep_advice) return;
         if (advice_out) {
             if (row >= advice_stride) throw SynthesisError("advice row beyond the compact stride");

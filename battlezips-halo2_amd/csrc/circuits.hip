@@ -335,6 +335,9 @@ static void build_blob_and_describe(bzh_circuit& c) {
           << ",\"row_hi\":" << r.row_hi << ",\"columns\":[";
         size_t i = 0;
         for (auto& col : r.columns) o << (i++ ? "," : "") << "[\"" << kind_name(col.kind) << "\"," << col.index << "]";
+        o << "],\"advice_cells\":[";   // every advice cell the region assigns: (column, absolute row)
+        i = 0;
+        for (auto& ac : r.advice_cells) o << (i++ ? "," : "") << "[" << ac.first << "," << ac.second << "]";
         o << "]}";
     }
     o << "],\"permutation\":[";

@@ -147,3 +147,81 @@ def verify(circ, desc, advice, instance, p: int = P):
                 f.update(_find_region(desc["regions"], row, {(kind, idx)}))
                 failures.append(f)
     return failures
+
+
+class LocalChecker:
+    """What MockProver::verify would newly report after ONE advice cell of an otherwise satisfying witness is changed,
+    without re-walking the whole table: only constraints that can see the cell are evaluated -- gate polynomials that
+    query (column, rotation r) at row - r, lookup inputs likewise, and the cell's permutation cycle.  Used by the mutation
+    test of the restated halo2_gadgets gates (tests/test_ecc_gate_mutation_cpu.py): a cell no constraint notices is a
+    dropped or mis-stated polynomial."""
+
+    def __init__(self, circ, desc, advice, instance, p: int = P):
+        self.circ, self.desc, self.p = circ, desc, p
+        self.n, self.usable = circ.n, desc["usable_rows"]
+        inst = [list(c) + [0] * (self.n - len(c)) for c in instance]
+        while len(inst) < circ.num_instance:
+            inst.append([0] * self.n)
+        self.cols = {'advice': [list(c) for c in advice], 'fixed': circ.fixed, 'instance': inst}
+        # per advice column: [(gate index, constraint index, polynomial, leading fixed column or None, rotation)]
+        self.by_column = {}
+        for gi, g in enumerate(desc["gates"]):
+            polys = circ.gates[g["first_poly"]:g["first_poly"] + len(g["constraints"])]
+            for ci, pl in enumerate(polys):
+                cells = set()
+                _cells_of(pl, cells)
+                lead = _leading_fixed_factor(pl)
+                for t, c, r in cells:
+                    if t == 'advice':
+                        self.by_column.setdefault(c, []).append((gi, ci, pl, lead, r))
+        self.lookup_by_column = {}
+        self.tables = []
+        for li, (ins, tabs) in enumerate(circ.lookups):
+            table = set()
+            for row in range(self.usable):
+                table.add(tuple(H.expr_eval(e, self._leaf(row), p) for e in tabs))
+            self.tables.append(table)
+            cells = set()
+            for e in ins:
+                _cells_of(e, cells)
+            for t, c, r in cells:
+                if t == 'advice':
+                    self.lookup_by_column.setdefault(c, []).append((li, ins, r))
+
+        class _CS:
+            pass
+        cs = _CS()
+        cs.perm_columns, cs.n = circ.perm_columns, self.n
+        self.mapping = H.build_permutation(cs, circ.copies)
+        self.perm_index = {tuple(pc): i for i, pc in enumerate(circ.perm_columns)}
+
+    def _leaf(self, row):
+        return lambda t, c, r: self.cols[t][c][(row + r) % self.n]
+
+    def failures_after(self, column: int, row: int, new_value: int):
+        """names of what fails with advice[column][row] = new_value (the cell is restored afterwards):
+        ('gate', gate index, constraint index, row) / ('lookup', index, row) / ('permutation', column, row)"""
+        p, old = self.p, self.cols['advice'][column][row]
+        self.cols['advice'][column][row] = new_value % p
+        out = []
+        try:
+            for gi, ci, pl, lead, r in self.by_column.get(column, ()):
+                at = (row - r) % self.n
+                if at >= self.usable or (lead is not None and self.circ.fixed[lead][at] % p == 0):
+                    continue
+                if H.expr_eval(pl, self._leaf(at), p) != 0:
+                    out.append(('gate', gi, ci, at))
+            for li, ins, r in self.lookup_by_column.get(column, ()):
+                at = (row - r) % self.n
+                if at < self.usable and tuple(H.expr_eval(e, self._leaf(at), p) for e in ins) not in self.tables[li]:
+                    out.append(('lookup', li, at))
+            pi = self.perm_index.get(('advice', column))
+            if pi is not None:
+                mc, mr = self.mapping[pi][row]
+                if (mc, mr) != (pi, row):
+                    mk, mi = self.circ.perm_columns[mc]
+                    if self.cols[mk][mi][mr] % p != new_value % p:
+                        out.append(('permutation', column, row))
+        finally:
+            self.cols['advice'][column][row] = old
+        return out
