@@ -488,7 +488,8 @@ EXPORTS += ["bzh_hash_to_curve", "bzh_params_generators", "bzh_group_ifft", "bzh
 # circuit front end (bzh2/circuits.py)
 EXPORTS += ["bzh_circuit_create", "bzh_circuit_free", "bzh_circuit_last_error", "bzh_circuit_blob", "bzh_circuit_describe",
             "bzh_circuit_info", "bzh_synthesize_shot", "bzh_synthesize_board", "bzh_synthesize_bitify_test", "bzh_board_witness",
-            "bzh_shot_serialize", "bzh_pedersen_commit_host", "bzh_fixed_base_tables", "bzh_circuit_set_vk_repr", "bzh_circuit_vk_repr"]
+            "bzh_shot_serialize", "bzh_pedersen_commit_host", "bzh_fixed_base_tables", "bzh_circuit_set_vk_repr", "bzh_circuit_vk_repr",
+            "bzh_pedersen_commit_batch"]
 E_VERIFY = -6
 
 

@@ -42,6 +42,7 @@ def _bind():
     L.bzh_shot_serialize.argtypes = [_VP, _VP, ctypes.c_size_t, _VP]
     L.bzh_pedersen_commit_host.argtypes = [_VP, _VP, _VP]
     L.bzh_fixed_base_tables.argtypes = [ctypes.c_int, _VP, _VP, _VP]
+    L.bzh_pedersen_commit_batch.argtypes = [_VP, _VP, _VP, ctypes.c_size_t, _VP]
     L.bzh_circuit_set_vk_repr.argtypes = [_VP, ctypes.c_char_p]
     L.bzh_circuit_vk_repr.argtypes = [_VP, _VP, ctypes.POINTER(ctypes.c_int)]
     L.bzh_vk_digest.argtypes = [ctypes.c_char_p, ctypes.c_size_t, _VP]
@@ -187,6 +188,22 @@ def pedersen_commit_host(message: int, trapdoor: int):
     m, t, out = int_to_limbs(message), int_to_limbs(trapdoor), np.zeros(8, dtype=np.uint64)
     _check(_bind().bzh_pedersen_commit_host(_VP(m.ctypes.data), _VP(t.ctypes.data), _VP(out.ctypes.data)), "bzh_pedersen_commit_host")
     return limbs_to_int(out[:4]), limbs_to_int(out[4:])
+
+
+def pedersen_commit_batch(ctx, messages, trapdoors):
+    """pedersen_commit (src/utils/pedersen.rs:17-28) for every (message, trapdoor) pair in one device launch
+    (bzh_pedersen_commit_batch).  Returns affine (x, y) int pairs, None for the identity."""
+    n = len(messages)
+    assert n == len(trapdoors) and n > 0
+    m, t, out = _limbs(messages), _limbs(trapdoors), np.zeros((n, 8), dtype=np.uint64)
+    rc = _bind().bzh_pedersen_commit_batch(ctx.handle, _VP(m.ctypes.data), _VP(t.ctypes.data), n, _VP(out.ctypes.data))
+    if rc:
+        raise BzhError(rc, "bzh_pedersen_commit_batch", ctx.last_error() if hasattr(ctx, "last_error") else "")
+    res = []
+    for a in out:
+        x, y = limbs_to_int(a[:4]), limbs_to_int(a[4:])
+        res.append(None if x == 0 and y == 0 else (x, y))
+    return res
 
 
 def fixed_base_tables(base: int):

@@ -23,8 +23,8 @@ def shard_range(total: int, rank: int, world: int) -> range:
 def gather_records(local: torch.Tensor, counts, dist=None) -> torch.Tensor:
     """all_gather fixed-stride records: `local` is (count_r, stride) on this rank, `counts[r]` the
     record count of every rank.  Returns the (sum(counts), stride) tensor in rank order on every rank."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
-        return local
+    if dist is None or not dist.is_initialized():
+        return local          # (a group of ONE rank -- bench.py --force-dist -- still runs the collective below)
     world = dist.get_world_size()
     stride = local.shape[1]
     cap = max(counts)

@@ -318,6 +318,7 @@ int bzh_ctx_destroy(bzh_ctx* ctx) {
     for (int i = 0; i < bzh_ctx::kWsSlots; i++)
         if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
     if (ctx->d_add_counter) (void)hipFree(ctx->d_add_counter);
+    if (ctx->ped_tbl) (void)hipFree(ctx->ped_tbl);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
     if (ctx->pin_big) (void)hipHostFree(ctx->pin_big);
     for (auto& s : ctx->spans) {

@@ -1,9 +1,11 @@
 // Context, workspace and timing plumbing behind the C ABI (include/bzh2.h).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <sched.h>
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -59,6 +61,7 @@ struct bzh_ctx {
         size_t bytes;
     };
     std::vector<PendingD2H> pending_d2h;
+    uint32_t* ped_tbl = nullptr;   // bzh_pedersen_commit_batch's direct-lookup table of V and R (csrc/pedersen.hip), built on first use
 };
 
 #define BZH_HIP_TRY(ctx, expr)                                                                    \
@@ -71,6 +74,23 @@ struct bzh_ctx {
     } while (0)
 
 namespace bzh {
+
+// Host threads one call may start (witness synthesis, the lookup's sort helpers, the verifier's per-proof pool, Params::new's
+// hash-to-curve): $BZH_HOST_THREADS when set -- a multi-rank launcher gives every rank its share of the node's cores there
+// (bench.py: affinity count / world size) --, else the calling thread's CPU affinity count (std::thread::hardware_concurrency
+// counts the machine's cores, not the cgroup / taskset share).  Read per call: a launcher may set it after loading the library.
+inline unsigned host_thread_budget() {
+    if (const char* e = getenv("BZH_HOST_THREADS")) {
+        const int v = atoi(e);
+        if (v > 0) return (unsigned)v;
+    }
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) {
+        const int c = CPU_COUNT(&set);
+        if (c > 0) return (unsigned)c;
+    }
+    return 1u;
+}
 
 // grow-only workspace slot
 inline int ws_ensure(bzh_ctx* ctx, int slot, size_t bytes, void** out) {

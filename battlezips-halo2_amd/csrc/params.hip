@@ -322,7 +322,7 @@ int bzh_params_generators(unsigned k, uint64_t* g_xy, uint64_t* w_xy, uint64_t* 
     const std::string domain = "Halo2-Parameters";
     std::atomic<int> bad{0};
     if (g_xy) {
-        if (!threads) threads = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+        if (!threads) threads = std::max(1u, std::min(32u, host_thread_budget()));
         threads = (unsigned)std::min<size_t>(threads, n);
         std::atomic<size_t> next{0};
         auto work = [&] {

@@ -451,7 +451,7 @@ int Prover<C>::prove(const uint32_t* d_advice_in, const uint64_t* instances, siz
         for (size_t v = 0; v < 2 * B; v++) memset(as + (v * n + usable) * 4, 0, (n - usable) * 32);
         {  // one sort per proof on host threads
             // short-lived pool, capped: several provers (threads, ranks) run this at once on the same host
-            const size_t nthreads = std::min<size_t>({B, (size_t)std::max(1u, std::thread::hardware_concurrency()), (size_t)8});
+            const size_t nthreads = std::min<size_t>({B, (size_t)host_thread_budget(), (size_t)8});
             std::vector<int> rcs(B, BZH_OK);
             std::vector<std::thread> th;
             auto work = [&](size_t t) {

@@ -437,7 +437,7 @@ static int verify_batch_t(bzh_ctx* ctx, bzh_pk* pk, size_t batch, const uint64_t
     const size_t nl_cap = ncommit + 2 * (size_t)pk->k + 1 + 3 + 4;
     std::vector<ProofView<C>> views(B);
     {
-        const size_t nthreads = std::min<size_t>({B, (size_t)std::max(1u, std::thread::hardware_concurrency()), (size_t)32});
+        const size_t nthreads = std::min<size_t>({B, (size_t)host_thread_budget(), (size_t)32});
         std::vector<std::thread> th;
         for (size_t t = 0; t < nthreads; t++)
             th.emplace_back([&, t]() {

@@ -56,28 +56,38 @@ def launch_ranks():
         return
     import socket
     import subprocess
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    procs = []
-    for r in range(known.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(known.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
-    pending = list(procs)
-    while pending:
-        for pr in list(pending):
-            code = pr.poll()
-            if code is None:
-                continue
-            pending.remove(pr)
-            if code != 0 and rc == 0:
-                rc = code
-                for other in pending:       # a failed rank leaves the others waiting in a collective: stop exactly those children
-                    other.terminate()
-        time.sleep(0.05)
-    sys.exit(rc)
+    for attempt in (0, 1):
+        # The port is probed and released before the children bind it (they import torch first): another process can take it
+        # in between.  The parent never touches the GPU, so a launch that dies early is simply started again, once, with
+        # fresh children and a new port.
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        t_launch = time.time()
+        procs = []
+        for r in range(known.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(known.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                       HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+        rc = 0
+        pending = list(procs)
+        while pending:
+            for pr in list(pending):
+                code = pr.poll()
+                if code is None:
+                    continue
+                pending.remove(pr)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for other in pending:       # a failed rank leaves the others waiting in a collective: stop exactly those children
+                        other.terminate()
+            time.sleep(0.05)
+        if rc == 0 or attempt == 1 or time.time() - t_launch > 120:
+            break
+        sys.stderr.write("bench.py: a rank exited with %d within %.0f s of the launch (rendezvous on port %d?): launching the ranks once more\n"
+                         % (rc, time.time() - t_launch, port))
+    sys.exit(128 - rc if rc < 0 else rc)      # a child killed by signal N reports 128 + N, like a shell
 
 
 if __name__ == "__main__":
@@ -171,6 +181,15 @@ def parse():
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU work: every rank joins the process group, gathers one fixed-stride record per rank and rank 0 prints "
                          "the line -- checks the --gpus launcher and the rendezvous on a CPU-only machine (tests/test_bench_launcher_cpu.py)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="world size 1: still join a process group on --dist-backend (nccl = RCCL) and run the record all_gather, the "
+                         "barriers and the MAX all_reduce of the multi-GPU path (tests/test_gpu_bench_ranks.py: the first 8-GPU run must "
+                         "not be the first time that code executes)")
+    ap.add_argument("--other-workloads", default="auto", choices=["auto", "all", "none"],
+                    help="after the main timed region, short regions for the rest of BASELINE.json's metric -- proof_k11 (Shot 128 x 8), "
+                         "proof_k12, proof_k17 (8 x 4), verify_k14, msm24 and ntt22 on vesta and bn254 -- reported under "
+                         "config.other_workloads, each with its own roofline and cpu_baseline.  auto: when the main workload is the default "
+                         "proof_k14 at the default batch / concurrency; with several ranks only the proof sizes run (weak scaling)")
     ap.add_argument("--concurrency", type=int, default=4,
                     help="proof_k* workloads: independent proofs in flight per GPU (host threads, one ctx + stream each)")
     return ap.parse_args()
@@ -234,6 +253,7 @@ class ProofRunner:
     `batch` witnesses of one real circuit: bzh_synthesize_{shot,board} (device output) then bzh_prove_batch."""
 
     POOL = 64   # distinct fleets / shots the witnesses cycle through; every proof also gets its own trapdoor
+    SYNTH_THREADS = 4   # host threads per bzh_synthesize_* call (main() lowers it to the rank's share of the cores)
 
     def __init__(self, kind, k, ctx, device, seed, batch, workers, window_bits=0, first_ctx=None):
         import random
@@ -295,6 +315,17 @@ class ProofRunner:
     def worker_ctxs(self):
         return [(st, types.SimpleNamespace(ctx=c)) for st, c in zip(self.streams, self.ctxs)]
 
+    def close(self):
+        """release the key, the SRS tables, the worker contexts and the advice tensors (the next workload gets the HBM)"""
+        torch.cuda.synchronize(self.device)
+        self.pk.close()
+        self.params.close()
+        for st, c in zip(self.streams, self.ctxs):
+            if st is not None:      # contexts this runner created (worker 0 may run on the caller's)
+                c.close()
+        self.layout.close()
+        self.adv, self.pks, self.ctxs, self.streams = [], [], [], []
+
     def _circuits(self, lo, count):
         Cm = self.Cm
         out = []
@@ -306,7 +337,7 @@ class ProofRunner:
 
     def _prove_slice(self, wi, lo, count):
         circuits = self._circuits(lo, count)
-        _, insts = self.layout.synthesize(circuits, ctx=self.ctxs[wi], device_ptr=self.adv[wi].data_ptr(), threads=4)
+        _, insts = self.layout.synthesize(circuits, ctx=self.ctxs[wi], device_ptr=self.adv[wi].data_ptr(), threads=ProofRunner.SYNTH_THREADS)
         if self.explicit_rng:   # the caller supplies every random byte (2 MB per proof at k = 14): the parity tests' mode
             blob = self.np_rng[wi].bytes(self.rng_bytes * count)
             rbs = [blob[i * self.rng_bytes:(i + 1) * self.rng_bytes] for i in range(count)]
@@ -536,6 +567,18 @@ class Workload:
         for _, fn in self.calls:
             fn()
 
+    def close(self):
+        for r in [getattr(self, "runner", None)] + list(getattr(self, "provers", [])):
+            if r is not None:
+                r.close()
+        if getattr(self, "bases", None) is not None:
+            self.bases.free()
+        for a in ("msm_scalars", "msm_out", "cols", "ext", "hx", "data", "result", "runner", "provers", "bases"):
+            if hasattr(self, a):
+                setattr(self, a, None)
+        self.calls = []
+        torch.cuda.empty_cache()
+
 
 def _cpu_cores():
     try:
@@ -686,21 +729,232 @@ def ubench_peaks():
     return best
 
 
+def cpu_baseline_micro(name, curve):
+    """msm24 / ntt22 on the host cores with the C oracle (oracle/oracle.c: best_multiexp / best_fft restated), on a BOUNDED sample:
+    the NTT at its full 2^22, the MSM on 2^21 of the 2^24 points (bases by the oracle's point walk) -- GB/s of the sample
+    (Pippenger's additions per point fall only slowly with n: c ~ ln n)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import coracle as C
+    import pasta as O
+    import random
+    cores = _cpu_cores()
+    cid = {"vesta": 0, "pallas": 1, "bn254": 2}[curve]
+    cv = O.CURVE_BY_ID[cid]
+    rng = np.random.default_rng(5)
+
+    def rnd(m):
+        a = np.frombuffer(rng.bytes(m * 32), dtype=np.uint64).reshape(m, 4).copy()
+        a[:, 3] &= (1 << 60) - 1
+        return a
+    if name == "ntt22":
+        F, fid = {0: O.FP, 1: O.FQ, 2: O.BN_FR}[cid], cid      # the curve's scalar field; field ids follow the curve ids
+        a = rnd(1 << 22)
+        t0 = time.perf_counter()
+        C.ntt(fid, a, F.omega(22), threads=cores)
+        dt = time.perf_counter() - t0
+        return {"value": (64 << 22) / dt / 1e9, "unit": "GB/s", "cores": cores, "kind": "port", "seconds": dt,
+                "sample": "C oracle radix-2 FFT (best_fft restated), one full 2^22 forward NTT over the scalar field of %s" % curve}
+    lg = 21
+    n = 1 << lg
+    g = cv.random_point(random.Random(1))
+    bases = C.point_walk(cid, C.points_to_array([g])[0], n)
+    sc = rnd(n)
+    t0 = time.perf_counter()
+    C.msm(cid, sc, bases, cores)
+    dt = time.perf_counter() - t0
+    return {"value": 96.0 * n / dt / 1e9, "unit": "GB/s", "cores": cores, "kind": "port", "seconds": dt,
+            "sample": "C oracle chunked Pippenger (best_multiexp restated) on 2^%d of the 2^24 points of %s (bases: G, 2G, ... by the oracle's "
+                      "point walk); 96 B per point / time" % (lg, curve)}
+
+
+def cpu_baseline_verify(runner):
+    """verify_proof for ONE proof of the runner's circuit on the host: the oracle's verifier (oracle/halo2_oracle.verify_proof,
+    protocol logic in Python, its n-term MSM / commitments through the C oracle via oracle/accel.py) on a proof the product just
+    made -- which must be accepted.  Key set-up (keygen_vk's fixed / permutation commitments) is not timed, as in
+    benches/board.rs:80-86."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import accel as A
+    import halo2_oracle as H
+    import pasta as O
+    from helpers import real_parity as R
+    cores = _cpu_cores()
+    g, _, w, u, _ = runner.params.points(want_lagrange=False)
+    insts, proofs = runner.last_insts[0], runner.last_batch[0]
+    with A.accelerated(cores):
+        keys = R.oracle_keys(runner.layout.blob(), R.points_of(g), w, u, verifier_only=True)
+        t0 = time.perf_counter()
+        ok = H.verify_proof(keys, insts[0], proofs[0], O.Blake2bTranscript(O.FP))
+        dt = time.perf_counter() - t0
+    assert ok, "the oracle verifier rejected a proof of the bench"
+    return {"value": 1.0 / dt, "unit": "verifications/s", "cores": cores, "kind": "port", "seconds": dt,
+            "sample": "oracle verify_proof (Python protocol logic, MSM / commitments in the C oracle on %d threads) of one %sCircuit proof at k=%d "
+                      "made by this run; accepted" % (cores, runner.kind.capitalize(), runner.k)}
+
+
+def measure_region(wl, ctx, device, dist, steps, warmup):
+    """W warmup steps, barrier, K timed steps between barriers (+ torch.cuda.synchronize on both sides), MAX over ranks;
+    kernel-class timings summed over the workload's contexts"""
+    def barrier():
+        torch.cuda.synchronize(device)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+    for _ in range(warmup):
+        wl.step()
+    barrier()
+    all_ctx = [ctx] + [w[1].ctx for w in getattr(wl, "workers", []) if w[0] is not None]
+    all_ctx = list({id(c): c for c in all_ctx}.values())
+    for c in all_ctx:
+        c.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        wl.step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    timings = ctx.timings()
+    for c in all_ctx[1:]:
+        for kname, v in c.timings().items():
+            for f in v:
+                timings[kname][f] += v[f]
+    for c in all_ctx:
+        c.profile(False)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed, timings, all_ctx
+
+
+OTHER_WORKLOADS = [
+    # (tag, workload, curve, batch, concurrency, steps, warmup)
+    ("proof_k11", "proof_k11", "vesta", 128, 8, 4, 1),      # ShotCircuit at the reference's size (benches/shot.rs:22)
+    ("proof_k12", "proof_k12", "vesta", 64, 4, 4, 1),       # BoardCircuit at the reference's size (benches/board.rs:22)
+    ("proof_k17", "proof_k17", "vesta", 8, 4, 3, 1),        # the metric's third size
+    ("verify_k14", "verify_k14", "vesta", 64, 1, 5, 1),     # benches/board.rs:80-86
+    ("msm24_vesta", "msm24", "vesta", 1, 1, 5, 2),
+    ("msm24_bn254", "msm24", "bn254", 1, 1, 5, 2),
+    ("ntt22_vesta", "ntt22", "vesta", 1, 1, 20, 3),
+    ("ntt22_bn254", "ntt22", "bn254", 1, 1, 20, 3),
+]
+
+
+def run_other_workloads(args, ctx, device, rank, world, dist):
+    """The rest of BASELINE.json's metric, one short region each, sequentially in this process; every workload is freed before
+    the next.  Every rank runs them (weak scaling; several ranks: proof sizes only, no CPU legs); a failure is recorded in the
+    entry of that workload and does not take the line down -- the collectives of a region are reached either way."""
+    out = {}
+    for tag, name, curve, batch, conc, steps, warmup in OTHER_WORKLOADS:
+        if world > 1 and not name.startswith("proof_k"):
+            continue
+        ent = {"workload": name, "steps": steps, "warmup": warmup}
+        t_begin = time.perf_counter()
+        wl, err = None, None
+        try:
+            wl = Workload(name, ctx, device, seed=4321 + rank, precompute=True, concurrency=conc, batch=batch, window_bits=0, circuit="auto",
+                          rank=0, world=1, mix_divisor=1, dist=None, curve=curve)
+            torch.cuda.synchronize(device)
+        except Exception as e:  # noqa: BLE001
+            err = "setup: %r" % (e,)
+        ent["setup_s"] = round(time.perf_counter() - t_begin, 2)
+        ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=device)
+        if dist is not None:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)      # every rank runs the region or none does (its barriers are collectives)
+        if int(ok.item()) == 0:
+            ent["error"] = err or "another rank failed to set this workload up"
+            out[tag] = ent
+            if wl is not None:
+                wl.close()
+            continue
+        try:
+            elapsed, timings, all_ctx = measure_region(wl, ctx, device, dist, steps, warmup)
+            units = wl.units_per_step * steps * world
+            acc, nt = timings["msm_accumulate"], timings["ntt"]
+            qt = timings.get("quotient", {"ms": 0.0, "launches": 0, "algorithmic_bytes": 0.0})
+            ent["ms_per_step"] = elapsed / steps * 1e3
+            solo = None
+            if hasattr(wl, "solo_step") and len(all_ctx) > 1:      # the dominant kernel with ONE batch in flight, as the main line does
+                wl.solo_step()
+                torch.cuda.synchronize(device)
+                ctx.profile(True)
+                wl.solo_step()
+                torch.cuda.synchronize(device)
+                solo = ctx.timings()
+                ctx.profile(False)
+            if name.startswith("proof_k"):
+                qname = "bzh_quotient" if wl.runner.quotient_codegen else "k_expr_vm2"
+                src = solo if solo is not None else timings
+                s_acc, s_q = src["msm_accumulate"], src.get("quotient", qt)
+                dom, dom_name = (s_q, qname) if s_q["ms"] > s_acc["ms"] else (s_acc, "k_msm_accumulate")
+                ent.update({"metric": "complete proofs per second (synthesis + create_proof), %sCircuit, k=%d" % (wl.runner.kind.capitalize(), wl.k),
+                            "value": units / elapsed, "unit": "proofs/s", "batch": wl.batch, "concurrent_batches": conc,
+                            "last_batches_verified": bool(wl.verify_last())})
+                basis = "HIP events, ONE batch in flight (1 step after the region)" if solo is not None else "HIP events over the region"
+            elif name.startswith("verify_k"):
+                dom, dom_name, basis = acc, "k_msm_accumulate", "HIP events over the region"
+                ent.update({"metric": "proof verifications per second, %sCircuit, k=%d" % (wl.runner.kind.capitalize(), wl.k),
+                            "value": units / elapsed, "unit": "verifications/s", "batch": batch, "accepted_in_last_batch": wl.accepted})
+            elif name == "msm24":
+                dom, dom_name, basis = dict(acc, algorithmic_bytes=wl.alg_bytes_msm_launch * acc["launches"]), "k_msm_accumulate", "HIP events over the region"
+                ent.update({"metric": "one 2^24-point MSM on %s: algorithmic GB/s of the whole call (96 B per point / call time)" % curve,
+                            "value": wl.alg_bytes_step * steps / elapsed / 1e9, "unit": "GB/s",
+                            "frac_of_hbm_peak": wl.alg_bytes_step * steps / elapsed / 1e9 / HBM_PEAK_GBS})
+            else:
+                dom, dom_name, basis = dict(nt, launches=steps, algorithmic_bytes=wl.alg_bytes_step * steps), "k_ntt_pass_wave (all passes of one NTT)", "HIP events over the region"
+                ent.update({"metric": "one 2^22 NTT over the scalar field of %s: algorithmic GB/s (64 B per element / call time)" % curve,
+                            "value": wl.alg_bytes_step * steps / elapsed / 1e9, "unit": "GB/s",
+                            "frac_of_hbm_peak": wl.alg_bytes_step * steps / elapsed / 1e9 / HBM_PEAK_GBS})
+            if dom["ms"] > 0 and dom["launches"]:
+                a_ms = dom["ms"] / dom["launches"]
+                a_bytes = dom["algorithmic_bytes"] / dom["launches"]
+                ach = a_bytes / (a_ms * 1e-3) / 1e9
+                ent["roofline"] = {"bound": "hbm", "kernel": dom_name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                   "traffic": None, "algorithmic_bytes_per_launch": a_bytes, "avg_launch_ms": a_ms, "basis": basis}
+            ent["kernel_ms_per_step"] = {kname: round(v["ms"] / steps, 3) for kname, v in timings.items() if v["launches"]}
+            if world == 1 and not args.no_cpu_baseline:
+                t_cpu = time.perf_counter()
+                if name.startswith("proof_k"):
+                    ent["cpu_baseline"] = cpu_baseline_proof(wl.runner)
+                elif name.startswith("verify_k"):
+                    ent["cpu_baseline"] = cpu_baseline_verify(wl.runner)
+                else:
+                    ent["cpu_baseline"] = cpu_baseline_micro(name, curve)
+                ent["cpu_baseline_s"] = round(time.perf_counter() - t_cpu, 2)
+        except Exception as e:  # noqa: BLE001
+            ent["error"] = "%r" % (e,)
+        try:
+            wl.close()
+        except Exception as e:  # noqa: BLE001
+            ent.setdefault("error", "close: %r" % (e,))
+        ent["wall_s"] = round(time.perf_counter() - t_begin, 2)
+        out[tag] = ent
+    return out
+
+
+
 def dry_run(args, rank, world):
     """--dry-run: the launcher / rendezvous / record-gather path without a GPU (gloo)."""
     import torch.distributed as dist
     from bzh2.shard import gather_records
-    if world > 1:
+    grouped = world > 1 or args.force_dist
+    if grouped:
+        if "MASTER_PORT" not in os.environ:      # --force-dist outside a launcher
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
     rec = torch.full((1, 8), rank, dtype=torch.uint8)
     t0 = time.perf_counter()
-    got = gather_records(rec, [1] * world, dist) if world > 1 else rec
+    got = gather_records(rec, [1] * world, dist) if grouped else rec
     elapsed = time.perf_counter() - t0
     if rank == 0:
         print(json.dumps({"metric": "dry run (no GPU work)", "value": 0.0, "unit": "proofs/s", "n_gpus": world, "steps": 0, "warmup": 0,
                           "ms_per_step": elapsed * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none",
-                          "data": "none", "config": {"workload": "dry_run", "ranks_gathered": sorted(int(v) for v in got[:, 0])}}))
-    if world > 1:
+                          "data": "none", "config": {"workload": "dry_run", "ranks_gathered": sorted(int(v) for v in got[:, 0]),
+                                     "dist": "gloo process group, world %d" % world if grouped else "none (one rank)"}}))
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 
@@ -722,12 +976,25 @@ def main():
     if args.dist_backend == "gloo":
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
+    # this rank's share of the node's host cores: witness synthesis threads, the lookup's sort helpers and the verifier's pool
+    # (libbzh2.so reads BZH_HOST_THREADS per call) -- 8 ranks on one node must not each start threads for the whole machine
+    cores_visible = len(os.sched_getaffinity(0))
+    host_threads = max(2, cores_visible // max(world, 1))
+    os.environ.setdefault("BZH_HOST_THREADS", str(host_threads))
+    host_threads = int(os.environ["BZH_HOST_THREADS"])
+    ProofRunner.SYNTH_THREADS = max(1, min(4, host_threads // max(args.concurrency, 1)))
     numa_node = pin_to_gpu_numa(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist_mod
         dist = dist_mod
+        if "MASTER_ADDR" not in os.environ or "MASTER_PORT" not in os.environ:     # --force-dist outside a launcher
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
@@ -782,9 +1049,12 @@ def main():
             wl.step()
         barrier()
     timings = ctx.timings()
+    per_stream = [{kname: v["ms"] for kname, v in timings.items()}]
     msm_adds = sum(c.msm_additions() for c in all_ctx)     # bucket additions actually made in the timed region (all contexts)
     for c in all_ctx[1:]:  # proofs in flight on their own ctx + stream: sum their kernel classes into the report
-        for kname, v in c.timings().items():
+        tc = c.timings()
+        per_stream.append({kname: v["ms"] for kname, v in tc.items()})
+        for kname, v in tc.items():
             for f in v:
                 timings[kname][f] += v[f]
     if profiled_steps != args.steps:   # totals as if measured over the timed region's steps (per-launch figures are unaffected)
@@ -794,6 +1064,7 @@ def main():
             v["ms"] *= f
             v["launches"] = int(round(v["launches"] * f))
             v["algorithmic_bytes"] *= f
+        per_stream = [{kname: ms * f for kname, ms in d.items()} for d in per_stream]
     for c in all_ctx:
         c.profile(False)
     # The same kernels with ONE batch in flight (two extra, untimed steps on the first context): with several batches
@@ -819,6 +1090,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    line = None
     if rank == 0:
         units = wl.units_per_step * args.steps * (1 if getattr(wl, "fixed_total", False) else world)
         is_proof = args.workload.startswith(("board", "shot"))
@@ -864,7 +1136,12 @@ def main():
                 dom_ms = s_dom["ms"] / s_dom["launches"]
                 alg = s_dom["algorithmic_bytes"] / s_dom["launches"]
                 roofline_basis = ("HIP events on the launch stream, ONE batch in flight (2 steps after the timed region); "
-                                  "the timed region's own per-launch average is in roofline.timed_region_average")
+                                  "the timed region's own per-launch average is in roofline.timed_region_average.  An event pair brackets "
+                                  "the kernel AND the command processor's hand-over on either side (the start event completes when the previous "
+                                  "kernel retires, the stop event after this one's end-of-kernel release): ~20-40 us per launch that rocprofv3's "
+                                  "kernel-only durations (profiles/r*_kernel_stats.csv) do not contain.  Most of a batch's ~25 accumulate launches "
+                                  "are the opening's short rounds, so the MEAN launch reads ~16 % longer here (r03: 1.88 ms against rocprof's "
+                                  "1.62 ms); `frac` is therefore a slight under-statement, never an over-statement")
         achieved = alg / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         # HBM-side traffic of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
         # separate runs of this same command), if one exists for this workload and kernel
@@ -914,16 +1191,34 @@ def main():
                               "none inside the timed region; kernel_ms and roofline from 2 extra untimed steps, scaled to the step count"),
         }
         line["config"]["host_threads_pinned_to_numa_node"] = numa_node
+        line["config"]["host_threads_per_rank"] = {"cores_visible": cores_visible, "world": world, "budget (BZH_HOST_THREADS)": host_threads,
+                                                   "prover_threads": args.concurrency, "synthesis_threads_per_prover": ProofRunner.SYNTH_THREADS,
+                                                   "sort_helpers_max": min(8, host_threads), "verifier_pool_max": min(32, host_threads)}
+        line["config"]["dist"] = (("%s process group, world %d%s" % (args.dist_backend, world, " (--force-dist)" if args.force_dist and world == 1 else ""))
+                                  if dist is not None else "none (one rank)")
+        # kernel_ms sums the host threads' contexts (their launches overlap on the GPU, so a class can exceed the timed region);
+        # per stream: the mean over the contexts, i.e. what ONE stream spent in each kernel class over the timed region
+        ns = max(len(per_stream), 1)
+        line["kernel_ms_per_stream"] = {"streams": ns, "ms": {kname: sum(d.get(kname, 0.0) for d in per_stream) / ns
+                                                              for kname in per_stream[0] if any(d.get(kname, 0.0) for d in per_stream)}}
         if (is_full or is_verify or is_mixed) and acc["ms"] > 0:
             # the bounds that actually bind these kernels: integer-multiplier rates against the same
             # operation in isolation (profiles/r*_ubench_field_gfx950.txt, read here); kernel time is summed over the host threads'
             # contexts, so overlapping batches understate the rates of the timed region
             wb = getattr(wl, "window_bits", 0) or 11
             nwin = (256 + wb - 1) // wb
-            alu = {"peaks_source": peaks["source"]}
+            # hardware-derived multiplier bound beside the self-referential `peak`s: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3 T
+            # lane-slots/s; a 256 x 256 -> 512-bit product + Montgomery reduction with a sparse modulus cannot avoid 64 + 32 = 96
+            # v_mad_u64_u32 (32 x 32 + 64 -> 64); an XYZZ mixed addition is 8 M + 2 S = 10 such products
+            lane_slots = 256 * 4 * 16 * 2.4e9
+            hw = {"lane_slots_per_s": lane_slots, "v_mad_u64_u32_per_fe_mul": 96, "fe_mul_G_per_s": lane_slots / 96 / 1e9,
+                  "xyzz_madd_G_per_s": lane_slots / 960 / 1e9,
+                  "note": "multiplier instructions only (no carries, loads, address arithmetic): a bound no 32-bit-limb implementation reaches"}
+            alu = {"peaks_source": peaks["source"], "hw_bound": hw}
             rate_a = msm_adds / (acc["ms"] * 1e-3) / 1e9
             alu["k_msm_accumulate"] = {"unit": "G mixed additions/s", "achieved": rate_a, "peak": peaks["xyzz_madd"],
                                        "frac": rate_a / peaks["xyzz_madd"] if peaks["xyzz_madd"] else None,
+                                       "frac_of_hw_bound": rate_a / hw["xyzz_madd_G_per_s"],
                                        "additions_per_step": msm_adds / max(args.steps, 1), "table_rows": nwin,
                                        "note": "bucket additions counted by the kernel (non-zero window digits only)"}
             if is_full and qt["ms"] > 0:
@@ -931,7 +1226,8 @@ def main():
                 rows = (1 << (wl.k + 3)) * wl.units_per_step * args.steps
                 rate = st["multiplications_per_row"] * rows / (qt["ms"] * 1e-3) / 1e9
                 alu["quotient"] = {"unit": "G field multiplications/s", "achieved": rate, "peak": peaks["fe_mul"],
-                                   "frac": rate / peaks["fe_mul"] if peaks["fe_mul"] else None, "program": st}
+                                   "frac": rate / peaks["fe_mul"] if peaks["fe_mul"] else None,
+                                   "frac_of_hw_bound": rate / hw["fe_mul_G_per_s"], "program": st}
             line["roofline"]["alu_equivalent"] = alu
             # what the whole GPU did over the timed region, against the two ALU yardsticks: independent of how launches overlap
             whole = {"G_mixed_additions_per_s": msm_adds / elapsed / 1e9,
@@ -1007,6 +1303,23 @@ def main():
                 line["cpu_baseline"] = cpu_baseline_proof(wl.runner)
             elif is_proof and args.workload != "shot_k11_batch":
                 line["cpu_baseline"] = cpu_baseline(args.workload, wl.k)
+            elif args.workload in ("msm24", "ntt22"):
+                line["cpu_baseline"] = cpu_baseline_micro(args.workload, args.curve)
+            elif is_verify:
+                line["cpu_baseline"] = cpu_baseline_verify(wl.runner)
+    # the rest of BASELINE.json's metric in the same line: short regions after the main one (every rank takes part)
+    want_others = args.other_workloads == "all" or (args.other_workloads == "auto" and args.workload == "proof_k14" and args.batch == 64
+                                                    and args.concurrency == 4 and not args.no_kernel_timers and not args.explicit_rng
+                                                    and not args.no_quotient_codegen and not args.window_bits)
+    others = None
+    if want_others:
+        wl.close()
+        others = run_other_workloads(args, ctx, device, rank, world, dist)
+    if rank == 0:
+        if others is not None:
+            line["config"]["other_workloads"] = others
+            line["config"]["other_workloads_note"] = ("short regions run after the main timed region in the same process, each workload freed before "
+                                                      "the next; `value` / `ms_per_step` of the line itself are the main workload's alone")
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()

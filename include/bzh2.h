@@ -449,6 +449,14 @@ int bzh_synthesize_bitify_test(const bzh_circuit* c, const uint64_t* value, cons
 int bzh_board_witness(const int8_t* ships, const int32_t* options, uint64_t* ship_commitments, uint64_t* state);
 int bzh_shot_serialize(const uint8_t* xs, const uint8_t* ys, size_t count, uint64_t* out);
 int bzh_pedersen_commit_host(const uint64_t* message, const uint64_t* trapdoor, uint64_t* out_xy);
+/* The same commitment for n (message, trapdoor) pairs in ONE launch on the device (the reference calls
+ * pedersen_commit once per proof from every frontend and a second time inside ShotChip::synthesize, src/chips/shot.rs:319,
+ * re-hashing V and R each time).  messages / trapdoors: n x 4 canonical limbs (host) -- the message is an Fp value re-read as a
+ * Pallas scalar through its repr, as pedersen.rs:23-24 does; out_xy: n affine canonical points x || y, (0, 0) = identity.
+ * V and R live in a ctx-owned direct-lookup table (d * 2^(8w) * G for 32 signed 8-bit windows, 512 KB, built on the first
+ * call): 64 mixed additions + one inversion per commitment, one lane each.  BZH_E_RANGE: a repr that is not a canonical
+ * Pallas scalar (from_repr(..).unwrap() panics upstream).  Returns when out_xy is filled. */
+int bzh_pedersen_commit_batch(bzh_ctx* ctx, const uint64_t* messages, const uint64_t* trapdoors, size_t n, uint64_t* out_xy);
 int bzh_fixed_base_tables(int base, uint64_t* z, uint64_t* u, uint64_t* lagrange);
 
 /* ---- host helpers (CPU, no device needed): what `.to_affine()` / `to_bytes()`

@@ -34,3 +34,12 @@ def test_gpus_1_stays_one_process():
 def test_gpus_that_contradicts_world_size_is_refused():
     r = _run(["--gpus", "8", "--dry-run"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29999"})
     assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
+
+
+def test_force_dist_joins_a_group_with_one_rank():
+    """--force-dist: world size 1 still goes through init_process_group, the record gather and the barrier (the GPU counterpart
+    runs them over RCCL: tests/test_gpu_bench_ranks.py)"""
+    r = _run(["--gpus", "1", "--dry-run", "--force-dist", "--dist-backend", "gloo"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["config"]["ranks_gathered"] == [0] and line["config"]["dist"].startswith("gloo process group")

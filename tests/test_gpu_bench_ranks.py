@@ -53,3 +53,23 @@ def test_weak_scaling_two_ranks_line(gpu_ctx):
                    "--concurrency", "2", "--no-cpu-baseline"])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["last_batches_verified"]
     assert line["value"] > 0 and abs(line["value"] - 2 * 16 * 2 * 2 / (line["ms_per_step"] * 2 / 1e3)) < 1e-6 * line["value"]
+
+
+def test_the_rccl_path_runs_with_one_rank(gpu_ctx, tmp_path):
+    """`--force-dist`: with WORLD_SIZE = 1 bench.py still does init_process_group("nccl", device_id=...) -- RCCL --, the device
+    all_gather of the proof records (uint8, fixed stride), the barriers and the MAX all_reduce of the elapsed time: everything the
+    8-GPU run executes except a second peer.  The gathered records decode and verify like the ungrouped run's."""
+    from bzh2.wire import BattleZipsRecord, KIND_SHOT
+    common = ["--workload", "proof_k11", "--steps", "2", "--warmup", "1", "--batch", "8", "--concurrency", "2", "--no-cpu-baseline",
+              "--other-workloads", "none"]
+    grouped = _bench(common + ["--force-dist", "--records-out", str(tmp_path / "g.npy")])
+    plain = _bench(common + ["--records-out", str(tmp_path / "p.npy")])
+    assert grouped["n_gpus"] == 1 and grouped["config"]["dist"].startswith("nccl process group, world 1")
+    assert plain["config"]["dist"].startswith("none")
+    assert grouped["config"]["last_batches_verified"] and grouped["config"]["host_threads_per_rank"]["world"] == 1
+    a, b = np.load(tmp_path / "g.npy"), np.load(tmp_path / "p.npy")
+    assert a.shape == b.shape and a.shape[0] == 16
+    ra = [BattleZipsRecord.from_fixed(a[i].tobytes()) for i in range(a.shape[0])]
+    rb = [BattleZipsRecord.from_fixed(b[i].tobytes()) for i in range(b.shape[0])]
+    assert all(r.kind == KIND_SHOT for r in ra) and sorted(r.index for r in ra) == sorted(r.index for r in rb)
+    assert {r.index: r.proof for r in ra} == {r.index: r.proof for r in rb}      # seeds derive from the proof index: same bytes
