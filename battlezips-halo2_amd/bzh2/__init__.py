@@ -40,7 +40,7 @@ CURVE_SCALAR_FIELD = {CURVE_VESTA: FIELD_FP, CURVE_PALLAS: FIELD_FQ, CURVE_BN254
 EXPORTS = [
     "bzh_version", "bzh_strerror", "bzh_device_count", "bzh_ctx_create", "bzh_ctx_create_on_stream",
     "bzh_ctx_destroy", "bzh_ctx_sync", "bzh_last_error", "bzh_ctx_profile", "bzh_ctx_timings", "bzh_ctx_work", "bzh_ctx_msm_additions",
-    "bzh_bases_upload", "bzh_bases_precompute", "bzh_bases_free", "bzh_bases_len", "bzh_msm", "bzh_ntt", "bzh_coeff_to_extended",
+    "bzh_bases_upload", "bzh_bases_precompute", "bzh_bases_free", "bzh_bases_len", "bzh_bases_walk", "bzh_bases_points", "bzh_msm", "bzh_ntt", "bzh_coeff_to_extended",
     "bzh_jacobian_to_affine", "bzh_jacobian_sum", "bzh_affine_compress", "bzh_field_omega",
 ]
 
@@ -204,6 +204,23 @@ class Context:
             ptr, mem = ctypes.c_void_p(xy.ctypes.data), MEM_HOST
         self._check(load().bzh_bases_upload(self.handle, curve, ptr, n, form, mem, ctypes.byref(h)), "bzh_bases_upload")
         return Bases(self, h, curve, n)
+
+    def bases_walk(self, curve: int, g_xy, n: int, form: int = FORM_CANONICAL) -> Bases:
+        """bases[i] = [i + 1] G for i < n, made on the device (bzh_bases_walk); g_xy: 8 limbs of one affine point"""
+        g = np.ascontiguousarray(g_xy, dtype=np.uint64).reshape(8)
+        h = ctypes.c_void_p()
+        L = load()
+        L.bzh_bases_walk.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]
+        self._check(L.bzh_bases_walk(self.handle, curve, ctypes.c_void_p(g.ctypes.data), form, n, ctypes.byref(h)), "bzh_bases_walk")
+        return Bases(self, h, curve, n)
+
+    def bases_points(self, bases: Bases, first: int, count: int) -> np.ndarray:
+        """points [first, first + count) of a table as (count, 8) canonical limbs (bzh_bases_points)"""
+        out = np.zeros((count, 8), dtype=np.uint64)
+        L = load()
+        L.bzh_bases_points.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p]
+        self._check(L.bzh_bases_points(self.handle, bases.handle, first, count, ctypes.c_void_p(out.ctypes.data)), "bzh_bases_points")
+        return out
 
     # ---- MSM ----
     def msm(self, bases: Bases, scalars: np.ndarray, form: int = FORM_CANONICAL) -> np.ndarray:

@@ -532,7 +532,9 @@ class Workload:
             self.k = k
             mine = shard_range(n, rank, world)
             nl = len(mine)
-            self.bases = ctx.upload_bases(self.curve, make_bases(ctx, self.curve, nl, 77 + rank))
+            # the rank's points: G_r, 2 G_r, ..., nl G_r for a rank-specific random G_r, made on the device (bzh_bases_walk: the
+            # 1 GB of a 2^24-point table never crosses PCIe; SURVEY 8d's "cheap generator walk")
+            self.bases = ctx.bases_walk(self.curve, make_bases(ctx, self.curve, 1, 77 + rank)[0], nl)
             if precompute:
                 self.bases.precompute()
             self.msm_scalars = rand_field((1, nl), gen, device)

@@ -121,6 +121,13 @@ int bzh_bases_upload(bzh_ctx* ctx, int curve, const uint64_t* xy, size_t n, int 
  * share one bucket set and the final doubling chain disappears.  Costs ceil(256/c) x the table's HBM
  * (k=14: 25 MB) and a one-time build; results are identical with or without it. */
 int bzh_bases_precompute(bzh_ctx* ctx, bzh_bases* bases, int window_bits);
+/* A synthetic table made on the device: bases[i] = [i + 1] G for i < n (SURVEY 8d's "cheap generator walk" for the 2^24-point
+ * MSM microbench, BASELINE.json configs[4]: 1 GB of points that never cross PCIe).  g_xy: one affine point in `form` (host).
+ * The CPU oracle's orc_point_walk makes the same set. */
+int bzh_bases_walk(bzh_ctx* ctx, int curve, const uint64_t* g_xy, int form, size_t n, bzh_bases** out);
+/* `count` points of a table from index `first`, affine canonical x || y into out_xy (host); a window table continues through
+ * its rows (row w starts at w * n).  BZH_E_RANGE past the end. */
+int bzh_bases_points(bzh_ctx* ctx, const bzh_bases* bases, size_t first, size_t count, uint64_t* out_xy);
 int bzh_bases_free(bzh_ctx* ctx, bzh_bases* bases);
 size_t bzh_bases_len(const bzh_bases* bases);
 

@@ -221,3 +221,33 @@ def test_msm_precomputed_many_vectors_chunk_presum(gpu_ctx, oracle_c, nvec):
         assert got == oracle_compressed(0, bases, batch)
     finally:
         hb.free()
+
+
+@pytest.mark.parametrize("cid", [0, 1, 2])
+def test_bases_walk_is_the_oracles_point_walk(gpu_ctx, oracle_c, cid):
+    """bzh_bases_walk (the device-made base set of the 2^24-point microbench, BASELINE.json configs[4]): bases[i] = [i + 1] G,
+    against the oracle's orc_point_walk -- sizes that end inside a thread's run of 16, on it, and across many workgroups --
+    read back through bzh_bases_points; and an MSM over the walked table equals the oracle's over its own walk."""
+    import random
+    import numpy as np
+    import pasta as O
+    cv = O.CURVE_BY_ID[cid]
+    g = oracle_c.points_to_array([cv.random_point(random.Random(90 + cid))])[0]
+    for n in (1, 15, 16, 17, 1000, 70001):
+        want = oracle_c.point_walk(cid, g, n)
+        b = gpu_ctx.bases_walk(cid, g, n)
+        try:
+            got = gpu_ctx.bases_points(b, 0, n)
+            assert (got == want).all(), (cid, n, int(np.argmax((got != want).any(axis=1))))
+            if n >= 1000:
+                assert (gpu_ctx.bases_points(b, n - 7, 7) == want[n - 7:]).all()
+                rng = np.random.default_rng(n)
+                sc = np.frombuffer(rng.bytes(n * 32), dtype=np.uint64).reshape(n, 4).copy()
+                sc[:, 3] &= (1 << 60) - 1
+                import bzh2
+                got_pt = oracle_c.array_to_point(bzh2.jacobian_to_affine(cid, gpu_ctx.msm(b, sc))[0])
+                assert got_pt == oracle_c.array_to_point(oracle_c.msm(cid, sc, want, 8))
+                with pytest.raises(bzh2.BzhError):
+                    gpu_ctx.bases_points(b, n - 1, 2)
+        finally:
+            b.free()
