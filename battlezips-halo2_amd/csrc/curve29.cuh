@@ -1,0 +1,108 @@
+// The bucket accumulator of k_msm_accumulate in unsaturated limbs (csrc/fe29.cuh): XYZZ mixed addition with the running sum
+// held as 4 x 9 limbs of 29 bits in R' = 2^261 Montgomery form, NOT canonical -- invariants after every operation:
+//     x < 11.5 p, y < 7.5 p, zz < 2 p, zzz < 2 p, every limb carried (< 2^29 + 8), identity kept as a flag.
+// The table points arrive in the saturated 2^256 form every other kernel uses and are re-sliced on the fly (x 2^5 = the R' form,
+// ~25 shifts per coordinate); a finished bucket goes back through one product per coordinate (fe29_to_sat).  Same group element
+// as curve.cuh's xyzz_madd computes, hence the same MSM result and the same proof bytes.
+#pragma once
+#include "curve.cuh"
+#include "fe29.cuh"
+
+namespace bzh {
+
+template <class P>
+struct Xyzz29 {
+    Fe29<P> x, y, zz, zzz;
+    bool id;
+};
+// constants of the representation, built once per thread from compile-time words (host: at first use)
+template <class P>
+struct Fe29Consts {
+    Fe29<P> one;      // 2^261 mod p: the R' form of 1, and the factor that reduces a re-sliced table coordinate below 2 p
+    Fe29<P> two256;   // 2^256 mod p: R' form -> saturated form
+};
+template <class P>
+BZH_HD Fe29Consts<P> fe29_consts() {
+    uint32_t w[8];
+    Fe29Consts<P> c;
+    fe29_pow2_mod_p<P>(261, w);
+    c.one = fe29_from_raw<P>(w);
+    fe29_pow2_mod_p<P>(256, w);
+    c.two256 = fe29_from_raw<P>(w);
+    return c;
+}
+
+template <class P>
+BZH_HD Xyzz29<P> xyzz29_identity() {
+    Xyzz29<P> r;
+    r.x = fe29_zero<P>();
+    r.y = r.x;
+    r.zz = r.x;
+    r.zzz = r.x;
+    r.id = true;
+    return r;
+}
+// is the carried value a multiple of p?  (exact; rare path only)
+template <class P>
+BZH_HD bool fe29_is_zero_mod_p(const Fe29<P>& v, const Fe29Consts<P>& k) {
+    return fe_is_zero(fe29_pack_canonical(fe29_mul(v, k.one)));
+}
+template <class P>
+BZH_HD Xyzz<P> xyzz29_to_sat(const Xyzz29<P>& a, const Fe29Consts<P>& k) {
+    if (a.id) return xyzz_identity<P>();
+    Xyzz<P> r;
+    r.x = fe29_to_sat(a.x, k.two256);
+    r.y = fe29_to_sat(a.y, k.two256);
+    r.zz = fe29_to_sat(a.zz, k.two256);
+    r.zzz = fe29_to_sat(a.zzz, k.two256);
+    return r;
+}
+template <class P>
+BZH_HD Xyzz29<P> xyzz29_from_sat(const Xyzz<P>& a, const Fe29Consts<P>& k) {
+    if (xyzz_is_id(a)) return xyzz29_identity<P>();
+    Xyzz29<P> r;
+    r.x = fe29_mul(fe29_from_sat_x32(a.x), k.one);
+    r.y = fe29_mul(fe29_from_sat_x32(a.y), k.one);
+    r.zz = fe29_mul(fe29_from_sat_x32(a.zz), k.one);
+    r.zzz = fe29_mul(fe29_from_sat_x32(a.zzz), k.one);
+    r.id = false;
+    return r;
+}
+
+// acc += q, q affine in the saturated form (not the identity).  madd-2008-s, 8 M + 2 S, as curve.cuh's xyzz_madd.
+template <class P>
+BZH_HD void xyzz29_madd(Xyzz29<P>& acc, const Affine<P>& q, const Fe29Consts<P>& k) {
+    const Fe29<P> qx = fe29_from_sat_x32(q.x), qy = fe29_from_sat_x32(q.y);   // < 32 p each: one factor of a product only
+    if (acc.id) {
+        acc.x = fe29_mul(qx, k.one);
+        acc.y = fe29_mul(qy, k.one);
+        acc.zz = k.one;
+        acc.zzz = k.one;
+        acc.id = false;
+        return;
+    }
+    const Fe29<P> u2 = fe29_mul(qx, acc.zz);                 // < 2 p
+    const Fe29<P> s2 = fe29_mul(qy, acc.zzz);
+    const Fe29<P> pp_ = fe29_sub<P, 16>(u2, acc.x);          // in (4.5 p, 18 p); = k p exactly when the x coordinates agree
+    const Fe29<P> r = fe29_sub<P, 16>(s2, acc.y);
+    // p = 1 mod 2^29 and the carried low limb is exact: a multiple k p of p, 4 < k <= 18, shows its k there
+    if (pp_.l[0] - 5u <= 13u && fe29_is_zero_mod_p(pp_, k)) {
+        if (fe29_is_zero_mod_p(r, k)) {
+            acc = xyzz29_from_sat(xyzz_dbl_affine(q), k);      // acc == q: doubling (rare; through the saturated code)
+        } else {
+            acc = xyzz29_identity<P>();                        // acc == -q
+        }
+        return;
+    }
+    const Fe29<P> pp = fe29_sqr(pp_);                        // < 3.5 p
+    const Fe29<P> ppp = fe29_mul(pp_, pp);                   // < 2 p
+    const Fe29<P> qq = fe29_mul(acc.x, pp);                  // < 2 p
+    const Fe29<P> x3 = fe29_sub3<P, 4>(fe29_sqr(r), ppp, qq);   // R^2 - PPP - 2 Q + 8 p < 11.5 p
+    const Fe29<P> t = fe29_mul(acc.y, ppp);                  // < 2 p
+    acc.y = fe29_sub<P, 4>(fe29_mul(r, fe29_sub<P, 16>(qq, x3)), t);   // < 3.5 p + 4 p
+    acc.x = x3;
+    acc.zz = fe29_mul(acc.zz, pp);
+    acc.zzz = fe29_mul(acc.zzz, ppp);
+}
+
+}  // namespace bzh

@@ -1,0 +1,271 @@
+// Unsaturated field arithmetic for the MSM's bucket accumulation: 9 limbs of 29 bits in 32-bit words.
+//
+// The saturated product (field_mul_fips.inc) spends one v_addc_co_u32 on every v_mad_u64_u32: its column sums are 96 bits wide
+// (96 multiply-adds + 96 carry instructions of the ~245 issue slots of a product).  With 29-bit limbs a column of the schoolbook
+// product holds at most 9 products of 2^30 x 2^30 plus 5 reduction products of 2^29 x 2^29 -- < 2^64 -- so a column is a plain
+// chain of v_mad_u64_u32 into ONE 64-bit accumulator, no carry instruction at all; the price is 81 + 45 multiply-adds instead of
+// 64 + 32 and a shift / mask per column.  Additions are 9 independent v_add_u32 (no carry chain), subtractions add a multiple of
+// p whose limbs dominate the subtrahend's and are followed by one parallel carry pass.
+//
+// Montgomery form with R' = 2^261 (9 x 29 bits).  Both Pasta moduli are 1 mod 2^32, hence 1 mod 2^29: -p^-1 = -1 mod 2^29 and the
+// quotient digit of a column is the negated low limb, no multiplication; p has five non-zero 29-bit limbs besides limb 0
+// (limbs 1..4 and 2^22 in limb 8).
+//
+// Bounds (values are NOT kept canonical):
+//   fe29_mul / fe29_sqr   inputs: limbs < 2^30 (one lazy addition of carried values), a * b < 2^515;
+//                         output: value < 2 p, limbs 0..7 < 2^29, limb 8 < 2^24
+//   fe29_add              limb-wise, no carry: use at most once before a product
+//   fe29_sub<K>           a - b + K p, carried; K p is written with limbs >= 2^30 - 2, so b's limbs may be anything < 2^30 - 2 and
+//                         b's top limb at most (K p >> 232) - 2, i.e. b < K p
+//   fe29_carry            one parallel pass: limbs 0..7 < 2^29 + 8
+// Interface with the saturated 2^256-Montgomery world (what every table, bucket plane and kernel outside the accumulation loop
+// holds): fe29_from_sat_x32 re-slices v * 2^5 (a value x 2^256 becomes x 2^261 = the R' form, unreduced: < 32 p, fine as ONE factor
+// of a product whose other factor is < 2 p); fe29_to_sat multiplies by 2^256 (back to x 2^256), reduces fully and packs 8 words.
+#pragma once
+#include "field.cuh"
+
+namespace bzh {
+
+template <class P>
+struct Fe29 {
+    uint32_t l[9];
+};
+
+constexpr uint32_t kM29 = (1u << 29) - 1;
+
+// limb i of the modulus in radix 2^29
+template <class P>
+BZH_HD constexpr uint32_t fe29_p(int i) {
+    const int bit = 29 * i, w = bit >> 5, s = bit & 31;
+    const uint64_t lo = w < 8 ? P::mod(w) : 0u, hi = w + 1 < 8 ? P::mod(w + 1) : 0u;
+    return (uint32_t)(((lo | (hi << 32)) >> s) & kM29);
+}
+template <class P>
+constexpr bool fe29_supported() {
+    return (P::mod(0) & kM29) == 1u && fe29_p<P>(5) == 0u && fe29_p<P>(6) == 0u && fe29_p<P>(7) == 0u;
+}
+
+// limb i of K * p written with every limb but the top one raised by 2^30 (and the limb above lowered by 2): a subtrahend with
+// limbs < 2^30 can be taken off limb-wise without a borrow
+template <class P, int K>
+BZH_HD constexpr uint32_t fe29_bias(int i) {
+    // canonical digits of K * p
+    uint64_t carry = 0;
+    uint32_t d = 0;
+    for (int j = 0; j <= i; j++) {
+        const uint64_t v = (uint64_t)fe29_p<P>(j) * K + carry;
+        d = j < 8 ? (uint32_t)(v & kM29) : (uint32_t)v;
+        carry = j < 8 ? v >> 29 : 0;
+    }
+    if (i == 0) return d + (1u << 30);
+    if (i < 8) return d + (1u << 30) - 2u;
+    return d - 2u;
+}
+
+template <class P>
+BZH_HD Fe29<P> fe29_zero() {
+    Fe29<P> r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = 0;
+    return r;
+}
+
+// (a * b + m * p) / 2^261, column by column
+template <class P>
+BZH_HD Fe29<P> fe29_mul(const Fe29<P>& a, const Fe29<P>& b) {
+    static_assert(fe29_supported<P>(), "fe29: modulus must be 1 mod 2^29 with zero limbs 5..7 (the Pasta fields)");
+    uint64_t acc = 0;
+    uint32_t m[9];
+    Fe29<P> r;
+#pragma unroll
+    for (int k = 0; k < 17; k++) {
+#pragma unroll
+        for (int j = (k > 8 ? k - 8 : 0); j <= (k < 8 ? k : 8); j++) acc += (uint64_t)a.l[j] * b.l[k - j];
+#pragma unroll
+        for (int j = (k > 8 ? k - 8 : 0); j <= (k - 1 < 8 ? k - 1 : 8); j++) {
+            if (fe29_p<P>(k - j) != 0u) acc += (uint64_t)m[j] * fe29_p<P>(k - j);
+        }
+        if (k < 9) {
+            m[k] = (0u - (uint32_t)acc) & kM29;   // p = 1 mod 2^29: the digit that clears the column's low limb
+            acc += m[k];                          // (m_k * p_0)
+            acc >>= 29;
+        } else {
+            r.l[k - 9] = (uint32_t)acc & kM29;
+            acc >>= 29;
+        }
+    }
+    r.l[8] = (uint32_t)acc;
+    return r;
+}
+
+template <class P>
+BZH_HD Fe29<P> fe29_sqr(const Fe29<P>& a) {
+    static_assert(fe29_supported<P>(), "fe29: unsupported modulus");
+    uint64_t acc = 0;
+    uint32_t m[9], d[9];
+    Fe29<P> r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) d[i] = a.l[i] << 1;
+#pragma unroll
+    for (int k = 0; k < 17; k++) {
+#pragma unroll
+        for (int j = (k > 8 ? k - 8 : 0); 2 * j < k; j++) acc += (uint64_t)d[j] * a.l[k - j];
+        if ((k & 1) == 0) acc += (uint64_t)a.l[k >> 1] * a.l[k >> 1];
+#pragma unroll
+        for (int j = (k > 8 ? k - 8 : 0); j <= (k - 1 < 8 ? k - 1 : 8); j++) {
+            if (fe29_p<P>(k - j) != 0u) acc += (uint64_t)m[j] * fe29_p<P>(k - j);
+        }
+        if (k < 9) {
+            m[k] = (0u - (uint32_t)acc) & kM29;
+            acc += m[k];
+            acc >>= 29;
+        } else {
+            r.l[k - 9] = (uint32_t)acc & kM29;
+            acc >>= 29;
+        }
+    }
+    r.l[8] = (uint32_t)acc;
+    return r;
+}
+
+template <class P>
+BZH_HD Fe29<P> fe29_add(const Fe29<P>& a, const Fe29<P>& b) {
+    Fe29<P> r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = a.l[i] + b.l[i];
+    return r;
+}
+// one parallel carry pass: every limb keeps its low 29 bits and takes the overflow of the limb below
+template <class P>
+BZH_HD Fe29<P> fe29_carry(const Fe29<P>& a) {
+    Fe29<P> r;
+    r.l[0] = a.l[0] & kM29;
+#pragma unroll
+    for (int i = 1; i < 8; i++) r.l[i] = (a.l[i] & kM29) + (a.l[i - 1] >> 29);
+    r.l[8] = a.l[8] + (a.l[7] >> 29);
+    return r;
+}
+// a - b + K p, carried.  b: limbs < 2^30 and value < (K p's top limb allows): K = 4 for b < 2 p, K = 8 for b < 4 p.
+template <class P, int K>
+BZH_HD Fe29<P> fe29_sub(const Fe29<P>& a, const Fe29<P>& b) {
+    Fe29<P> r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = a.l[i] + (fe29_bias<P, K>(i) - b.l[i]);
+    return fe29_carry(r);
+}
+// a - b - c - c + K p (the x3 of the mixed addition: R^2 - PPP - 2 Q), carried.  K p must dominate b + 2 c limb-wise: every bias
+// limb is ~2^30 + digit, so b, c are taken in carried form (limbs < 2^29 + 8) and the bias is used TWICE (2 K p).
+template <class P, int K>
+BZH_HD Fe29<P> fe29_sub3(const Fe29<P>& a, const Fe29<P>& b, const Fe29<P>& c) {
+    Fe29<P> r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = a.l[i] + (2u * fe29_bias<P, K>(i) - b.l[i] - 2u * c.l[i]);
+    return fe29_carry(r);   // limbs stay below 2^32 (2^31 + 2^30 + 2^29): one pass leaves them under 2^29 + 8
+}
+
+// ---- saturated (8 x 32, 2^256-Montgomery, < p) <-> fe29 ----------------------------------------------------------
+// v * 2^5 re-sliced into 9 limbs: bit 29 i of the result is bit 29 i - 5 of v
+template <class P>
+BZH_HD Fe29<P> fe29_from_sat_x32(const Fe<P>& v) {
+    Fe29<P> r;
+    r.l[0] = (v.l[0] << 5) & kM29;
+#pragma unroll
+    for (int i = 1; i < 9; i++) {
+        const int bit = 29 * i - 5, w = bit >> 5, s = bit & 31;
+        const uint32_t lo = v.l[w] >> s, hi = (s && w + 1 < 8) ? v.l[w + 1] << (32 - s) : 0u;
+        r.l[i] = (lo | hi) & kM29;
+    }
+    return r;
+}
+// constants in fe29 form from a value given as 8 saturated words (raw integer, not shifted)
+template <class P>
+BZH_HD Fe29<P> fe29_from_raw(const uint32_t w8[8]) {
+    Fe29<P> r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const int bit = 29 * i, w = bit >> 5, s = bit & 31;
+        const uint32_t lo = w < 8 ? w8[w] >> s : 0u, hi = (s && w + 1 < 8) ? w8[w + 1] << (32 - s) : 0u;
+        r.l[i] = (lo | hi) & kM29;
+    }
+    return r;
+}
+// 2^k mod p as 8 raw words (host / constexpr-free: a few doublings at first use are cheap, but the kernels want constants):
+// computed by doubling from 1 with conditional subtraction
+template <class P>
+BZH_HD void fe29_pow2_mod_p(int k, uint32_t out[8]) {
+    uint32_t v[8] = {1, 0, 0, 0, 0, 0, 0, 0};
+    for (int s = 0; s < k; s++) {
+        uint32_t c = 0;
+        for (int i = 0; i < 8; i++) {
+            const uint32_t n = (v[i] << 1) | c;
+            c = v[i] >> 31;
+            v[i] = n;
+        }
+        // v < 2 p < 2^256: subtract p if v >= p
+        bool ge = true;
+        for (int i = 7; i >= 0; i--) {
+            if (v[i] != P::mod(i)) {
+                ge = v[i] > P::mod(i);
+                break;
+            }
+        }
+        if (ge) {
+            uint64_t br = 0;
+            for (int i = 0; i < 8; i++) {
+                const uint64_t d = (uint64_t)v[i] - P::mod(i) - br;
+                v[i] = (uint32_t)d;
+                br = (d >> 63) & 1;
+            }
+        }
+    }
+    for (int i = 0; i < 8; i++) out[i] = v[i];
+}
+// full reduction of a carried value < 4 p to the canonical representative, packed into 8 saturated words
+template <class P>
+BZH_HD Fe<P> fe29_pack_canonical(const Fe29<P>& a) {
+    // exact digits: sequential carry
+    uint32_t d[9];
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint32_t t = a.l[i] + c;
+        d[i] = t & kM29;
+        c = t >> 29;
+    }
+    d[8] = a.l[8] + c;
+    // subtract p while >= p (at most three times for a value < 4 p)
+#pragma unroll
+    for (int rep = 0; rep < 3; rep++) {
+        uint32_t t[9];
+        uint32_t br = 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            const uint32_t s = d[i] - fe29_p<P>(i) - br;
+            br = (i < 8) ? (s >> 31) : 0u;          // limb went negative: borrow from the limb above
+            t[i] = (i < 8) ? (s & kM29) : s;
+        }
+        const bool neg = (int32_t)t[8] < 0;
+        if (!neg) {
+#pragma unroll
+            for (int i = 0; i < 9; i++) d[i] = t[i];
+        }
+    }
+    Fe<P> r;
+#pragma unroll
+    for (int w = 0; w < 8; w++) {
+        // word w holds bits [32 w, 32 w + 32): from limbs floor(32 w / 29) ...
+        const int bit = 32 * w, i = bit / 29, s = bit - 29 * i;
+        uint64_t v = (uint64_t)d[i] >> s;
+        if (i + 1 < 9) v |= (uint64_t)d[i + 1] << (29 - s);
+        if (i + 2 < 9 && 58 - s < 32) v |= (uint64_t)d[i + 2] << (58 - s);
+        r.l[w] = (uint32_t)v;
+    }
+    return r;
+}
+// R'-form (x 2^261, < 2 p or so) -> saturated 2^256-Montgomery (< p): one product with 2^256 mod p, full reduction, repack
+template <class P>
+BZH_HD Fe<P> fe29_to_sat(const Fe29<P>& a, const Fe29<P>& two256) {
+    return fe29_pack_canonical(fe29_mul(a, two256));
+}
+
+}  // namespace bzh

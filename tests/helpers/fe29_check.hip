@@ -1,0 +1,118 @@
+// Test program (not product code): the unsaturated 9 x 29-bit field arithmetic of the bucket accumulator (csrc/fe29.cuh,
+// csrc/curve29.cuh) against the library's saturated host arithmetic, on the two Pasta fields -- products and squares of random and
+// edge operands at the documented input bounds (lazily added, biased-subtracted, 32 p re-sliced inputs), the round trip with the
+// saturated form, and chains of mixed additions (incl. the doubling and the inverse special cases) against curve.cuh's xyzz_madd
+// as group elements.  Host code only.  Prints one line per field; tests/test_fe29_cpu.py asserts "OK".
+#include <cstdio>
+#include <cstdint>
+#include <cstring>
+#include <random>
+#include <vector>
+#include "curve29.cuh"
+using namespace bzh;
+
+template <class P>
+static Fe<P> rnd(std::mt19937_64& rng) {
+    Fe<P> v;
+    for (int i = 0; i < 8; i++) v.l[i] = (uint32_t)rng();
+    v.l[7] &= 0x3fffffffu;   // < 2^254 < p
+    return v;
+}
+template <class P>
+static Fe<P> mul32x(const Fe<P>& a) {   // a * 32 mod p (saturated, canonical in / out)
+    Fe<P> r = a;
+    for (int i = 0; i < 5; i++) r = fe_dbl(r);
+    return r;
+}
+// the value a fe29 operand stands for, as a saturated 2^256-Montgomery element: v29 = X * 2^261  ->  X * 2^256
+template <class P>
+static Fe<P> sat_of(const Fe29<P>& a, const Fe29Consts<P>& k) {
+    return fe29_to_sat(a, k.two256);
+}
+
+template <class C>
+static bool check(const char* name) {
+    using P = typename C::Base;
+    std::mt19937_64 rng(2929);
+    const Fe29Consts<P> k = fe29_consts<P>();
+    long fails = 0, cases = 0;
+    auto expect = [&](bool ok, const char* what) {
+        cases++;
+        if (!ok && fails++ < 5) printf("  %s: FAIL %s\n", name, what);
+    };
+    std::vector<Fe<P>> vals;
+    vals.push_back(fe_zero<P>());
+    vals.push_back(fe_one<P>());
+    Fe<P> pm1;
+    for (int i = 0; i < 8; i++) pm1.l[i] = P::mod(i);
+    pm1.l[0] -= 1;
+    vals.push_back(pm1);
+    for (int i = 0; i < 200; i++) vals.push_back(rnd<P>(rng));
+    // round trip and products: from_sat_x32(A) stands for A's value in R' form
+    for (size_t i = 0; i < vals.size(); i++) {
+        const Fe<P> A = vals[i], B = vals[(i * 7 + 3) % vals.size()];
+        const Fe29<P> a = fe29_from_sat_x32(A), b = fe29_mul(fe29_from_sat_x32(B), k.one);
+        expect(fe_eq(sat_of(fe29_mul(a, k.one), k), A), "round trip");
+        expect(fe_eq(sat_of(fe29_mul(a, b), k), fe_mul(A, B)), "mul (32 p x 2 p)");
+        const Fe29<P> ar = fe29_mul(a, k.one);
+        expect(fe_eq(sat_of(fe29_sqr(ar), k), fe_sqr(A)), "sqr");
+        expect(fe_eq(sat_of(fe29_mul(fe29_add(ar, b), fe29_add(b, b)), k), fe_mul(fe_add(A, B), fe_dbl(B))), "mul of lazy sums");
+        const Fe29<P> d16 = fe29_sub<P, 16>(ar, b), d4 = fe29_sub<P, 4>(b, ar);
+        expect(fe_eq(sat_of(d16, k), fe_sub(A, B)), "sub<16>");
+        expect(fe_eq(sat_of(d4, k), fe_sub(B, A)), "sub<4>");
+        expect(fe_eq(sat_of(fe29_sqr(d16), k), fe_sqr(fe_sub(A, B))), "sqr of an 18 p operand");
+        expect(fe_eq(sat_of(fe29_mul(d16, fe29_sub<P, 16>(b, ar)), k), fe_mul(fe_sub(A, B), fe_sub(B, A))), "18 p x 18 p");
+        expect(fe_eq(sat_of(fe29_sub3<P, 4>(fe29_sqr(d16), ar, b), k), fe_sub(fe_sub(fe_sqr(fe_sub(A, B)), A), fe_dbl(B))), "sub3");
+        expect(fe29_is_zero_mod_p(fe29_sub<P, 16>(ar, fe29_mul(a, k.one)), k), "a - a is a multiple of p");
+        for (int j = 0; j < 8; j++) expect(d16.l[j] < (1u << 29) + 8u, "carried limb bound");
+    }
+    // chains of mixed additions against the saturated code, as group elements
+    Affine<P> g;
+    {   // a curve point: x = 1, 2, ... until x^3 + b is a square (p = 1 mod 4: Tonelli via exponent is heavy; use the generator)
+        // (-1, 2) on Pasta: 4 = -1 + 5
+        g.x = fe_neg(fe_one<P>());
+        g.y = fe_from_u32<P>(2);
+    }
+    std::vector<Affine<P>> pts;
+    {
+        Xyzz<P> w = xyzz_from_affine(g);
+        for (int i = 0; i < 40; i++) {
+            pts.push_back(xyzz_to_affine(w));
+            w = xyzz_dbl(w);
+            xyzz_madd(w, g);
+        }
+    }
+    for (int trial = 0; trial < 6; trial++) {
+        Xyzz<P> ref = xyzz_identity<P>();
+        Xyzz29<P> acc = xyzz29_identity<P>();
+        for (int i = 0; i < 300; i++) {
+            Affine<P> q = pts[rng() % pts.size()];
+            if (trial == 1 && i == 1) q = pts[0], (void)0;
+            if (trial >= 1 && i == 0) q = pts[0];
+            if (trial == 1 && i == 1) q = pts[0];                         // acc == q: the doubling path
+            if (trial == 2 && i == 1) { q = pts[0]; q.y = fe_neg(q.y); }  // acc == -q: back to the identity
+            if (rng() & 1) q.y = fe_neg(q.y);
+            if (trial == 1 && i == 1) q = pts[0];
+            if (trial == 2 && i == 1) { q = pts[0]; q.y = fe_neg(q.y); }
+            xyzz_madd(ref, q);
+            xyzz29_madd(acc, q, k);
+            if (i < 4 || i % 50 == 49) {
+                const Affine<P> a = xyzz_to_affine(ref), b = xyzz_to_affine(xyzz29_to_sat(acc, k));
+                expect(fe_eq(a.x, b.x) && fe_eq(a.y, b.y), "mixed-addition chain");
+            }
+        }
+        // invariants of the representation
+        if (!acc.id) {
+            for (int j = 0; j < 8; j++) expect(acc.x.l[j] < (1u << 29) + 8u && acc.y.l[j] < (1u << 29) + 8u, "accumulator limb bound");
+            expect(acc.x.l[8] < (12u << 22) && acc.y.l[8] < (8u << 22) && acc.zz.l[8] <= (2u << 22) && acc.zzz.l[8] <= (2u << 22), "accumulator value bound");
+        }
+    }
+    printf("%s: %ld cases, %ld failures -> %s\n", name, cases, fails, fails ? "FAIL" : "OK");
+    return fails == 0;
+}
+
+int main() {
+    bool ok = check<PallasCurve>("fe29 over Fp (Pallas coordinates)");
+    ok = check<VestaCurve>("fe29 over Fq (Vesta coordinates)") && ok;
+    return ok ? 0 : 1;
+}
