@@ -425,7 +425,8 @@ Context.vec_mul = _ctx_vec_mul
 
 
 # ---- transcript (host) ---------------------------------------------------------------------------
-EXPORTS += ["bzh_pk_quotient_select", "bzh_pk_quotient_selected", "bzh_quotient_source_for_circuit", "bzh_builtin_quotients"]
+EXPORTS += ["bzh_pk_quotient_select", "bzh_pk_quotient_selected", "bzh_quotient_source_for_circuit", "bzh_builtin_quotients",
+            "bzh_quotient_degree_histogram"]
 EXPORTS += ["bzh_record_stride", "bzh_record_encode", "bzh_record_decode", "bzh_record_to_json", "bzh_record_from_json"]
 EXPORTS += ["bzh_transcript_new", "bzh_transcript_free", "bzh_transcript_common_point", "bzh_transcript_common_scalar",
             "bzh_transcript_write_point", "bzh_transcript_write_scalar", "bzh_transcript_squeeze_challenge",

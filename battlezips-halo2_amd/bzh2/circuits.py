@@ -112,6 +112,15 @@ class CircuitLayout:
         _check(_bind().bzh_circuit_vk_repr(self.handle, out, ctypes.byref(ph)), "bzh_circuit_vk_repr")
         return int.from_bytes(bytes(out), "little"), bool(ph.value)
 
+    def quotient_degree_histogram(self, curve: int = 0):
+        """{degree: (terms, tree multiplications)} of the quotient numerator of this circuit (bzh_quotient_degree_histogram)"""
+        L = _bind()
+        L.bzh_quotient_degree_histogram.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t, _VP, _VP]
+        blob = self.blob()
+        polys, muls = np.zeros(16, dtype=np.uint32), np.zeros(16, dtype=np.uint32)
+        _check(L.bzh_quotient_degree_histogram(curve, blob, len(blob), _VP(polys.ctypes.data), _VP(muls.ctypes.data)), "bzh_quotient_degree_histogram")
+        return {d: (int(polys[d]), int(muls[d])) for d in range(16) if polys[d]}
+
     def describe(self) -> dict:
         L = _bind()
         n = ctypes.c_size_t()

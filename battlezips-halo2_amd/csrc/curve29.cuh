@@ -23,12 +23,12 @@ struct Fe29Consts {
 };
 template <class P>
 BZH_HD Fe29Consts<P> fe29_consts() {
-    uint32_t w[8];
     Fe29Consts<P> c;
-    fe29_pow2_mod_p<P>(261, w);
-    c.one = fe29_from_raw<P>(w);
-    fe29_pow2_mod_p<P>(256, w);
-    c.two256 = fe29_from_raw<P>(w);
+    static_for<9>([&](auto i) {
+        constexpr uint32_t one_i = fe29_pow2_limb<P, 261>(decltype(i)::value), t_i = fe29_pow2_limb<P, 256>(decltype(i)::value);
+        c.one.l[decltype(i)::value] = one_i;
+        c.two256.l[decltype(i)::value] = t_i;
+    });
     return c;
 }
 
@@ -57,6 +57,24 @@ BZH_HD Xyzz<P> xyzz29_to_sat(const Xyzz29<P>& a, const Fe29Consts<P>& k) {
     r.zzz = fe29_to_sat(a.zzz, k.two256);
     return r;
 }
+// the same without products (fe29_to_sat_div32), branch-free: what the accumulate kernel's hand-over pass runs
+template <class P>
+BZH_HD Xyzz<P> xyzz29_to_sat_fast(const Xyzz29<P>& a) {
+    Xyzz<P> r;
+    r.x = fe29_to_sat_div32(a.x);
+    r.y = fe29_to_sat_div32(a.y);
+    r.zz = fe29_to_sat_div32(a.zz);
+    r.zzz = fe29_to_sat_div32(a.zzz);
+    const uint32_t keep = a.id ? 0u : 0xffffffffu;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        r.x.l[i] &= keep;
+        r.y.l[i] &= keep;
+        r.zz.l[i] &= keep;
+        r.zzz.l[i] &= keep;
+    }
+    return r;
+}
 template <class P>
 BZH_HD Xyzz29<P> xyzz29_from_sat(const Xyzz<P>& a, const Fe29Consts<P>& k) {
     if (xyzz_is_id(a)) return xyzz29_identity<P>();
@@ -69,13 +87,38 @@ BZH_HD Xyzz29<P> xyzz29_from_sat(const Xyzz<P>& a, const Fe29Consts<P>& k) {
     return r;
 }
 
+// the special cases of the mixed addition, out of line: reached when P = u2 - x1 shows a small multiple of p in its low limb
+// (14 chances in 2^29 for unrelated points).  Behind a call, so that the compiler cannot hoist the exact test -- a product and a
+// canonical reduction -- into the main path; everything by VALUE: an accumulator whose address is passed to a function lives in
+// scratch memory, and scratch accesses share the vector-memory counter with the table gathers (every wait for a spilled limb
+// then also waits for the point prefetched for the next iteration: 1.8 x on the whole kernel, measured).
+template <class P>
+struct Madd29Special {
+    Xyzz29<P> v;
+    bool handled;
+};
+template <class P>
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __noinline__
+#else
+inline
+#endif
+Madd29Special<P> xyzz29_madd_special(const Affine<P> q, const Fe29<P> pp_, const Fe29<P> r) {
+    const Fe29Consts<P> k = fe29_consts<P>();
+    Madd29Special<P> out;
+    out.v = xyzz29_identity<P>();                                                    // acc == -q
+    out.handled = fe29_is_zero_mod_p(pp_, k);
+    if (out.handled && fe29_is_zero_mod_p(r, k)) out.v = xyzz29_from_sat(xyzz_dbl_affine(q), k);   // acc == q: doubling, through the saturated code
+    return out;
+}
+
 // acc += q, q affine in the saturated form (not the identity).  madd-2008-s, 8 M + 2 S, as curve.cuh's xyzz_madd.
 template <class P>
 BZH_HD void xyzz29_madd(Xyzz29<P>& acc, const Affine<P>& q, const Fe29Consts<P>& k) {
-    const Fe29<P> qx = fe29_from_sat_x32(q.x), qy = fe29_from_sat_x32(q.y);   // < 32 p each: one factor of a product only
-    if (acc.id) {
-        acc.x = fe29_mul(qx, k.one);
-        acc.y = fe29_mul(qy, k.one);
+    const Fe29<P> qx = fe29_from_sat_reduced(q.x), qy = fe29_from_sat_reduced(q.y);   // < 2 p, carried
+    if (acc.id) {   // first point of a bucket: lanes reach this on different iterations, so it has to be free
+        acc.x = qx;
+        acc.y = qy;
         acc.zz = k.one;
         acc.zzz = k.one;
         acc.id = false;
@@ -86,13 +129,12 @@ BZH_HD void xyzz29_madd(Xyzz29<P>& acc, const Affine<P>& q, const Fe29Consts<P>&
     const Fe29<P> pp_ = fe29_sub<P, 16>(u2, acc.x);          // in (4.5 p, 18 p); = k p exactly when the x coordinates agree
     const Fe29<P> r = fe29_sub<P, 16>(s2, acc.y);
     // p = 1 mod 2^29 and the carried low limb is exact: a multiple k p of p, 4 < k <= 18, shows its k there
-    if (pp_.l[0] - 5u <= 13u && fe29_is_zero_mod_p(pp_, k)) {
-        if (fe29_is_zero_mod_p(r, k)) {
-            acc = xyzz29_from_sat(xyzz_dbl_affine(q), k);      // acc == q: doubling (rare; through the saturated code)
-        } else {
-            acc = xyzz29_identity<P>();                        // acc == -q
+    if (pp_.l[0] - 5u <= 13u) {
+        const Madd29Special<P> sp = xyzz29_madd_special<P>(q, pp_, r);
+        if (sp.handled) {
+            acc = sp.v;
+            return;
         }
-        return;
     }
     const Fe29<P> pp = fe29_sqr(pp_);                        // < 3.5 p
     const Fe29<P> ppp = fe29_mul(pp_, pp);                   // < 2 p

@@ -70,61 +70,64 @@ BZH_HD Fe29<P> fe29_zero() {
     return r;
 }
 
-// (a * b + m * p) / 2^261, column by column
+// (a * b + m * p) / 2^261.  Every column of the product gets its OWN 64-bit accumulator: the 81 limb products are independent
+// multiply-adds (nothing but the column they land in orders them), and only the Montgomery pass -- carry in, quotient digit, the
+// digit's five products with p's non-zero limbs dealt to the columns above -- is a dependent chain.  One running accumulator
+// (the textbook product scanning) makes ALL 126 multiply-adds one chain: fine while two waves per SIMD alternate, but whenever the
+// other wave waits for its table gather the lone wave issues a dependent v_mad_u64_u32 only every other slot -- measured in
+// k_msm_accumulate as 0.8 instructions per slot against 1.0 for the saturated code, which ate the whole gain.
+template <class P>
+BZH_HD void fe29_montgomery_pass(uint64_t (&c)[17], Fe29<P>& r) {
+    uint64_t carry = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        c[k] += carry;
+        const uint32_t m = (0u - (uint32_t)c[k]) & kM29;   // p = 1 mod 2^29: the digit that clears the column's low limb
+        carry = (c[k] + kM29) >> 29;                        // = (c_k + m) >> 29 without waiting for m
+#pragma unroll
+        for (int l = 1; l < 9; l++) {
+            if (fe29_p<P>(l) != 0u) c[k + l] += (uint64_t)m * fe29_p<P>(l);
+        }
+    }
+#pragma unroll
+    for (int k = 9; k < 17; k++) {
+        c[k] += carry;
+        r.l[k - 9] = (uint32_t)c[k] & kM29;
+        carry = c[k] >> 29;
+    }
+    r.l[8] = (uint32_t)carry;
+}
 template <class P>
 BZH_HD Fe29<P> fe29_mul(const Fe29<P>& a, const Fe29<P>& b) {
     static_assert(fe29_supported<P>(), "fe29: modulus must be 1 mod 2^29 with zero limbs 5..7 (the Pasta fields)");
-    uint64_t acc = 0;
-    uint32_t m[9];
-    Fe29<P> r;
+    uint64_t c[17];
 #pragma unroll
     for (int k = 0; k < 17; k++) {
+        c[k] = 0;
 #pragma unroll
-        for (int j = (k > 8 ? k - 8 : 0); j <= (k < 8 ? k : 8); j++) acc += (uint64_t)a.l[j] * b.l[k - j];
-#pragma unroll
-        for (int j = (k > 8 ? k - 8 : 0); j <= (k - 1 < 8 ? k - 1 : 8); j++) {
-            if (fe29_p<P>(k - j) != 0u) acc += (uint64_t)m[j] * fe29_p<P>(k - j);
-        }
-        if (k < 9) {
-            m[k] = (0u - (uint32_t)acc) & kM29;   // p = 1 mod 2^29: the digit that clears the column's low limb
-            acc += m[k];                          // (m_k * p_0)
-            acc >>= 29;
-        } else {
-            r.l[k - 9] = (uint32_t)acc & kM29;
-            acc >>= 29;
-        }
+        for (int j = (k > 8 ? k - 8 : 0); j <= (k < 8 ? k : 8); j++) c[k] += (uint64_t)a.l[j] * b.l[k - j];
     }
-    r.l[8] = (uint32_t)acc;
+    Fe29<P> r;
+    fe29_montgomery_pass<P>(c, r);
     return r;
 }
 
 template <class P>
 BZH_HD Fe29<P> fe29_sqr(const Fe29<P>& a) {
     static_assert(fe29_supported<P>(), "fe29: unsupported modulus");
-    uint64_t acc = 0;
-    uint32_t m[9], d[9];
-    Fe29<P> r;
+    uint64_t c[17];
+    uint32_t d[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) d[i] = a.l[i] << 1;
 #pragma unroll
     for (int k = 0; k < 17; k++) {
+        c[k] = 0;
 #pragma unroll
-        for (int j = (k > 8 ? k - 8 : 0); 2 * j < k; j++) acc += (uint64_t)d[j] * a.l[k - j];
-        if ((k & 1) == 0) acc += (uint64_t)a.l[k >> 1] * a.l[k >> 1];
-#pragma unroll
-        for (int j = (k > 8 ? k - 8 : 0); j <= (k - 1 < 8 ? k - 1 : 8); j++) {
-            if (fe29_p<P>(k - j) != 0u) acc += (uint64_t)m[j] * fe29_p<P>(k - j);
-        }
-        if (k < 9) {
-            m[k] = (0u - (uint32_t)acc) & kM29;
-            acc += m[k];
-            acc >>= 29;
-        } else {
-            r.l[k - 9] = (uint32_t)acc & kM29;
-            acc >>= 29;
-        }
+        for (int j = (k > 8 ? k - 8 : 0); 2 * j < k; j++) c[k] += (uint64_t)d[j] * a.l[k - j];
+        if ((k & 1) == 0) c[k] += (uint64_t)a.l[k >> 1] * a.l[k >> 1];
     }
-    r.l[8] = (uint32_t)acc;
+    Fe29<P> r;
+    fe29_montgomery_pass<P>(c, r);
     return r;
 }
 
@@ -177,6 +180,27 @@ BZH_HD Fe29<P> fe29_from_sat_x32(const Fe<P>& v) {
     }
     return r;
 }
+// v (saturated, canonical) -> v * 2^5 mod p in carried limbs, value < 2 p: the R' form of a table coordinate, fit to BE an
+// accumulator coordinate.  32 v = top 2^254 + low and 2^254 = -c (mod p), c = p - 2^254 (limbs 0..4 of p): low + p - top c.
+template <class P>
+BZH_HD Fe29<P> fe29_from_sat_reduced(const Fe<P>& v) {
+    Fe29<P> t = fe29_from_sat_x32(v);
+    const uint32_t top = t.l[8] >> 22;           // < 64
+    t.l[8] &= (1u << 22) - 1u;
+    uint32_t e[6];
+    uint64_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        acc += (uint64_t)top * fe29_p<P>(i);
+        e[i] = (uint32_t)acc & kM29;
+        acc >>= 29;
+    }
+    e[5] = (uint32_t)acc;
+    Fe29<P> r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = t.l[i] + (fe29_bias<P, 1>(i) - (i < 6 ? e[i] : 0u));
+    return fe29_carry(r);
+}
 // constants in fe29 form from a value given as 8 saturated words (raw integer, not shifted)
 template <class P>
 BZH_HD Fe29<P> fe29_from_raw(const uint32_t w8[8]) {
@@ -189,11 +213,15 @@ BZH_HD Fe29<P> fe29_from_raw(const uint32_t w8[8]) {
     }
     return r;
 }
-// 2^k mod p as 8 raw words (host / constexpr-free: a few doublings at first use are cheap, but the kernels want constants):
-// computed by doubling from 1 with conditional subtraction
+// 2^k mod p as 8 raw words, by doubling from 1 with a conditional subtraction: constant-evaluated (fe29_k below)
 template <class P>
-BZH_HD void fe29_pow2_mod_p(int k, uint32_t out[8]) {
-    uint32_t v[8] = {1, 0, 0, 0, 0, 0, 0, 0};
+struct Fe29Words {
+    uint32_t w[8];
+};
+template <class P>
+BZH_HD constexpr Fe29Words<P> fe29_pow2_mod_p(int k) {
+    Fe29Words<P> r{{1, 0, 0, 0, 0, 0, 0, 0}};
+    uint32_t* v = r.w;
     for (int s = 0; s < k; s++) {
         uint32_t c = 0;
         for (int i = 0; i < 8; i++) {
@@ -218,7 +246,15 @@ BZH_HD void fe29_pow2_mod_p(int k, uint32_t out[8]) {
             }
         }
     }
-    for (int i = 0; i < 8; i++) out[i] = v[i];
+    return r;
+}
+// limb i (radix 2^29) of 2^k mod p, a compile-time constant
+template <class P, int K>
+BZH_HD constexpr uint32_t fe29_pow2_limb(int i) {
+    constexpr Fe29Words<P> w = fe29_pow2_mod_p<P>(K);
+    const int bit = 29 * i, wi = bit >> 5, s = bit & 31;
+    const uint64_t lo = wi < 8 ? w.w[wi] : 0u, hi = wi + 1 < 8 ? w.w[wi + 1] : 0u;
+    return (uint32_t)(((lo | (hi << 32)) >> s) & kM29);
 }
 // full reduction of a carried value < 4 p to the canonical representative, packed into 8 saturated words
 template <class P>
@@ -259,6 +295,76 @@ BZH_HD Fe<P> fe29_pack_canonical(const Fe29<P>& a) {
         if (i + 1 < 9) v |= (uint64_t)d[i + 1] << (29 - s);
         if (i + 2 < 9 && 58 - s < 32) v |= (uint64_t)d[i + 2] << (58 - s);
         r.l[w] = (uint32_t)v;
+    }
+    return r;
+}
+// R'-form (x 2^261, carried, < 128 p) -> saturated 2^256-Montgomery (< p) WITHOUT a product: the two forms differ by 2^5, and
+// p = 1 mod 32, so  v / 32 = (u + ((-u) mod 32) p) >> 5  for the canonical u = v mod p -- exact digits, one fold of the bits above
+// 2^254 (2^254 = -c mod p), one conditional subtraction, five small multiply-adds, a re-slice: ~170 instructions against ~370
+// for fe29_to_sat.  This is what a finished bucket costs on its way back to the planes every other kernel reads.
+template <class P>
+BZH_HD Fe<P> fe29_to_sat_div32(const Fe29<P>& a) {
+    // 1. exact digits
+    uint32_t d[9], c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint32_t t = a.l[i] + c;
+        d[i] = t & kM29;
+        c = t >> 29;
+    }
+    d[8] = a.l[8] + c;
+    // 2. v = top 2^254 + low = low - top c (mod p):  w = low + p - top c  in (0, 2 p)
+    const uint32_t top = d[8] >> 22;
+    d[8] &= (1u << 22) - 1u;
+    uint32_t e[6];
+    uint64_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        acc += (uint64_t)top * fe29_p<P>(i);
+        e[i] = (uint32_t)acc & kM29;
+        acc >>= 29;
+    }
+    e[5] = (uint32_t)acc;
+    uint32_t w[9];
+    c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint32_t t = d[i] + (fe29_bias<P, 1>(i) - (i < 6 ? e[i] : 0u)) + c;
+        w[i] = t & kM29;
+        c = t >> 29;
+    }
+    w[8] = d[8] + fe29_bias<P, 1>(8) + c;
+    // 3. u = w - p if that is not negative
+    uint32_t u[9], br = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const uint32_t t = w[i] - fe29_p<P>(i) - br;
+        br = i < 8 ? t >> 31 : 0u;
+        u[i] = i < 8 ? t & kM29 : t;
+    }
+    const bool neg = (int32_t)u[8] < 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) u[i] = neg ? w[i] : u[i];
+    // 4. z = u + m p, m = -u mod 32: divisible by 32; z >> 5 < p
+    const uint32_t m = (0u - u[0]) & 31u;
+    uint32_t z[9];
+    acc = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        acc += (uint64_t)u[i];
+        if (fe29_p<P>(i) != 0u) acc += (uint64_t)m * fe29_p<P>(i);
+        z[i] = i < 8 ? (uint32_t)acc & kM29 : (uint32_t)acc;
+        acc >>= 29;
+    }
+    // 5. words of z >> 5: bit 32 w + 5 of z onwards
+    Fe<P> r;
+#pragma unroll
+    for (int wd = 0; wd < 8; wd++) {
+        const int bit = 32 * wd + 5, i = bit / 29, sh = bit - 29 * i;
+        uint64_t v = (uint64_t)z[i] >> sh;
+        if (i + 1 < 9) v |= (uint64_t)z[i + 1] << (29 - sh);
+        if (i + 2 < 9 && 58 - sh < 32) v |= (uint64_t)z[i + 2] << (58 - sh);
+        r.l[wd] = (uint32_t)v;
     }
     return r;
 }

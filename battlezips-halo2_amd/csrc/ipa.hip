@@ -440,11 +440,11 @@ static int ipa_open_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_po
                        (kHc + 4) * 8;
     const size_t tail_words = jstar ? B * (tail_m + 2) * (size_t)tail_nwin * 16 + (tail_scratch + 3) / 4 + 64 : 0;
     void* arena = nullptr;
-    IPA_TRY(ws_ensure(ctx, 4, (B * per + tail_words) * 4 + 256, &arena));
+    IPA_TRY(ws_ensure(ctx, 4, (B * per + tail_words) * 4 + 256 + 16 * 16, &arena));   // (+ the roundings of take())
     uint32_t* cur = (uint32_t*)arena;
-    auto take = [&](size_t w) {
+    auto take = [&](size_t w) {   // every piece starts 16-byte aligned (uint4 loads / stores): word counts rounded up to 4
         uint32_t* r = cur;
-        cur += w;
+        cur += (w + 3) & ~(size_t)3;
         return r;
     };
     uint32_t* d_raw = take(B * nrand * 16);

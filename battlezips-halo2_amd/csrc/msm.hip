@@ -19,7 +19,7 @@
 //   k_msm_finalize    otherwise, per vector: sum chunks per window, Horner over windows
 // Modular-integer work (v_mad_u64_u32), no MFMA.
 #include "ctx.hpp"
-#include "curve.cuh"
+#include "curve29.cuh"
 
 namespace bzh {
 
@@ -229,8 +229,50 @@ __device__ __forceinline__ void block_exclusive_scan(uint32_t* a, int len, uint3
 // partial B; B is suffix-reduced per bucket across threads (Hillis-Steele over a global
 // scratch pair, log2(span) steps) and the starting thread stores A + B'.
 // ---------------------------------------------------------------------------
-template <class C, int T>
-__global__ void __launch_bounds__(T) k_msm_accumulate(const uint32_t* __restrict__ bases,
+// U29: the running sum of a slice is kept in unsaturated 9 x 29-bit limbs (csrc/fe29.cuh, curve29.cuh: no carry instruction in
+// the products, 1.13 x the mixed additions per second at this kernel's two waves per SIMD); table points are re-sliced as they
+// arrive and a finished bucket is converted back, so every byte outside the loop -- tables, bucket planes, stitch buffers -- is
+// what the saturated variant reads and writes.  The Pasta curves only (p = 1 mod 2^29 with three zero limbs).
+template <class P>
+__device__ __forceinline__ Xyzz<P> acc29_to_sat(const Xyzz29<P>& a) {
+    return xyzz29_to_sat_fast(a);   // product-free (x 2^-5 exactly), inline: no call, no copy of the argument through scratch
+}
+// A finished running sum leaves the loop RAW: its 36 limb words as they are, limbs 0..7 of the four coordinates in the eight planes
+// a saturated bucket occupies and the four ninth limbs in one extra uint4 (identity: all zero).  Lanes end buckets on different
+// iterations, so whatever the hand-over costs is paid by the whole wave on nearly every iteration: a conversion there (four
+// products and canonical reductions) made the kernel 1.6 x slower than the saturated one.  Raw buckets are converted in place
+// by a uniform pass at the end of the kernel.
+template <class P>
+__device__ __forceinline__ void raw29_put(uint4* planes, size_t stride, size_t t, uint4* ninth, const Xyzz29<P>& v) {
+    const Fe29<P>* f[4] = {&v.x, &v.y, &v.zz, &v.zzz};
+    const uint32_t keep = v.id ? 0u : 0xffffffffu;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        planes[(2 * k) * stride + t] = make_uint4(f[k]->l[0] & keep, f[k]->l[1] & keep, f[k]->l[2] & keep, f[k]->l[3] & keep);
+        planes[(2 * k + 1) * stride + t] = make_uint4(f[k]->l[4] & keep, f[k]->l[5] & keep, f[k]->l[6] & keep, f[k]->l[7] & keep);
+    }
+    ninth[t] = make_uint4(v.x.l[8] & keep, v.y.l[8] & keep, v.zz.l[8] & keep, v.zzz.l[8] & keep);
+}
+template <class P>
+__device__ __forceinline__ Xyzz29<P> raw29_get(const uint4* planes, size_t stride, size_t t, const uint4* ninth) {
+    Xyzz29<P> v;
+    Fe29<P>* f[4] = {&v.x, &v.y, &v.zz, &v.zzz};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint4 a = planes[(2 * k) * stride + t], b = planes[(2 * k + 1) * stride + t];
+        f[k]->l[0] = a.x; f[k]->l[1] = a.y; f[k]->l[2] = a.z; f[k]->l[3] = a.w;
+        f[k]->l[4] = b.x; f[k]->l[5] = b.y; f[k]->l[6] = b.z; f[k]->l[7] = b.w;
+    }
+    const uint4 n = ninth[t];
+    v.x.l[8] = n.x, v.y.l[8] = n.y, v.zz.l[8] = n.z, v.zzz.l[8] = n.w;
+    uint32_t any = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) any |= v.zz.l[i];
+    v.id = any == 0u;     // zz = Z^2 is never 0 mod p for a point, and a raw identity is stored as zeros
+    return v;
+}
+template <class C, int T, bool U29>
+__device__ __forceinline__ void msm_accumulate_body(const uint32_t* __restrict__ bases,
                                                                   const uint16_t* __restrict__ digits, size_t n, int nwin,
                                                                   int M, size_t chunk, uint4* __restrict__ buckets,
                                                                   uint4* __restrict__ partials, size_t row_len,
@@ -316,8 +358,13 @@ __global__ void __launch_bounds__(T) k_msm_accumulate(const uint32_t* __restrict
     // bucket m owns sorted[cnt[m-1] .. cnt[m]); cnt[M] = number of non-zero digits
     const size_t segi = (b * (size_t)nwin + w) * nchunks + ck;
     uint4* seg = buckets + segi * (size_t)M * 8;
-    uint4* pbuf0 = partials + segi * (size_t)(2 * T) * 8;
+    // per segment: two stitch buffers of T x 8 planes; U29: + the ninth limbs of raw buckets [M] and of raw head partials [T]
+    const size_t part_stride = (size_t)(2 * T) * 8 + (U29 ? (size_t)M + (size_t)T : (size_t)0);
+    uint4* pbuf0 = partials + segi * part_stride;
     uint4* pbuf1 = pbuf0 + (size_t)T * 8;
+    uint4* raw9 = pbuf1 + (size_t)T * 8;
+    uint4* raw9_head = raw9 + (size_t)M;
+    (void)raw9_head;
     // Precomputed tables: item e of the flattened [window][point] digit array addresses row
     // e / row_len, column e % row_len of a table whose rows are row_stride points apart
     // (row_len < row_stride when a prefix of the table is used).  row_len == 0: plain bases.
@@ -333,9 +380,50 @@ __global__ void __launch_bounds__(T) k_msm_accumulate(const uint32_t* __restrict
     for (int m = 1 + tid; m <= M; m += T)
         if (cnt[m] == cnt[m - 1]) planes_put(seg, (size_t)M, (size_t)(m - 1), xyzz_identity<P>());
 
-    Xyzz<P> acc = xyzz_identity<P>();
+    // what the slice leaves for the stitch below
+    Xyzz<P> acc = xyzz_identity<P>();   // the slice's last partial sum (start of a cut bucket), saturated
     uint32_t head_id = 0, tail_id = 0;  // tail_id: bucket whose sum continues in later threads (acc = A)
     bool tail_through = false;          // ... and that had also begun before this slice (A is the identity)
+    // The slice, in one of two arithmetics chosen PER WORKGROUP (uniform): unsaturated limbs when the chunk is dense (on average
+    // 8 or more points per bucket: the n-term commitments of h, f, s, the random polynomial, the opening's rounds), saturated
+    // when it is sparse (witness columns in the Lagrange basis leave one or two points per bucket: there a bucket's conversion
+    // back to the saturated form would cost as much as the additions it holds -- measured: 63.6 ms per batch of 64 with the
+    // unsaturated loop everywhere against 39.9 saturated).
+    auto slice = [&](auto u29_tag) {
+    constexpr bool U = decltype(u29_tag)::value;
+    // the slice's running sum: saturated XYZZ, or (U) the unsaturated form
+    using Acc = typename std::conditional<U, Xyzz29<P>, Xyzz<P>>::type;
+    Acc run;
+    Fe29Consts<P> k29;
+    if constexpr (U) {
+        run = xyzz29_identity<P>();
+        k29 = fe29_consts<P>();
+    } else {
+        run = xyzz_identity<P>();
+    }
+    auto run_value = [&]() -> Xyzz<P> {
+        if constexpr (U) return acc29_to_sat<P>(run);
+        else return run;
+    };
+    auto run_clear = [&] {
+        if constexpr (U) run = xyzz29_identity<P>();
+        else run = xyzz_identity<P>();
+    };
+    // hand-over of a finished sum INSIDE the loop: raw (U29) or as it is
+    auto put_bucket = [&](uint32_t m) {
+        if constexpr (U) raw29_put<P>(seg, (size_t)M, (size_t)(m - 1), raw9, run);
+        else planes_put(seg, (size_t)M, (size_t)(m - 1), run);
+    };
+    bool head_raw = false;   // U29: the head partial in pbuf0 is still raw
+    (void)head_raw;
+    auto put_head = [&] {
+        if constexpr (U) {
+            raw29_put<P>(pbuf0, (size_t)T, (size_t)tid, raw9_head, run);
+            head_raw = true;
+        } else {
+            planes_put(pbuf0, (size_t)T, (size_t)tid, run);
+        }
+    };
     if (start < end) {
         // first bucket with cnt[m] > start
         uint32_t lo = 1, hi = (uint32_t)M;
@@ -366,42 +454,63 @@ __global__ void __launch_bounds__(T) k_msm_accumulate(const uint32_t* __restrict
         for (uint32_t j = start; j < end; j++) {
             if (j == bend) {  // bucket m ended inside this slice
                 if (bbeg < start) {  // head partial: parked in the stitch buffer, not in registers
-                    planes_put(pbuf0, (size_t)T, (size_t)tid, acc);
+                    put_head();
                     head_id = m;
                 } else {
-                    planes_put(seg, (size_t)M, (size_t)(m - 1), acc);
+                    put_bucket(m);
                 }
-                acc = xyzz_identity<P>();
+                run_clear();
                 do { m++; } while (cnt[m] <= j);
                 bbeg = cnt[m - 1];
                 bend = cnt[m];
             }
             const uint32_t e = e_next;
             Affine<P> q = q_next;
-            if (j + 1 < end) {
+            if (j + 1 < end) {   // (a second point in flight -- prefetch two additions ahead -- measured no better: 39.7 vs 38.7 ms per batch)
                 e_next = sorted[j + 1];
                 q_next = affine_load<P>(base0 + point_index(e_next) * 16);
             }
             if (!aff_is_id(q)) {
                 if (e & 0x8000u) q.y = fe_neg(q.y);
-                xyzz_madd(acc, q);
+                if constexpr (U) xyzz29_madd(run, q, k29);
+                else xyzz_madd(run, q);
             }
         }
         // last segment of the slice: bucket m, items [max(bbeg,start), min(bend,end))
         if (bend > end) {
             tail_id = m;
             if (bbeg < start) {  // neither begins nor ends here
-                planes_put(pbuf0, (size_t)T, (size_t)tid, acc);
+                put_head();
                 head_id = m;
-                acc = xyzz_identity<P>();
                 tail_through = true;
+            } else {
+                acc = run_value();   // the start of a cut bucket: the stitch continues with it (once per thread, outside the loop)
             }
         } else if (bbeg < start) {
-            planes_put(pbuf0, (size_t)T, (size_t)tid, acc);
+            put_head();
             head_id = m;
         } else {
-            planes_put(seg, (size_t)M, (size_t)(m - 1), acc);
+            put_bucket(m);
         }
+    }
+    if constexpr (U) {
+        // raw -> saturated, uniformly: every thread its own head partial (nearly every slice begins inside a bucket) ...
+        if (head_raw) planes_put(pbuf0, (size_t)T, (size_t)tid, acc29_to_sat<P>(raw29_get<P>(pbuf0, (size_t)T, (size_t)tid, raw9_head)));
+        // ... and the buckets that lie inside ONE slice (those were put raw; cut buckets are written by the stitch below, empty ones
+        // above), M / T each whoever summed them
+        __syncthreads();
+        for (int m = 1 + tid; m <= M; m += T) {
+            const uint32_t b0 = cnt[m - 1], b1 = cnt[m];
+            if (b1 > b0 && b0 / L == (b1 - 1) / L)
+                planes_put(seg, (size_t)M, (size_t)(m - 1), acc29_to_sat<P>(raw29_get<P>(seg, (size_t)M, (size_t)(m - 1), raw9)));
+        }
+    }
+    };
+    if constexpr (U29) {
+        if (total >= 8u * (uint32_t)M) slice(std::true_type{});
+        else slice(std::false_type{});
+    } else {
+        slice(std::false_type{});
     }
     // ---- stitch buckets cut by slice boundaries (uniform control flow from here) ----
     idB[tid] = head_id;
@@ -434,6 +543,19 @@ __global__ void __launch_bounds__(T) k_msm_accumulate(const uint32_t* __restrict
         }
     }
 }
+
+#define BZH_ACC_PARAMS                                                                                                       \
+    const uint32_t *__restrict__ bases, const uint16_t *__restrict__ digits, size_t n, int nwin, int M, size_t chunk,              \
+        uint4 *__restrict__ buckets, uint4 *__restrict__ partials, size_t row_len, size_t row_stride, size_t dup_from,            \
+        unsigned long long *__restrict__ add_counter, size_t vec_col_stride, size_t vec0, uint32_t xcd_vecs, uint32_t xcd_chunks
+#define BZH_ACC_ARGS \
+    bases, digits, n, nwin, M, chunk, buckets, partials, row_len, row_stride, dup_from, add_counter, vec_col_stride, vec0, xcd_vecs, xcd_chunks
+template <class C, int T, bool U29>
+__global__ void __launch_bounds__(T) k_msm_accumulate(BZH_ACC_PARAMS) {
+    msm_accumulate_body<C, T, U29>(BZH_ACC_ARGS);
+}
+#undef BZH_ACC_PARAMS
+#undef BZH_ACC_ARGS
 
 // ---------------------------------------------------------------------------
 // k_msm_reduce: one workgroup per segment computes sum_{m=1..M} m * B_m.
@@ -1241,7 +1363,11 @@ static int msm_run_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_sca
     // fewer, longer slices mean fewer buckets cut by slice boundaries to stitch, and the LDS-bound two workgroups per CU leave
     // more room for the other streams' kernels
     const int acc_threads = acc_threads_env == 128 || acc_threads_env == 256 || acc_threads_env == 512 ? acc_threads_env : 256;
-    const size_t part_bytes = (size_t)2 * acc_threads * 128;  // per segment: two stitch buffers
+    // per segment: two stitch buffers (+ the ninth limbs of raw buckets and raw head partials when the accumulator is unsaturated:
+    // msm_accumulate_body computes the same stride from its template arguments)
+    static const bool acc_sat_env = getenv("BZH_ACC_SATURATED") != nullptr;
+    const bool acc_u29 = fe29_supported<typename C::Base>() && !acc_sat_env && !use_gs;
+    const size_t part_bytes = (size_t)2 * acc_threads * 128 + (acc_u29 ? ((size_t)M_acc + acc_threads) * 16 : 0);
     int rc;
     if ((rc = ws_ensure(ctx, 0, slice * (size_t)p.nwin * n * sizeof(uint16_t), &d_digits))) return rc;
     if ((rc = ws_ensure(ctx, 1, use_gs ? slice * gs_vec_bytes + 4096 : slice * segs_per_vec * (seg_bytes + part_bytes), &d_buckets)))
@@ -1274,12 +1400,20 @@ static int msm_run_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_sca
     // per context (= per device; the ctx mutex is held): the dynamic-LDS limit is a per-device function attribute, so a
     // process that opens contexts on several GPUs has to raise it on each of them
     if (!ctx->msm_attr_set[C::id]) {
-        BZH_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msm_accumulate<C, 256>),
+        BZH_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msm_accumulate<C, 256, false>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        BZH_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msm_accumulate<C, 512>),
+        BZH_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msm_accumulate<C, 512, false>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        BZH_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msm_accumulate<C, 128>),
+        BZH_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msm_accumulate<C, 128, false>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        if constexpr (fe29_supported<typename C::Base>()) {
+            BZH_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msm_accumulate<C, 256, true>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            BZH_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msm_accumulate<C, 512, true>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            BZH_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msm_accumulate<C, 128, true>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        }
         BZH_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msm_reduce<C>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
         BZH_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gs_hist<512>),
@@ -1331,14 +1465,27 @@ static int msm_run_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_sca
             const bool xmap = xcd_map && acc_nwin == 1 && nb >= 8 && !bases->vec_col_stride;
             const dim3 grid = xmap ? dim3((unsigned)(((nb * p.nchunks + 7) / 8) * 8)) : dim3((unsigned)nb, (unsigned)acc_nwin, (unsigned)p.nchunks);
             const uint32_t xv = xmap ? (uint32_t)nb : 0u, xc = xmap ? (uint32_t)p.nchunks : 0u;
-#define BZH_LAUNCH_ACC(TT)                                                                                              \
-    hipLaunchKernelGGL((k_msm_accumulate<C, TT>), grid, dim3(TT), acc_lds, ctx->stream, bases->d_xy,                      \
+            // unsaturated-limb accumulation on the Pasta curves (BZH_ACC_SATURATED=1: the 8 x 32 variant, parity-tested against it)
+            const bool acc_sat = !acc_u29;
+            constexpr bool can29 = fe29_supported<typename C::Base>();
+#define BZH_LAUNCH_ACC_U(TT, UU)                                                                                         \
+    hipLaunchKernelGGL((k_msm_accumulate<C, TT, UU>), grid, dim3(TT), acc_lds, ctx->stream, bases->d_xy,                  \
                        (const uint16_t*)d_digits, n_eff, acc_nwin, M_acc, p.chunk, (uint4*)d_buckets, d_partials, row_len, \
                        row_stride, pair_in ? n - 2 : (size_t)0, ctx->profiling ? ctx->d_add_counter : nullptr,            \
                        bases->vec_col_stride, b0, xv, xc)
+#define BZH_LAUNCH_ACC(TT)                                  \
+    do {                                                    \
+        if constexpr (can29) {                              \
+            if (!acc_sat) BZH_LAUNCH_ACC_U(TT, true);       \
+            else BZH_LAUNCH_ACC_U(TT, false);               \
+        } else {                                            \
+            BZH_LAUNCH_ACC_U(TT, false);                    \
+        }                                                   \
+    } while (0)
             if (acc_threads == 128) BZH_LAUNCH_ACC(128);
             else if (acc_threads == 512) BZH_LAUNCH_ACC(512);
             else BZH_LAUNCH_ACC(256);
+#undef BZH_LAUNCH_ACC_U
 #undef BZH_LAUNCH_ACC
         }
         const size_t nseg = nb * segs_per_vec;

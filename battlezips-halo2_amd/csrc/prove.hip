@@ -52,6 +52,43 @@ extern "C" const bzh_builtin_quotient* bzh_builtin_quotients(size_t* count) __at
 }  // namespace
 }  // namespace bzh
 
+namespace {
+// degree (in units of n - 1: every column polynomial has degree < n) and tree multiplications of the quotient's terms
+template <class C>
+static int quotient_histogram_t(const uint8_t* circuit, size_t circuit_len, uint32_t* polys, uint32_t* muls) {
+    using SF = typename bzh::CurveScalar<C>::SF;
+    bzh_pk pk;
+    bzh::ParsedKey<SF> po;
+    const int rc = bzh::pk_parse_t<C>(circuit, circuit_len, pk, po);
+    if (rc) return rc;
+    bzh::Cols reg;
+    bzh::quotient_registry(pk, bzh::QuotientPtrs{}, reg);
+    bzh::EPool ep;
+    int tinv = -1;
+    const std::vector<int> terms = bzh::quotient_terms<SF>(pk, reg, ep, &tinv);
+    std::vector<int> deg(ep.n.size(), 0), mu(ep.n.size(), 0);
+    for (size_t i = 0; i < ep.n.size(); i++) {   // children precede parents in the pool
+        const bzh::ENode& e = ep.n[i];
+        switch (e.tag) {
+            case bzh::EX_QUERY: deg[i] = 1; break;
+            case bzh::EX_NEG: deg[i] = deg[e.a], mu[i] = mu[e.a]; break;
+            case bzh::EX_SCALE: deg[i] = deg[e.a], mu[i] = mu[e.a] + 1; break;
+            case bzh::EX_ADD: deg[i] = std::max(deg[e.a], deg[e.b]), mu[i] = mu[e.a] + mu[e.b]; break;
+            case bzh::EX_MUL: deg[i] = deg[e.a] + deg[e.b], mu[i] = mu[e.a] + mu[e.b] + 1; break;
+            default: break;
+        }
+    }
+    for (int d = 0; d < 16; d++) polys[d] = muls[d] = 0;
+    for (int t : terms) {
+        const int d = std::min(deg[t], 15);
+        polys[d]++;
+        muls[d] += (uint32_t)mu[t];
+    }
+    return BZH_OK;
+}
+}  // namespace
+
+
 extern "C" {
 
 int bzh_pk_create(bzh_ctx* ctx, const bzh_bases* srs, const uint8_t* circuit, size_t circuit_len, bzh_pk** out) {
@@ -156,6 +193,13 @@ int bzh_quotient_source_for_circuit(int curve, const uint8_t* circuit, size_t ci
     if (!pk.q_ok) return BZH_E_RANGE;
     if (program_hash) *program_hash = pk.q_hash;
     return copy_text(bzh::program2_source(pk.qprog, pk.field, true), buf, cap, len);
+}
+
+int bzh_quotient_degree_histogram(int curve, const uint8_t* circuit, size_t circuit_len, uint32_t* polys, uint32_t* muls) {
+    if (!circuit || !polys || !muls) return BZH_E_ARG;
+    if (curve == BZH_CURVE_VESTA) return quotient_histogram_t<bzh::VestaCurve>(circuit, circuit_len, polys, muls);
+    if (curve == BZH_CURVE_PALLAS) return quotient_histogram_t<bzh::PallasCurve>(circuit, circuit_len, polys, muls);
+    return BZH_E_ARG;
 }
 
 int bzh_pk_quotient_select(bzh_pk* pk, int flavour) {

@@ -88,6 +88,34 @@ KERNEL(k_fma_f32, DECLF32, B_FMA32, SINKF)
 typedef void (*kfn)(uint32_t*, uint32_t);
 struct Case { const char* name; kfn fn; int ops_per_iter; };
 
+// round 4: the 64-bit shift / add forms the compiler picks for the unsaturated product's column hand-over, and their 32-bit stand-ins
+#define OP8_64S(OPSTR)                                                                                                   \
+    asm volatile(OPSTR " %0, 29, %0\n " OPSTR " %1, 29, %1\n " OPSTR " %2, 29, %2\n " OPSTR " %3, 29, %3\n " OPSTR      \
+                       " %4, 29, %4\n " OPSTR " %5, 29, %5\n " OPSTR " %6, 29, %6\n " OPSTR " %7, 29, %7\n"              \
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7))
+#define B_LSHR64 OP8_64S("v_lshrrev_b64")
+#define B_LSHL64 OP8_64S("v_lshlrev_b64")
+KERNEL(k_lshrrev_b64, DECL64, B_LSHR64, SINK64)
+KERNEL(k_lshlrev_b64, DECL64, B_LSHL64, SINK64)
+#define B_LSHLADD64 asm volatile("v_lshl_add_u64 %0, %0, 0, %8\n v_lshl_add_u64 %1, %1, 0, %8\n v_lshl_add_u64 %2, %2, 0, %8\n v_lshl_add_u64 %3, %3, 0, %8\n" \
+                    "v_lshl_add_u64 %4, %4, 0, %8\n v_lshl_add_u64 %5, %5, 0, %8\n v_lshl_add_u64 %6, %6, 0, %8\n v_lshl_add_u64 %7, %7, 0, %8\n" \
+                    : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(a7 ^ seed))
+KERNEL(k_lshl_add_u64, DECL64, B_LSHLADD64, SINK64)
+#define B_ALIGNBIT asm volatile("v_alignbit_b32 %0, %8, %0, 29\n v_alignbit_b32 %1, %8, %1, 29\n v_alignbit_b32 %2, %8, %2, 29\n v_alignbit_b32 %3, %8, %3, 29\n" \
+                    "v_alignbit_b32 %4, %8, %4, 29\n v_alignbit_b32 %5, %8, %5, 29\n v_alignbit_b32 %6, %8, %6, 29\n v_alignbit_b32 %7, %8, %7, 29\n" \
+                    : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(x))
+KERNEL(k_alignbit, DECL32, B_ALIGNBIT, SINK32)
+#define B_AND OP8("v_and_b32")
+#define B_LSHR32 OP8("v_lshrrev_b32")
+#define B_SUB OP8("v_sub_u32")
+KERNEL(k_and_b32, DECL32, B_AND, SINK32)
+KERNEL(k_lshrrev_b32, DECL32, B_LSHR32, SINK32)
+KERNEL(k_sub_u32, DECL32, B_SUB, SINK32)
+#define B_ANDOR OP8_3("v_and_or_b32")
+#define B_BFE OP8_3("v_bfe_u32")
+KERNEL(k_and_or, DECL32Y, B_ANDOR, SINK32)
+KERNEL(k_bfe, DECL32Y, B_BFE, SINK32)
+
 int main() {
     hipDeviceProp_t prop;
     CHK(hipGetDeviceProperties(&prop, 0));
@@ -103,6 +131,9 @@ int main() {
         {"v_pk_mad_u16", k_mad_u16_pk, 8}, {"v_add_u32", k_add_u32, 8}, {"v_xor_b32", k_xor_b32, 8},
         {"v_add3_u32", k_add3_u32, 8}, {"v_lshl_add_u32", k_lshl_add, 8}, {"add_co+addc pair(2 ops)", k_addc_pair, 8},
         {"v_fma_f64", k_fma_f64, 8}, {"v_fma_f32", k_fma_f32, 8},
+        {"v_lshrrev_b64", k_lshrrev_b64, 8}, {"v_lshlrev_b64", k_lshlrev_b64, 8}, {"v_lshl_add_u64", k_lshl_add_u64, 8},
+        {"v_alignbit_b32", k_alignbit, 8}, {"v_and_b32", k_and_b32, 8}, {"v_lshrrev_b32", k_lshrrev_b32, 8}, {"v_sub_u32", k_sub_u32, 8},
+        {"v_and_or_b32", k_and_or, 8}, {"v_bfe_u32", k_bfe, 8},
     };
     hipEvent_t e0, e1;
     CHK(hipEventCreate(&e0));

@@ -346,6 +346,13 @@ int bzh_pk_quotient_selected(bzh_pk* pk, int* flavour, int* builtin_available);
  * build-time generator calls; BZH_E_RANGE if the circuit does not fit the evaluator (such circuits use the VM v1 fold). */
 int bzh_quotient_source_for_circuit(int curve, const uint8_t* circuit, size_t circuit_len, char* buf, size_t cap, size_t* len,
                                     uint64_t* program_hash);
+/* Host only: the terms of a circuit's quotient numerator (gate constraints with their compressed selectors, permutation and
+ * lookup argument terms, in protocol order) by polynomial degree -- polys[d] terms of degree d (in units of n - 1, d < 16) and
+ * muls[d] field multiplications in their expression trees.  A term of degree d vanishes on the 2^k-row domain by itself, so its
+ * share of h(X) could be computed from (d - 1) n evaluations instead of the extended domain's; the histogram says what that
+ * would buy (halo2's selector compression pads nearly every gate of the reference's circuits to degree
+ * 7 - 9, so for them it buys ~3 %). */
+int bzh_quotient_degree_histogram(int curve, const uint8_t* circuit, size_t circuit_len, uint32_t* polys16, uint32_t* muls16);
 /* launcher of one builtin kernel, and the table the generated file exports (used inside the library) */
 typedef void (*bzh_quotient_launch_fn)(unsigned grid_x, unsigned grid_y, void* hip_stream, const uint32_t* const* cols, const size_t* strides,
                                        const uint32_t* consts, size_t const_stride, size_t size, uint32_t* out);
@@ -421,7 +428,9 @@ int bzh_params_points(const bzh_params* p, uint64_t* g_xy, uint64_t* g_lagrange_
  *                        Pallas scalars.  `threads` host threads (0 = auto).  BZH_E_RANGE: an input the reference would
  *                        panic on (H and V share a bit: src/utils/binary.rs:97-108; non-canonical trapdoor).
  *   bzh_board_witness    Board::from(&Deck::from(ships)).{witness, state}(options): ships = 5 x (x, y, z), x < 0 = None;
- *                        options = 5 WitnessOption values (src/utils/ship.rs:315-331) or NULL;
+ *                        options = 5 WitnessOption values (src/utils/ship.rs:315-331) or NULL.  Anything but NULL / all
+ *                        BZH_WITNESS_DEFAULT is the reference's TEST-ONLY fault injection (malicious ship commitments for its
+ *                        negative MockProver tests): a negative-test aid, never a production input;
  *                        out: 10 ship commitments [H5, V5, H4, V4, H3a, V3a, H3b, V3b, H2, V2] and the board state.
  *   bzh_shot_serialize   shot::serialize (src/utils/shot.rs:12-19).
  *   bzh_pedersen_commit_host   pedersen_commit (src/utils/pedersen.rs:17-28) on the host, from the circuit's window tables.

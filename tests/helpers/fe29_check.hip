@@ -47,13 +47,30 @@ static bool check(const char* name) {
     for (int i = 0; i < 8; i++) pm1.l[i] = P::mod(i);
     pm1.l[0] -= 1;
     vals.push_back(pm1);
+    {   // values whose x 32 has every possible top part: k * p / 64 + small
+        for (int kk = 1; kk < 64; kk += 3) {
+            Fe<P> v = fe_zero<P>();
+            v.l[7] = (uint32_t)(((uint64_t)kk << 24) / 1u) & 0x3fffffffu;   // ~ kk * 2^248
+            v.l[0] = (uint32_t)kk * 2654435761u;
+            vals.push_back(v);
+        }
+    }
     for (int i = 0; i < 200; i++) vals.push_back(rnd<P>(rng));
     // round trip and products: from_sat_x32(A) stands for A's value in R' form
     for (size_t i = 0; i < vals.size(); i++) {
         const Fe<P> A = vals[i], B = vals[(i * 7 + 3) % vals.size()];
         const Fe29<P> a = fe29_from_sat_x32(A), b = fe29_mul(fe29_from_sat_x32(B), k.one);
         expect(fe_eq(sat_of(fe29_mul(a, k.one), k), A), "round trip");
+        {   // the cheap reduction of a table coordinate: same value, below 2 p (top limb), carried limbs
+            const Fe29<P> ared = fe29_from_sat_reduced(A);
+            expect(fe_eq(sat_of(ared, k), A), "from_sat_reduced value");
+            expect(ared.l[8] <= (2u << 22), "from_sat_reduced < 2 p");
+            for (int j = 0; j < 8; j++) expect(ared.l[j] < (1u << 29) + 8u, "from_sat_reduced limb bound");
+        }
         expect(fe_eq(sat_of(fe29_mul(a, b), k), fe_mul(A, B)), "mul (32 p x 2 p)");
+        expect(fe_eq(fe29_to_sat_div32(fe29_mul(a, b)), fe_mul(A, B)), "to_sat_div32 of a product");
+        expect(fe_eq(fe29_to_sat_div32(fe29_from_sat_x32(A)), A), "to_sat_div32 of a 32 p value");
+        expect(fe_eq(fe29_to_sat_div32(fe29_sub<P, 16>(fe29_mul(a, k.one), b)), fe_sub(A, B)), "to_sat_div32 of an 18 p value");
         const Fe29<P> ar = fe29_mul(a, k.one);
         expect(fe_eq(sat_of(fe29_sqr(ar), k), fe_sqr(A)), "sqr");
         expect(fe_eq(sat_of(fe29_mul(fe29_add(ar, b), fe29_add(b, b)), k), fe_mul(fe_add(A, B), fe_dbl(B))), "mul of lazy sums");
@@ -99,6 +116,8 @@ static bool check(const char* name) {
             if (i < 4 || i % 50 == 49) {
                 const Affine<P> a = xyzz_to_affine(ref), b = xyzz_to_affine(xyzz29_to_sat(acc, k));
                 expect(fe_eq(a.x, b.x) && fe_eq(a.y, b.y), "mixed-addition chain");
+                const Xyzz<P> s1 = xyzz29_to_sat(acc, k), s2 = xyzz29_to_sat_fast(acc);
+                expect(fe_eq(s1.x, s2.x) && fe_eq(s1.y, s2.y) && fe_eq(s1.zz, s2.zz) && fe_eq(s1.zzz, s2.zzz), "to_sat_fast == to_sat");
             }
         }
         // invariants of the representation
