@@ -76,24 +76,40 @@ BZH_HD Fe29<P> fe29_zero() {
 // (the textbook product scanning) makes ALL 126 multiply-adds one chain: fine while two waves per SIMD alternate, but whenever the
 // other wave waits for its table gather the lone wave issues a dependent v_mad_u64_u32 only every other slot -- measured in
 // k_msm_accumulate as 0.8 instructions per slot against 1.0 for the saturated code, which ate the whole gain.
+// p's limb 8 (2^22 for the Pasta fields) as a value the compiler cannot see through: m * 2^22 then stays ONE v_mad_u64_u32
+// instead of becoming a 64-bit shift + a 64-bit add
+template <class P>
+BZH_HD uint32_t fe29_p8_opaque() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t v;
+    asm("s_mov_b32 %0, %1" : "=s"(v) : "i"(fe29_p<P>(8)));
+    return v;
+#else
+    return fe29_p<P>(8);
+#endif
+}
+// The columns below 9 arrive with 2^29 - 1 already added (fe29_mul / fe29_sqr start them there): with t = column + carry,
+// the quotient digit is ~t mod 2^29 and the carry into the next column -- (t + digit) >> 29 -- is just t >> 29.
 template <class P>
 BZH_HD void fe29_montgomery_pass(uint64_t (&c)[17], Fe29<P>& r) {
+    const uint32_t p8 = fe29_p8_opaque<P>();
     uint64_t carry = 0;
 #pragma unroll
     for (int k = 0; k < 9; k++) {
-        c[k] += carry;
-        const uint32_t m = (0u - (uint32_t)c[k]) & kM29;   // p = 1 mod 2^29: the digit that clears the column's low limb
-        carry = (c[k] + kM29) >> 29;                        // = (c_k + m) >> 29 without waiting for m
+        const uint64_t t = c[k] + carry;
+        const uint32_t m = ~(uint32_t)t & kM29;   // p = 1 mod 2^29: the digit that clears the column's low limb
+        carry = t >> 29;
 #pragma unroll
-        for (int l = 1; l < 9; l++) {
+        for (int l = 1; l < 8; l++) {
             if (fe29_p<P>(l) != 0u) c[k + l] += (uint64_t)m * fe29_p<P>(l);
         }
+        c[k + 8] += (uint64_t)m * p8;
     }
 #pragma unroll
     for (int k = 9; k < 17; k++) {
-        c[k] += carry;
-        r.l[k - 9] = (uint32_t)c[k] & kM29;
-        carry = c[k] >> 29;
+        const uint64_t t = c[k] + carry;
+        r.l[k - 9] = (uint32_t)t & kM29;
+        carry = t >> 29;
     }
     r.l[8] = (uint32_t)carry;
 }
@@ -103,7 +119,7 @@ BZH_HD Fe29<P> fe29_mul(const Fe29<P>& a, const Fe29<P>& b) {
     uint64_t c[17];
 #pragma unroll
     for (int k = 0; k < 17; k++) {
-        c[k] = 0;
+        c[k] = k < 9 ? (uint64_t)kM29 : 0;
 #pragma unroll
         for (int j = (k > 8 ? k - 8 : 0); j <= (k < 8 ? k : 8); j++) c[k] += (uint64_t)a.l[j] * b.l[k - j];
     }
@@ -121,7 +137,7 @@ BZH_HD Fe29<P> fe29_sqr(const Fe29<P>& a) {
     for (int i = 0; i < 9; i++) d[i] = a.l[i] << 1;
 #pragma unroll
     for (int k = 0; k < 17; k++) {
-        c[k] = 0;
+        c[k] = k < 9 ? (uint64_t)kM29 : 0;
 #pragma unroll
         for (int j = (k > 8 ? k - 8 : 0); 2 * j < k; j++) c[k] += (uint64_t)d[j] * a.l[k - j];
         if ((k & 1) == 0) c[k] += (uint64_t)a.l[k >> 1] * a.l[k >> 1];
