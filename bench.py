@@ -724,7 +724,7 @@ def ubench_peaks():
         if not m:
             continue
         v = float(m.group(1))
-        if line.startswith("xyzz_madd"):
+        if line.startswith(("xyzz_madd", "xyzz29_madd")):   # saturated and unsaturated-limb mixed addition: the better one is the yardstick
             best["xyzz_madd"] = max(best["xyzz_madd"] or 0, v)
         elif line.startswith("fe_mul<Fp>"):
             best["fe_mul"] = max(best["fe_mul"] or 0, v)
@@ -1149,7 +1149,7 @@ def main():
         # separate runs of this same command), if one exists for this workload and kernel
         traffic, traffic_src = None, None
         want_kernel = qname if dom_name.startswith(qname) else "k_msm_accumulate"
-        for tag in ("r03", "r02", "r01_h", "r01_e"):
+        for tag in ("r04", "r03", "r02", "r01_h", "r01_e"):
             tj = os.path.join(ROOT, "profiles", "%s_%s_pmc_traffic.json" % (tag, args.workload))
             if traffic is not None or not os.path.exists(tj) or args.workload == "ntt22":
                 continue
@@ -1165,7 +1165,7 @@ def main():
                 if launches:
                     traffic = tot / launches
                     traffic_src = os.path.relpath(tj, ROOT) + (" (real circuit, one default-size batch in flight; mean over %d launches)" % launches
-                                                               if tag in ("r03", "r02") else " (round-1 synthetic circuit: stale for the real one)")
+                                                               if tag in ("r04", "r03", "r02") else " (round-1 synthetic circuit: stale for the real one)")
             except Exception:
                 traffic = None
         line = {

@@ -9,10 +9,11 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/final
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-python3 $R/bench.py > $O/proof_k14_default_bench.json 2> $O/proof_k14_default_bench.err && echo default done
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_default -o d -- python3 $R/bench.py --no-cpu-baseline > $O/proof_k14_default_bench_under_rocprof.json 2> $O/prof_default.err && echo prof default done
-python3 $R/bench.py --no-cpu-baseline --concurrency 1 --steps 5 --warmup 2 > $O/proof_k14_b64c1_bench.json 2> /dev/null && echo b64c1 done
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_b64c1 -o d -- python3 $R/bench.py --no-cpu-baseline --concurrency 1 --steps 5 --warmup 2 > $O/proof_k14_b64c1_bench_under_rocprof.json 2> $O/prof_b64c1.err && echo prof b64c1 done
+python3 $R/bench.py --steps 20 --warmup 5 > $O/proof_k14_default_bench.json 2> $O/proof_k14_default_bench.err && echo default done   # the driver's command: the whole metric in one line
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_default -o d -- python3 $R/bench.py --no-cpu-baseline --other-workloads none > $O/proof_k14_default_bench_under_rocprof.json 2> $O/prof_default.err && echo prof default done
+python3 $R/bench.py --no-cpu-baseline --other-workloads none --concurrency 1 --steps 5 --warmup 2 > $O/proof_k14_b64c1_bench.json 2> /dev/null && echo b64c1 done
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_b64c1 -o d -- python3 $R/bench.py --no-cpu-baseline --other-workloads none --concurrency 1 --steps 5 --warmup 2 > $O/proof_k14_b64c1_bench_under_rocprof.json 2> $O/prof_b64c1.err && echo prof b64c1 done
+BZH_ACC_SATURATED=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_b64c1_sat -o d -- python3 $R/bench.py --no-cpu-baseline --other-workloads none --concurrency 1 --steps 5 --warmup 2 > $O/proof_k14_b64c1_saturated_acc_bench_under_rocprof.json 2> $O/prof_b64c1_sat.err && echo prof b64c1 saturated done
 python3 $R/bench.py --no-cpu-baseline --batch 1 --concurrency 1 --no-kernel-timers --steps 10 --warmup 3 > $O/proof_k14_b1c1_bench.json 2> /dev/null && echo b1 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_b1c1 -o d -- python3 $R/bench.py --no-cpu-baseline --batch 1 --concurrency 1 --steps 10 --warmup 3 > $O/proof_k14_b1c1_bench_under_rocprof.json 2> $O/prof_b1c1.err && echo prof b1c1 done
 python3 $R/bench.py --no-cpu-baseline --workload proof_k11 --batch 1 --concurrency 1 --no-kernel-timers --steps 10 --warmup 3 > $O/proof_k11_b1c1_bench.json 2> /dev/null && echo k11 b1 done
@@ -28,8 +29,10 @@ done
 python3 $R/bench.py --no-cpu-baseline --workload mixed_board_shot --mix-divisor 4 --steps 3 --warmup 1 > $O/mixed_div4_bench.json 2> /dev/null && echo mixed done
 python3 $R/bench.py --no-cpu-baseline --workload mixed_board_shot --steps 2 --warmup 1 > $O/mixed_full_bench.json 2> /dev/null && echo mixed full done
 python3 $R/bench.py --no-cpu-baseline --workload proof_k17 --batch 1 --concurrency 1 --no-kernel-timers --steps 5 --warmup 2 > $O/proof_k17_b1c1_bench.json 2> /dev/null && echo k17 b1 done
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python3 $R/bench.py --no-cpu-baseline --concurrency 1 --steps 3 --warmup 1 > $O/pmc_fetch.log 2>&1 && echo pmc fetch done
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python3 $R/bench.py --no-cpu-baseline --concurrency 1 --steps 3 --warmup 1 > $O/pmc_write.log 2>&1 && echo pmc write done
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python3 $R/bench.py --no-cpu-baseline --other-workloads none --concurrency 1 --steps 3 --warmup 1 > $O/pmc_fetch.log 2>&1 && echo pmc fetch done
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python3 $R/bench.py --no-cpu-baseline --other-workloads none --concurrency 1 --steps 3 --warmup 1 > $O/pmc_write.log 2>&1 && echo pmc write done
 python3 $R/tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write > $O/proof_k14_pmc_traffic.json && rm -rf $O/pmc_fetch $O/pmc_write && echo pmc merged
+$R/battlezips-halo2_amd/tools/ubench_field > $O/ubench_field_gfx950.txt 2>&1 && echo ubench field done
+$R/battlezips-halo2_amd/tools/ubench_valu > $O/ubench_valu_gfx950.txt 2>&1 && echo ubench valu done
 (cd $R && bash examples/run_example.sh 64 3 > $O/example_cpp_client.txt 2>&1; tail -2 $O/example_cpp_client.txt)
 ls $O
