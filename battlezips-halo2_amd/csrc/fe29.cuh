@@ -217,6 +217,33 @@ BZH_HD Fe29<P> fe29_from_sat_reduced(const Fe<P>& v) {
     for (int i = 0; i < 9; i++) r.l[i] = t.l[i] + (fe29_bias<P, 1>(i) - (i < 6 ? e[i] : 0u));
     return fe29_carry(r);
 }
+// carried value < 128 p -> the same residue below 2 p (carried): the bits above 2^254 fold back as -top c, plus one p so that
+// nothing goes negative.  ~45 instructions; what keeps long chains of lazy additions / biased subtractions inside the product's
+// input range.
+template <class P>
+BZH_HD Fe29<P> fe29_fold(const Fe29<P>& a) {
+    // limbs 0..7 < 2^29 + 8, limb 8 < 2^29: top = bits from 2^254 up
+    const uint32_t top = a.l[8] >> 22;            // < 128
+    uint32_t e[6];
+    uint64_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        acc += (uint64_t)top * fe29_p<P>(i);
+        e[i] = (uint32_t)acc & kM29;
+        acc >>= 29;
+    }
+    e[5] = (uint32_t)acc;
+    Fe29<P> r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.l[i] = a.l[i] + (fe29_bias<P, 1>(i) - (i < 6 ? e[i] : 0u));
+    r.l[8] = (a.l[8] & ((1u << 22) - 1u)) + fe29_bias<P, 1>(8);
+    return fe29_carry(r);
+}
+// a + b, carried (the quotient evaluator's addition: every value it holds keeps limbs below 2^29 + 8)
+template <class P>
+BZH_HD Fe29<P> fe29_add_c(const Fe29<P>& a, const Fe29<P>& b) {
+    return fe29_carry(fe29_add(a, b));
+}
 // constants in fe29 form from a value given as 8 saturated words (raw integer, not shifted)
 template <class P>
 BZH_HD Fe29<P> fe29_from_raw(const uint32_t w8[8]) {
@@ -389,5 +416,52 @@ template <class P>
 BZH_HD Fe<P> fe29_to_sat(const Fe29<P>& a, const Fe29<P>& two256) {
     return fe29_pack_canonical(fe29_mul(a, two256));
 }
+
+// ---- fe29 values at rest: three planes per column of `size` elements -- limbs 0..3 (uint4), limbs 4..7 (uint4), limb 8 (u32);
+//      9 size words per column.  Every plane is read coalesced by consecutive rows.  (The quotient evaluator's columns.)
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
+template <class P>
+__device__ __forceinline__ Fe29<P> fe29_load_planes(const uint32_t* __restrict__ col, size_t idx, size_t size) {
+    const uint4 a = reinterpret_cast<const uint4*>(col)[idx];
+    const uint4 b = reinterpret_cast<const uint4*>(col + 4 * size)[idx];
+    Fe29<P> r;
+    r.l[0] = a.x, r.l[1] = a.y, r.l[2] = a.z, r.l[3] = a.w;
+    r.l[4] = b.x, r.l[5] = b.y, r.l[6] = b.z, r.l[7] = b.w;
+    r.l[8] = col[8 * size + idx];
+    return r;
+}
+template <class P>
+__device__ __forceinline__ void fe29_store_planes(uint32_t* __restrict__ col, size_t idx, size_t size, const Fe29<P>& v) {
+    reinterpret_cast<uint4*>(col)[idx] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+    reinterpret_cast<uint4*>(col + 4 * size)[idx] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+    col[8 * size + idx] = v.l[8];
+}
+// An Fe29 across a CALL: a 36-byte struct goes through scratch memory (byval / sret), a 9-lane vector travels in VGPRs.
+typedef uint32_t fe29_vec __attribute__((ext_vector_type(9)));
+template <class P>
+__device__ __forceinline__ fe29_vec fe29_pack_vec(const Fe29<P>& a) {
+    fe29_vec v;
+#pragma unroll
+    for (int i = 0; i < 9; i++) v[i] = a.l[i];
+    return v;
+}
+template <class P>
+__device__ __forceinline__ Fe29<P> fe29_unpack_vec(fe29_vec v) {
+    Fe29<P> a;
+#pragma unroll
+    for (int i = 0; i < 9; i++) a.l[i] = v[i];
+    return a;
+}
+// a per-proof constant: 12 words apart (9 used), 16-byte aligned
+template <class P>
+__device__ __forceinline__ Fe29<P> fe29_load_const(const uint32_t* __restrict__ p) {
+    const uint4 a = reinterpret_cast<const uint4*>(p)[0], b = reinterpret_cast<const uint4*>(p)[1];
+    Fe29<P> r;
+    r.l[0] = a.x, r.l[1] = a.y, r.l[2] = a.z, r.l[3] = a.w;
+    r.l[4] = b.x, r.l[5] = b.y, r.l[6] = b.z, r.l[7] = b.w;
+    r.l[8] = p[8];
+    return r;
+}
+#endif
 
 }  // namespace bzh

@@ -56,9 +56,9 @@ int main() {
         }
     }
     printf("// GENERATED at build time by csrc/gen_quotient.cpp -- do not edit, do not commit.\n"
-           "#include <hip/hip_runtime.h>\n#include \"field.cuh\"\n#include \"../../include/bzh2.h\"\n\n%s", body.c_str());
+           "#include <hip/hip_runtime.h>\n#include \"field.cuh\"\n#include \"fe29.cuh\"\n#include \"../../include/bzh2.h\"\n\n%s", body.c_str());
     printf("static const bzh_builtin_quotient kTable[] = {\n");
-    for (auto& t : table) printf("    {0x%016llxull, bzh_q_%016llx::launch, \"%s\"},\n", t.first, t.first, t.second.c_str());
+    for (auto& t : table) printf("    {0x%016llxull, bzh_q_%016llx::launch, \"%s\", bzh_q29_%016llx::launch},\n", t.first, t.first, t.second.c_str(), t.first);
     printf("};\nextern \"C\" const bzh_builtin_quotient* bzh_builtin_quotients(size_t* count) {\n"
            "    if (count) *count = sizeof(kTable) / sizeof(kTable[0]);\n    return kTable;\n}\n");
     return 0;

@@ -39,6 +39,7 @@
 #include "chacha.hpp"
 #include "ctx.hpp"
 #include "curve.cuh"
+#include "fe29.cuh"
 
 // the table of quotient kernels generated at build time (quotient_builtin.hip); absent (null) in the generator's own link
 extern "C" const bzh_builtin_quotient* bzh_builtin_quotients(size_t* count) __attribute__((weak));
@@ -131,6 +132,7 @@ int bzh_pk_free(bzh_ctx* ctx, bzh_pk* pk) {
     (void)hipDeviceSynchronize();   // every ctx's stream: the arenas below belong to all of them
     if (pk->dev) (void)hipFree(pk->dev);
     if (pk->hoist) (void)hipFree(pk->hoist);
+    if (pk->key29) (void)hipFree(pk->key29);
     if (pk->q_module) (void)hipModuleUnload(pk->q_module);
     for (auto& kv : pk->arenas) kv.second->release();
     delete pk;
@@ -192,7 +194,8 @@ int bzh_quotient_source_for_circuit(int curve, const uint8_t* circuit, size_t ci
     if (rc) return rc;
     if (!pk.q_ok) return BZH_E_RANGE;
     if (program_hash) *program_hash = pk.q_hash;
-    return copy_text(bzh::program2_source(pk.qprog, pk.field, true), buf, cap, len);
+    // two flavours of the same program: saturated limbs (namespace bzh_q_<hash>) and unsaturated 9 x 29-bit limbs (bzh_q29_<hash>)
+    return copy_text(bzh::program2_source(pk.qprog, pk.field, true) + "\n" + bzh::program2_source29(pk.qprog, pk.field), buf, cap, len);
 }
 
 int bzh_quotient_degree_histogram(int curve, const uint8_t* circuit, size_t circuit_len, uint32_t* polys, uint32_t* muls) {

@@ -34,6 +34,15 @@ __global__ void __launch_bounds__(256) k_commit_shift(const uint32_t* __restrict
     fe_store(sc + (v * (n + 3) + i) * 8, o);
 }
 
+// `ncols` saturated columns of `size` elements (2^256-Montgomery) -> the quotient evaluator's unsaturated planes (fe29.cuh:
+// value x 2^261, below 2 p, limbs carried; 9 size words per column)
+template <class P>
+__global__ void __launch_bounds__(256) k_sat_to_fe29_planes(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, size_t size) {
+    const size_t i = blockIdx.x * (size_t)256 + threadIdx.x, c = blockIdx.y;
+    if (i >= size) return;
+    fe29_store_planes<P>(dst + c * 9 * size, i, size, fe29_from_sat_reduced(fe_load<P>(src + (c * size + i) * 8)));
+}
+
 // flag |= any word of rows[b][0 .. words) non-zero
 __global__ void __launch_bounds__(256) k_any_nonzero(const uint32_t* __restrict__ p, size_t words, size_t row_stride_words,
                                                        uint32_t* __restrict__ flag) {

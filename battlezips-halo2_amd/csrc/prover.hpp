@@ -264,7 +264,90 @@ struct Prover {
 
     // the quotient through VM v2 (the program compiled at bzh_pk_create), as the builtin kernel, the caller's module or the
     // interpreter.  Returns BZH_E_RANGE when the circuit does not fit VM v2 (the caller falls back to the plain fold through `run`).
-    int run_quotient(const Cols& reg, size_t size, uint32_t* d_out) {
+    // The builtin kernel in unsaturated limbs: the per-proof columns (advice, instance, grand products, permuted lookup columns on
+    // the extended coset) are re-written as fe29 planes first (k_sat_to_fe29_planes: value x 2^5 reduced below 2 p, 36 bytes per
+    // element), the key's columns were converted at bzh_pk_create, the constants are converted on the host.
+    int run_quotient29(const Cols& reg, const QuotientPtrs& qp, size_t size, uint32_t* d_out) {
+        const Program2& pg = pk.qprog;
+        const size_t nc = pg.consts.size(), m = pk.perm_columns.size();
+        const int na = pk.na, ni = pk.ni, nz = pk.nsets + pk.nl;
+        struct Family {
+            const uint32_t* sat;
+            size_t ncols;
+            uint32_t* f29;
+        };
+        std::vector<Family> fam;
+        {   // key-owned families, in the order bzh_pk_create converted them
+            uint32_t* d = pk.key29;
+            auto keyfam = [&](const uint32_t* sat, size_t ncols) {
+                fam.push_back(Family{sat, ncols, d});
+                d += ncols * 9 * size;
+            };
+            keyfam(pk.fixed_cosets, (size_t)pk.nf);
+            keyfam(pk.sigma_cosets, m);
+            keyfam(pk.l0, 5);
+            keyfam(pk.hoist, pk.hoist_cols);
+        }
+        ScopedTimer t(ctx, BZH_T_QUOTIENT);
+        auto convert = [&](const uint32_t* sat, size_t ncols) -> int {
+            if (!sat || !ncols) return BZH_OK;
+            uint32_t* d = (uint32_t*)arena.alloc(ncols * 9 * size * 4);
+            if (!d) return BZH_E_OOM;
+            hipLaunchKernelGGL((k_sat_to_fe29_planes<SF>), dim3((unsigned)((size + 255) / 256), (unsigned)ncols), dim3(256), 0, st, sat, d, size);
+            fam.push_back(Family{sat, ncols, d});
+            return BZH_OK;
+        };
+        PV_TRY(convert(qp.adv, B * (size_t)na));
+        PV_TRY(convert(qp.inst, B * (size_t)ni));
+        PV_TRY(convert(qp.z, B * (size_t)nz));
+        for (const uint32_t* c : qp.lk) PV_TRY(convert(c, B * 2));
+        BZH_HIP_TRY(ctx, hipGetLastError());
+        // registry (+ hoisted columns) -> plane pointers: a column is found in its family by its saturated address
+        std::vector<const uint32_t*> ptrs;
+        std::vector<size_t> strides;
+        auto map_col = [&](const uint32_t* sat, size_t stride_elems) -> bool {
+            for (const Family& f : fam) {
+                if (sat >= f.sat && sat < f.sat + f.ncols * size * 8) {
+                    const size_t col = (size_t)(sat - f.sat) / (size * 8);
+                    ptrs.push_back(f.f29 + col * 9 * size);
+                    strides.push_back(stride_elems * 9);      // (elements between proofs) x 9 words
+                    return true;
+                }
+            }
+            return false;
+        };
+        for (size_t i = 0; i < reg.ptr.size(); i++)
+            if (!map_col(reg.ptr[i], reg.stride[i])) return BZH_E_ARG;
+        for (size_t hi = 0; hi < pk.hoist_cols; hi++)
+            if (!map_col(pk.hoist + hi * size * 8, 0)) return BZH_E_ARG;
+        std::vector<uint32_t> cv(std::max<size_t>(B * nc, 1) * 12, 0u);
+        for (size_t b = 0; b < B; b++)
+            for (size_t i = 0; i < nc; i++) {
+                const ConstEnt& c = pg.consts[i];
+                Fe<SF> v;
+                if (c.sym >= 0) {
+                    auto f = env[b].find(c.sym);
+                    if (f == env[b].end()) return BZH_E_ARG;
+                    v = f->second;
+                } else {
+                    memcpy(v.l, c.val, 32);
+                }
+                const Fe29<SF> w = fe29_from_sat_reduced(v);
+                memcpy(&cv[(b * nc + i) * 12], w.l, 36);
+            }
+        ProgramArgs pa;
+        PV_TRY(upload_program(cv.data(), cv.size() * 4, pg.ops.data(), 0, ptrs.data(), strides.data(), ptrs.size(), pa));
+        if (ctx->profiling) {
+            double cols_read = 0;
+            for (size_t i = 0; i < reg.stride.size(); i++) cols_read += reg.stride[i] ? (double)B : 1.0;
+            ctx->alg_bytes[BZH_T_QUOTIENT] += (cols_read + (double)B) * (double)size * 32.0;
+        }
+        pk.q_builtin29((unsigned)(size / 128), (unsigned)B, (void*)st, (const uint32_t* const*)pa.ptrs, (const size_t*)pa.strides, pa.consts, nc, size, d_out);
+        BZH_HIP_TRY(ctx, hipGetLastError());
+        return BZH_OK;
+    }
+
+    int run_quotient(const Cols& reg, size_t size, uint32_t* d_out, const QuotientPtrs* qp = nullptr) {
         if (!pk.q_ok || size % 128 || size != pk.en) return BZH_E_RANGE;
         hipFunction_t q_fn = nullptr;
         bzh_quotient_launch_fn q_builtin = nullptr;
@@ -276,6 +359,9 @@ struct Prover {
         const Program2* pgp = &pk.qprog;
         const Program2& pg = *pgp;
         if (!pg.ok) return BZH_E_RANGE;
+        if constexpr (fe29_supported<SF>()) {
+            if (q_builtin && qp && pk.q_builtin29 && pk.key29) return run_quotient29(reg, *qp, size, d_out);
+        }
         const size_t nc = pg.consts.size(), ncols = reg.ptr.size() + pk.hoist_cols;
         std::vector<const uint32_t*> ptrs(reg.ptr);
         std::vector<size_t> strides(reg.stride);
@@ -636,7 +722,7 @@ int Prover<C>::prove(const uint32_t* d_advice_in, const uint64_t* instances, siz
         for (int i = 0; i < nl; i++) qp.lk.push_back(lk[i].cosets);
         quotient_registry(pk, qp, reg);
         // VM v2 (gate-factored fold, shared subexpressions in LDS); the plain Horner fold through VM v1 if it does not fit
-        int qrc = getenv("BZH_QUOTIENT_V1") ? BZH_E_RANGE : run_quotient(reg, en, h);
+        int qrc = getenv("BZH_QUOTIENT_V1") ? BZH_E_RANGE : run_quotient(reg, en, h, &qp);
         if (qrc == BZH_E_RANGE) {
             qrc = run(key(40, 0), [&](EPool& ep) {
                 int tinv = -1;

@@ -45,6 +45,10 @@ struct bzh_pk {
     //   q_module / q_fn: a code object the caller compiled from bzh_pk_quotient_source (any other circuit).
     // q_select: BZH_QUOTIENT_* -- which of the three runs.
     bzh_quotient_launch_fn q_builtin = nullptr;
+    // the builtin kernel's unsaturated-limb flavour (csrc/fe29.cuh) and the key-owned columns it reads as fe29 planes, converted
+    // once at bzh_pk_create: fixed cosets | sigma cosets | l0, l_last, l_blind, X, 1/(X^n - 1) | hoisted columns (9 en words each)
+    bzh_quotient_launch_fn q_builtin29 = nullptr;
+    uint32_t* key29 = nullptr;
     hipModule_t q_module = nullptr;
     hipFunction_t q_fn = nullptr;
     int q_select = BZH_QUOTIENT_INTERPRETER;
@@ -813,7 +817,31 @@ static int pk_create_t(bzh_ctx* ctx, const bzh_bases* srs, const uint8_t* blob, 
         size_t nb = 0;
         const bzh_builtin_quotient* tab = bzh_builtin_quotients ? bzh_builtin_quotients(&nb) : nullptr;
         for (size_t i = 0; i < nb; i++)
-            if (tab[i].program_hash == pk.q_hash) pk.q_builtin = tab[i].launch;
+            if (tab[i].program_hash == pk.q_hash) {
+                pk.q_builtin = tab[i].launch;
+                pk.q_builtin29 = tab[i].launch29;
+            }
+    }
+    if constexpr (fe29_supported<SF>()) {
+        if (pk.q_builtin29 && !getenv("BZH_QUOTIENT_SATURATED")) {
+            const size_t cols29 = (size_t)pk.nf + m + 5 + pk.hoist_cols;
+            BZH_HIP_TRY(ctx, hipMalloc((void**)&pk.key29, cols29 * 9 * en * 4));
+            const dim3 blk(256);
+            uint32_t* d = pk.key29;
+            auto conv = [&](const uint32_t* src, size_t ncols) {
+                if (ncols) hipLaunchKernelGGL((k_sat_to_fe29_planes<SF>), dim3((unsigned)((en + 255) / 256), (unsigned)ncols), blk, 0, st, src, d, en);
+                d += ncols * 9 * en;
+            };
+            conv(pk.fixed_cosets, (size_t)pk.nf);
+            conv(pk.sigma_cosets, m);
+            conv(pk.l0, 5);       // l0, l_last, l_blind, x_col, tinv_col are consecutive columns of the key's allocation
+            conv(pk.hoist, pk.hoist_cols);
+            BZH_HIP_TRY(ctx, hipGetLastError());
+        } else {
+            pk.q_builtin29 = nullptr;
+        }
+    } else {
+        pk.q_builtin29 = nullptr;
     }
     const char* qenv = getenv("BZH_QUOTIENT");
     pk.q_select = (pk.q_builtin && !(qenv && !strcmp(qenv, "interp"))) ? BZH_QUOTIENT_BUILTIN : BZH_QUOTIENT_INTERPRETER;

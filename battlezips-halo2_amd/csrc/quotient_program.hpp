@@ -346,6 +346,166 @@ static std::string program2_source(const Program2& pg, int field, bool builtin =
     return src;
 }
 
+// The same program over UNSATURATED limbs (csrc/fe29.cuh): values are 9 x 29-bit limbs in R' = 2^261 Montgomery form, not kept
+// canonical; every value the kernel holds has carried limbs (< 2^29 + 8) and a statically known bound in multiples of p, tracked
+// HERE while the straight-line code is emitted: leaves and constants arrive below 2 p, a product leaves its result below 2 p,
+// a + b adds the bounds, a - b adds K p with K the power of two that dominates b's bound (fe29_sub<P, K>), and an operand is
+// folded back below 2 p (fe29_fold, ~45 instructions) whenever a product's operand bounds would multiply past 100 or a sum would
+// pass 100 (the representation holds 128 p).  Columns are fe29 planes (fe29_load_planes), constants 12 words apart; the result is
+// converted back to the saturated form by fe29_to_sat_div32 as it is stored, so h is what the saturated kernel writes, bit for bit.
+static std::string program2_source29(const Program2& pg, int field) {
+    std::string src;
+    char buf[640];
+    auto add = [&](const char* fmt, auto... a) {
+        snprintf(buf, sizeof(buf), fmt, a...);
+        src += buf;
+    };
+    const unsigned long long hash = (unsigned long long)program2_hash(pg, field);
+    char kname[64];
+    snprintf(kname, sizeof(kname), "bzh_quotient29_%016llx", hash);
+    add("// generated by libbzh2 (bzh_quotient_source_for_circuit): quotient evaluator in unsaturated limbs, %zu instructions\n", pg.ops.size());
+    add("namespace bzh_q29_%016llx {\n", hash);
+    src += "using namespace bzh;\n";
+    add("typedef %s P;\n", field == BZH_FIELD_FQ ? "FqParams" : "FpParams");
+    // (out of line like the saturated flavour's, for the instruction cache; operands as 9-lane vectors: a 36-byte struct would
+    // cross the call through scratch memory)
+    src += "__device__ __noinline__ fe29_vec mulv(fe29_vec a, fe29_vec b) { return fe29_pack_vec(fe29_mul(fe29_unpack_vec<P>(a), fe29_unpack_vec<P>(b))); }\n"
+           "__device__ __forceinline__ Fe29<P> mulx(const Fe29<P>& a, const Fe29<P>& b) { return fe29_unpack_vec<P>(mulv(fe29_pack_vec(a), fe29_pack_vec(b))); }\n";
+    // (132 VGPRs, three waves per SIMD: forcing four with amdgpu_waves_per_eu(4, 4) -- 128 VGPRs, 3 spilled -- measured slower,
+    // 34.2 against 33.4 ms per batch of 64)
+    add("extern \"C\" __global__ void __launch_bounds__(128) %s(const uint32_t* const* __restrict__ cols, ", kname);
+    src += "const size_t* __restrict__ strides, const uint32_t* __restrict__ consts, size_t const_stride, size_t size, "
+           "uint32_t* __restrict__ out) {\n"
+           "    const size_t r = blockIdx.x * (size_t)128 + threadIdx.x, v = blockIdx.y;\n"
+           "    if (r >= size) return;\n"
+           "    const size_t mask = size - 1;\n"
+           "    const uint32_t* cv = consts + v * const_stride * 12;\n"
+           "    Fe29<P> r0 = fe29_zero<P>(), r1 = r0, r2 = r0, r3 = r0;\n";
+    const int nslots = std::max(pg.nlds, 1);
+    for (int i = 0; i < nslots; i++) add("    Fe29<P> s%d = r0;\n", i);
+    std::vector<double> bs((size_t)nslots, 0.0);
+    double br[4] = {0, 0, 0, 0};
+    const size_t nops = pg.ops.size();
+    auto is_mem = [](int kind) { return kind == BZH_EXPR_COLUMN || kind == BZH_EXPR_CONST; };
+    auto emit_load = [&](const char* name, size_t i, int kind, int idx, int rot) {
+        if (kind == BZH_EXPR_COLUMN)
+            add("    const Fe29<P> %s%zu = fe29_load_planes<P>(cols[%d] + v * strides[%d], (r + (size_t)(long)(%d)) & mask, size);\n", name, i, idx, idx, rot);
+        else if (kind == BZH_EXPR_CONST)
+            add("    const Fe29<P> %s%zu = fe29_load_const<P>(cv + %d * 12);\n", name, i, idx);
+    };
+    auto emit_loads = [&](size_t i) {
+        if (i >= nops) return;
+        const ExprOp2& o = pg.ops[i];
+        const int form = o.code >> 4, op = (o.code >> 2) & 3;
+        if (form == V2_LL || (form == V2_UN && op == V2_LOAD)) emit_load("la", i, o.a_kind, o.a_idx, o.a_rot);
+        if (form == V2_SL || form == V2_LL) emit_load("lb", i, o.b_kind, o.b_idx, o.b_rot);
+    };
+    struct Val {
+        std::string name;
+        double bound;
+        bool mem;   // a freshly loaded leaf (const Fe29: cannot be folded in place)
+    };
+    auto operand = [&](const char* name, size_t i, int kind, int idx) -> Val {
+        char t[32];
+        if (is_mem(kind)) {
+            snprintf(t, sizeof(t), "%s%zu", name, i);
+            return Val{t, 2.0, true};
+        }
+        snprintf(t, sizeof(t), "s%d", idx);
+        return Val{t, bs[(size_t)idx], false};
+    };
+    int ntmp = 0;
+    // bring an operand below 2 p
+    auto fold = [&](Val& x) {
+        if (x.bound <= 2.0) return;
+        if (x.mem) {
+            char t[32];
+            snprintf(t, sizeof(t), "f%d", ntmp++);
+            add("    const Fe29<P> %s = fe29_fold(%s);\n", t, x.name.c_str());
+            x.name = t;
+        } else {
+            add("    %s = fe29_fold(%s);\n", x.name.c_str(), x.name.c_str());
+            // the variable itself is now small: remember it
+            if (x.name[0] == 'r') br[x.name[1] - '0'] = 2.0;
+            else if (x.name[0] == 's') bs[(size_t)atoi(x.name.c_str() + 1)] = 2.0;
+        }
+        x.bound = 2.0;
+    };
+    auto pow2_over = [](double b) {
+        int k = 4;
+        while ((double)k < b + 1.0) k *= 2;
+        return k;
+    };
+    // dst = a (op) b with bounds; returns the bound of dst
+    auto arith = [&](int op, const std::string& dst, Val a, Val b) -> double {
+        if (op == V2_RSUB) {   // b - a
+            std::swap(a, b);
+            op = V2_SUB;
+        }
+        if (op == V2_MUL) {
+            if (a.bound * b.bound > 100.0) {
+                if (a.bound >= b.bound) fold(a);
+                else fold(b);
+            }
+            if (a.bound * b.bound > 100.0) {
+                fold(a);
+                fold(b);
+            }
+            add("    %s = mulx(%s, %s);\n", dst.c_str(), a.name.c_str(), b.name.c_str());
+            return 2.0;
+        }
+        if (op == V2_ADD) {
+            if (a.bound + b.bound > 100.0) {
+                if (a.bound >= b.bound) fold(a);
+                else fold(b);
+            }
+            if (a.bound + b.bound > 100.0) fold(a.bound >= b.bound ? a : b);
+            add("    %s = fe29_add_c(%s, %s);\n", dst.c_str(), a.name.c_str(), b.name.c_str());
+            return a.bound + b.bound;
+        }
+        // a - b
+        if (b.bound > 60.0) fold(b);
+        int K = pow2_over(b.bound);
+        if (a.bound + K > 100.0) fold(a);
+        add("    %s = fe29_sub<P, %d>(%s, %s);\n", dst.c_str(), K, a.name.c_str(), b.name.c_str());
+        return a.bound + K;
+    };
+    static const char* const regs[4] = {"r0", "r1", "r2", "r3"};
+    emit_loads(0);
+    for (size_t i = 0; i < nops; i++) {
+        const ExprOp2& o = pg.ops[i];
+        const int form = o.code >> 4, op = (o.code >> 2) & 3, pos = o.code & 3;
+        emit_loads(i + 1);
+        const std::string ra = regs[pos];
+        if (form == V2_SS) {
+            br[pos] = arith(op, ra, Val{ra, br[pos], false}, Val{regs[(pos + 1) & 3], br[(pos + 1) & 3], false});
+        } else if (form == V2_SL) {
+            br[pos] = arith(op, ra, Val{ra, br[pos], false}, operand("lb", i, o.b_kind, o.b_idx));
+        } else if (form == V2_LL) {
+            br[pos] = arith(op, ra, operand("la", i, o.a_kind, o.a_idx), operand("lb", i, o.b_kind, o.b_idx));
+        } else if (op == V2_NEG) {
+            Val a{ra, br[pos], false};
+            if (a.bound > 60.0) fold(a);
+            const int K = pow2_over(a.bound);
+            add("    %s = fe29_sub<P, %d>(fe29_zero<P>(), %s);\n", ra.c_str(), K, ra.c_str());
+            br[pos] = (double)K;
+        } else if (op == V2_LOAD) {
+            const Val a = operand("la", i, o.a_kind, o.a_idx);
+            src += "    " + ra + " = " + a.name + ";\n";
+            br[pos] = a.bound;
+        } else {
+            add("    s%d = %s;\n", o.a_idx, ra.c_str());
+            bs[(size_t)o.a_idx] = br[pos];
+        }
+        src += "    __builtin_amdgcn_sched_barrier(0);\n";
+    }
+    src += "    fe_store(out + (v * size + r) * 8, fe29_to_sat_div32(r0));\n}\n";
+    add("static void launch(unsigned gx, unsigned gy, void* st, const uint32_t* const* cols, const size_t* strides, const uint32_t* consts, "
+        "size_t nc, size_t size, uint32_t* out) {\n    hipLaunchKernelGGL(%s, dim3(gx, gy), dim3(128), 0, (hipStream_t)st, cols, strides, consts, nc, size, out);\n}\n", kname);
+    add("}  // namespace bzh_q29_%016llx\n", hash);
+    return src;
+}
+
 struct Compiler2 {
     const EPool& pool;
     Program2 prog;

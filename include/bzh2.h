@@ -356,7 +356,10 @@ int bzh_quotient_degree_histogram(int curve, const uint8_t* circuit, size_t circ
 /* launcher of one builtin kernel, and the table the generated file exports (used inside the library) */
 typedef void (*bzh_quotient_launch_fn)(unsigned grid_x, unsigned grid_y, void* hip_stream, const uint32_t* const* cols, const size_t* strides,
                                        const uint32_t* consts, size_t const_stride, size_t size, uint32_t* out);
-typedef struct { uint64_t program_hash; bzh_quotient_launch_fn launch; const char* name; } bzh_builtin_quotient;
+/* launch29 (may be NULL): the same program in unsaturated 9 x 29-bit limbs (csrc/fe29.cuh: 188-instruction products without carry
+ * instructions).  Its columns are fe29 planes (9 * size words per column: limbs 0-3 | limbs 4-7 | limb 8), `strides` in words
+ * between proofs, constants 12 words apart (9 used), `out` saturated as for `launch`. */
+typedef struct { uint64_t program_hash; bzh_quotient_launch_fn launch; const char* name; bzh_quotient_launch_fn launch29; } bzh_builtin_quotient;
 const bzh_builtin_quotient* bzh_builtin_quotients(size_t* count);
 int bzh_pk_info(const bzh_pk* pk, size_t* rng_bytes_per_proof, size_t* max_proof_bytes, uint32_t* num_advice, uint32_t* n_rows,
                 uint32_t* usable_rows);

@@ -70,6 +70,14 @@ static bool check(const char* name) {
         expect(fe_eq(sat_of(fe29_mul(a, b), k), fe_mul(A, B)), "mul (32 p x 2 p)");
         expect(fe_eq(fe29_to_sat_div32(fe29_mul(a, b)), fe_mul(A, B)), "to_sat_div32 of a product");
         expect(fe_eq(fe29_to_sat_div32(fe29_from_sat_x32(A)), A), "to_sat_div32 of a 32 p value");
+        {   // fold: a 32 p and a 96 p value come back below 2 p, same residue, carried
+            const Fe29<P> big = fe29_sub<P, 64>(fe29_from_sat_x32(A), b);     // < 32 p + 64 p
+            const Fe29<P> f1 = fe29_fold(fe29_carry(fe29_from_sat_x32(A))), f2 = fe29_fold(big);
+            expect(fe_eq(fe29_to_sat_div32(f1), A) && f1.l[8] <= (2u << 22), "fold of a 32 p value");
+            expect(fe_eq(fe29_to_sat_div32(f2), fe_sub(A, B)) && f2.l[8] <= (2u << 22), "fold of a 96 p value");
+            for (int j = 0; j < 8; j++) expect(f2.l[j] < (1u << 29) + 8u, "fold limb bound");
+            expect(fe_eq(fe29_to_sat_div32(fe29_add_c(f1, fe29_add_c(f2, f2))), fe_add(A, fe_dbl(fe_sub(A, B)))), "add_c chain");
+        }
         expect(fe_eq(fe29_to_sat_div32(fe29_sub<P, 16>(fe29_mul(a, k.one), b)), fe_sub(A, B)), "to_sat_div32 of an 18 p value");
         const Fe29<P> ar = fe29_mul(a, k.one);
         expect(fe_eq(sat_of(fe29_sqr(ar), k), fe_sqr(A)), "sqr");

@@ -108,13 +108,13 @@ def test_builtin_quotient_kernels_cover_the_references_circuits(bzh2_lib):
     L = bzh2_lib.load()
 
     class Entry(ctypes.Structure):
-        _fields_ = [("program_hash", ctypes.c_uint64), ("launch", ctypes.c_void_p), ("name", ctypes.c_char_p)]
+        _fields_ = [("program_hash", ctypes.c_uint64), ("launch", ctypes.c_void_p), ("name", ctypes.c_char_p), ("launch29", ctypes.c_void_p)]
     L.bzh_builtin_quotients.restype = ctypes.POINTER(Entry)
     L.bzh_builtin_quotients.argtypes = [ctypes.POINTER(ctypes.c_size_t)]
     n = ctypes.c_size_t()
     tab = L.bzh_builtin_quotients(ctypes.byref(n))
     table = {tab[i].name.decode(): tab[i].program_hash for i in range(n.value)}
-    assert set(table) == {"ShotCircuit", "BoardCircuit"} and all(tab[i].launch for i in range(n.value))
+    assert set(table) == {"ShotCircuit", "BoardCircuit"} and all(tab[i].launch and tab[i].launch29 for i in range(n.value))
     L.bzh_quotient_source_for_circuit.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t,
                                                   ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_uint64)]
     for kind, name, ks in ((Cm.SHOT, "ShotCircuit", (11, 13)), (Cm.BOARD, "BoardCircuit", (12, 14))):
@@ -127,5 +127,6 @@ def test_builtin_quotient_kernels_cover_the_references_circuits(bzh2_lib):
             assert h.value == table[name], (name, k)
             buf = ctypes.create_string_buffer(ln.value + 1)
             assert L.bzh_quotient_source_for_circuit(0, blob, len(blob), buf, ln.value + 1, ctypes.byref(ln), ctypes.byref(h)) == 0
-            assert ("bzh_quotient_%016x" % h.value) in buf.value.decode()
+            text = buf.value.decode()
+            assert ("bzh_quotient_%016x" % h.value) in text and ("bzh_quotient29_%016x" % h.value) in text   # both limb flavours
     assert L.bzh_quotient_source_for_circuit(0, b"junk", 4, None, 0, ctypes.byref(ln), ctypes.byref(h)) == bzh2_lib.E_ARG
