@@ -271,8 +271,10 @@ int msm_run_paired(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_scala
                    int form, uint32_t* d_out_xyz);
 int ntt_run(bzh_ctx* ctx, int field, uint32_t* d_data, unsigned log_n, size_t batch, const uint64_t* omega,
             const uint64_t* coset_shift, int inverse, int form);
+// d_out29 != null (Pasta scalar fields): the evaluations leave the last pass as unsaturated planes (fe29.cuh, 9 * 2^log_n words per
+// polynomial) instead of going to d_dst, which may then be null
 int ntt_run_padded(bzh_ctx* ctx, int field, uint32_t* d_dst, const uint32_t* d_src, unsigned src_log, unsigned log_n, size_t batch,
-                   const uint64_t* omega, const uint64_t* coset_shift);
+                   const uint64_t* omega, const uint64_t* coset_shift, uint32_t* d_out29 = nullptr);
 int bases_to_montgomery(bzh_ctx* ctx, int curve, uint32_t* d_xy, size_t n);
 int bases_precompute(bzh_ctx* ctx, bzh_bases* bases, int window_bits);
 // The IPA's generator collapse on the device.  For every proof b of `batch`: G'[b][i] = sum_{t < cnt} s[b][t] * G[i + t*m], i < m

@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(kNttThreads) __attribute__((amdgpu_waves_per_e
             const size_t k = ((size_t)kr << g.logA) + (tile_id << logW) + i;
             if (g.post_lo) v = fe_mul(v, pow_table<P>(g.post_lo, g.post_hi, g.h, k));
             if (g.cube_post) v = fe_mul(v, cube_const<P>(g, (unsigned)(k % 3)));
-            fe_store(vec + k * 8, v);
+            ntt_store_out<P>(g, vec, (size_t)blockIdx.y, (size_t)1 << g.log_n, k, v);
         }
     }
 }
@@ -335,8 +335,9 @@ static int build_domain(bzh_ctx* ctx, NttDomain& d, const Fe<P>& omega_m, const 
 
 template <class P>
 static int ntt_run_t(bzh_ctx* ctx, uint32_t* d_data, unsigned log_n, size_t batch, const uint64_t* omega,
-                     const uint64_t* coset_shift, int inverse, int form, const uint32_t* d_src = nullptr, unsigned src_log = 0) {
-    if (log_n == 0) return BZH_OK;  // size-1 transform is the identity (n^-1 = 1, shift^0 = 1)
+                     const uint64_t* coset_shift, int inverse, int form, const uint32_t* d_src = nullptr, unsigned src_log = 0,
+                     uint32_t* d_out29 = nullptr) {
+    if (log_n == 0) return d_out29 ? BZH_E_ARG : BZH_OK;  // size-1 transform is the identity (n^-1 = 1, shift^0 = 1)
     Fe<P> w, sh = fe_one<P>();
     for (int i = 0; i < 4; i++) {
         w.l[2 * i] = (uint32_t)omega[i];
@@ -386,6 +387,7 @@ static int ntt_run_t(bzh_ctx* ctx, uint32_t* d_data, unsigned log_n, size_t batc
     if (d_src) {
         if (src_log > log_n || form != BZH_FORM_MONTGOMERY) return BZH_E_ARG;
         nz = (int)(log_n - src_log);
+        if ((np < 2 || nz > bits[0] || nz == 0) && !d_data) return BZH_E_ARG;   // (planes-only output needs the multi-pass path)
         if (np < 2 || nz > bits[0] || nz == 0) {  // single-pass sizes: pad in memory and run the plain transform
             BZH_HIP_TRY(ctx, hipMemsetAsync(d_data, 0, total * 32, ctx->stream));
             BZH_HIP_TRY(ctx, hipMemcpy2DAsync(d_data, ((size_t)32) << log_n, d_src, ((size_t)32) << src_log, ((size_t)32) << src_log, batch,
@@ -431,6 +433,7 @@ static int ntt_run_t(bzh_ctx* ctx, uint32_t* d_data, unsigned log_n, size_t batc
         a.post_lo = (post && a.last) ? dom->d_tables + dom->off_sc_lo : nullptr;
         a.post_hi = dom->d_tables + dom->off_sc_hi;
         a.cube_pre = a.cube_post = a.tw_always = 0;
+        a.dst29 = nullptr;
         memcpy(a.cube, dom->cube, sizeof(a.cube));
         if (pre && dom->shift_is_cube) {  // coeff_to_extended: shift = ZETA
             if (p == 0) a.cube_pre = 1;
@@ -459,7 +462,8 @@ static int ntt_run_t(bzh_ctx* ctx, uint32_t* d_data, unsigned log_n, size_t batc
                 size_t nb = batch - b0 < 65535 ? batch - b0 : 65535;
                 NttPassArgs aa = a;
                 aa.src = a.src + (b0 << (log_n - (unsigned)a.nz)) * 8;
-                aa.dst = a.dst + (b0 << log_n) * 8;
+                aa.dst = a.dst ? a.dst + (b0 << log_n) * 8 : nullptr;
+                aa.dst29 = (a.last && d_out29) ? d_out29 + (b0 << log_n) * 9 : nullptr;
                 // in-wave butterflies when the tile is a full 2048 elements of 6..9 radix bits; BZH_NTT_LDS=1 keeps the LDS tile
                 static const bool lds_only = getenv("BZH_NTT_LDS") != nullptr;
                 const dim3 grid((unsigned)tiles, (unsigned)nb), blk(kNttThreads);
@@ -518,11 +522,12 @@ int ntt_run(bzh_ctx* ctx, int field, uint32_t* d_data, unsigned log_n, size_t ba
 // coeff_to_extended without the padded copy: `batch` polynomials of 2^src_log coefficients at d_src (pitch 2^src_log)
 // -> their evaluations over the 2^log_n coset at d_dst (pitch 2^log_n).  Montgomery form.
 int ntt_run_padded(bzh_ctx* ctx, int field, uint32_t* d_dst, const uint32_t* d_src, unsigned src_log, unsigned log_n, size_t batch,
-                   const uint64_t* omega, const uint64_t* coset_shift) {
+                   const uint64_t* omega, const uint64_t* coset_shift, uint32_t* d_out29) {
     const int f = BZH_FORM_MONTGOMERY;
+    if (d_out29 && field != BZH_FIELD_FP && field != BZH_FIELD_FQ) return BZH_E_ARG;
     switch (field) {
-        case BZH_FIELD_FP: return ntt_run_t<FpParams>(ctx, d_dst, log_n, batch, omega, coset_shift, 0, f, d_src, src_log);
-        case BZH_FIELD_FQ: return ntt_run_t<FqParams>(ctx, d_dst, log_n, batch, omega, coset_shift, 0, f, d_src, src_log);
+        case BZH_FIELD_FP: return ntt_run_t<FpParams>(ctx, d_dst, log_n, batch, omega, coset_shift, 0, f, d_src, src_log, d_out29);
+        case BZH_FIELD_FQ: return ntt_run_t<FqParams>(ctx, d_dst, log_n, batch, omega, coset_shift, 0, f, d_src, src_log, d_out29);
         case BZH_FIELD_BN254_FR: return ntt_run_t<BnFrParams>(ctx, d_dst, log_n, batch, omega, coset_shift, 0, f, d_src, src_log);
         case BZH_FIELD_BN254_FQ: return ntt_run_t<BnFqParams>(ctx, d_dst, log_n, batch, omega, coset_shift, 0, f, d_src, src_log);
     }

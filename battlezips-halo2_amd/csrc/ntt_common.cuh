@@ -3,6 +3,7 @@
 #pragma once
 #include "ctx.hpp"
 #include "field.cuh"
+#include "fe29.cuh"
 
 namespace bzh {
 
@@ -38,7 +39,20 @@ struct NttPassArgs {
     int nz;         // first pass of a zero-padded transform: the source holds N >> nz coefficients per vector (rows
                     // >= R >> nz are zero and are not read); the first nz stages then only replicate values
     uint32_t cube[3][8];
+    uint32_t* dst29;  // last pass, non-null: vector b's output goes to the unsaturated planes at dst29 + b * 9 * N (fe29.cuh: what the
+                      // quotient evaluator reads) INSTEAD of dst -- coeff_to_extended straight into the evaluator's format
 };
+// the last pass's store: saturated element k of the vector, or its fe29 planes
+template <class P>
+__device__ __forceinline__ void ntt_store_out(const NttPassArgs& g, uint32_t* vec, size_t vec_index, size_t N, size_t k, const Fe<P>& v) {
+    if constexpr (fe29_supported<P>()) {
+        if (g.dst29) {
+            fe29_store_planes<P>(g.dst29 + vec_index * 9 * N, k, N, fe29_from_sat_reduced(v));
+            return;
+        }
+    }
+    fe_store(vec + k * 8, v);
+}
 
 template <class P>
 __device__ __forceinline__ Fe<P> tile_get(const uint4* t, int idx) {

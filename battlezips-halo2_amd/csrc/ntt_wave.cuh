@@ -170,7 +170,7 @@ __global__ void __launch_bounds__(kNttThreads) k_ntt_pass_wave(NttPassArgs g) {
             const size_t k = ((size_t)t << g.logA) + (tile_id << logW) + col;
             if (g.post_lo) v = fe_mul(v, pow_table<P>(g.post_lo, g.post_hi, g.h, k));
             if (g.cube_post) v = fe_mul(v, cube_const<P>(g, (unsigned)(k % 3)));
-            fe_store(vec + k * 8, v);
+            ntt_store_out<P>(g, vec, (size_t)blockIdx.y, N, k, v);
         }
     }
 }

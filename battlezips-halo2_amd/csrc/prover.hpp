@@ -45,6 +45,16 @@ struct Prover {
     }
 
     uint32_t* dalloc(size_t elems) { return (uint32_t*)arena.alloc(elems * 32); }
+    // The quotient's per-proof columns on the extended coset exist for the quotient alone.  When the builtin kernel's
+    // unsaturated-limb flavour will run (decided once per call), coeff_to_extended writes them straight as fe29 planes
+    // (9 words per element, ntt_store_out) and no saturated copy is ever made.
+    const bool q29 = [&] {
+        if constexpr (!fe29_supported<SF>()) return false;
+        std::lock_guard<std::mutex> lk(pk.mu);
+        return pk.q_ok && pk.q_builtin29 && pk.key29 && pk.q_select == BZH_QUOTIENT_BUILTIN && pk.en % 128 == 0 && pk.ek >= 12 &&
+               !getenv("BZH_QUOTIENT_V1");
+    }();
+    uint32_t* ext_alloc(size_t cols) { return q29 ? (uint32_t*)arena.alloc(cols * 9 * en * 4) : dalloc(cols * en); }
     int zero(uint32_t* p, size_t elems) {
         BZH_HIP_TRY(ctx, hipMemsetAsync(p, 0, elems * 32, st));
         return BZH_OK;
@@ -148,6 +158,17 @@ struct Prover {
     }
     int to_extended(uint32_t* dst, const uint32_t* polys, size_t count) {
         if (!count) return BZH_OK;
+        if (q29) {
+            static const bool unfused = getenv("BZH_QUOTIENT29_UNFUSED") != nullptr;   // experiment: saturated cosets + a conversion pass
+            if (!unfused) return ntt_run_padded(ctx, field, nullptr, polys, pk.k, pk.ek, count, pk.eomega, pk.zeta, dst);
+            ArenaScope scope(arena);
+            uint32_t* sat = dalloc(count * en);
+            if (!sat) return BZH_E_OOM;
+            PV_TRY(ntt_run_padded(ctx, field, sat, polys, pk.k, pk.ek, count, pk.eomega, pk.zeta));
+            hipLaunchKernelGGL((k_sat_to_fe29_planes<SF>), dim3((unsigned)((en + 255) / 256), (unsigned)count), dim3(256), 0, st, sat, dst, en);
+            BZH_HIP_TRY(ctx, hipGetLastError());
+            return BZH_OK;
+        }
         return ntt_run_padded(ctx, field, dst, polys, pk.k, pk.ek, count, pk.eomega, pk.zeta);
     }
     // Params::commit for `count` polynomials (rows of `pitch` elements): affine canonical points out
@@ -264,62 +285,37 @@ struct Prover {
 
     // the quotient through VM v2 (the program compiled at bzh_pk_create), as the builtin kernel, the caller's module or the
     // interpreter.  Returns BZH_E_RANGE when the circuit does not fit VM v2 (the caller falls back to the plain fold through `run`).
-    // The builtin kernel in unsaturated limbs: the per-proof columns (advice, instance, grand products, permuted lookup columns on
-    // the extended coset) are re-written as fe29 planes first (k_sat_to_fe29_planes: value x 2^5 reduced below 2 p, 36 bytes per
-    // element), the key's columns were converted at bzh_pk_create, the constants are converted on the host.
-    int run_quotient29(const Cols& reg, const QuotientPtrs& qp, size_t size, uint32_t* d_out) {
+    // The builtin kernel in unsaturated limbs.  qp holds fe29 PLANE buffers here (to_extended wrote them: [proof][column][9 size
+    // words]); the key's columns were converted at bzh_pk_create, the constants are converted on the host.  The column order is
+    // quotient_registry's (the program's column indices refer to it), followed by the hoisted columns.
+    int run_quotient29(const QuotientPtrs& qp, size_t size, uint32_t* d_out) {
         const Program2& pg = pk.qprog;
-        const size_t nc = pg.consts.size(), m = pk.perm_columns.size();
-        const int na = pk.na, ni = pk.ni, nz = pk.nsets + pk.nl;
-        struct Family {
-            const uint32_t* sat;
-            size_t ncols;
-            uint32_t* f29;
-        };
-        std::vector<Family> fam;
-        {   // key-owned families, in the order bzh_pk_create converted them
-            uint32_t* d = pk.key29;
-            auto keyfam = [&](const uint32_t* sat, size_t ncols) {
-                fam.push_back(Family{sat, ncols, d});
-                d += ncols * 9 * size;
-            };
-            keyfam(pk.fixed_cosets, (size_t)pk.nf);
-            keyfam(pk.sigma_cosets, m);
-            keyfam(pk.l0, 5);
-            keyfam(pk.hoist, pk.hoist_cols);
-        }
-        ScopedTimer t(ctx, BZH_T_QUOTIENT);
-        auto convert = [&](const uint32_t* sat, size_t ncols) -> int {
-            if (!sat || !ncols) return BZH_OK;
-            uint32_t* d = (uint32_t*)arena.alloc(ncols * 9 * size * 4);
-            if (!d) return BZH_E_OOM;
-            hipLaunchKernelGGL((k_sat_to_fe29_planes<SF>), dim3((unsigned)((size + 255) / 256), (unsigned)ncols), dim3(256), 0, st, sat, d, size);
-            fam.push_back(Family{sat, ncols, d});
-            return BZH_OK;
-        };
-        PV_TRY(convert(qp.adv, B * (size_t)na));
-        PV_TRY(convert(qp.inst, B * (size_t)ni));
-        PV_TRY(convert(qp.z, B * (size_t)nz));
-        for (const uint32_t* c : qp.lk) PV_TRY(convert(c, B * 2));
-        BZH_HIP_TRY(ctx, hipGetLastError());
-        // registry (+ hoisted columns) -> plane pointers: a column is found in its family by its saturated address
+        const size_t nc = pg.consts.size(), m = pk.perm_columns.size(), col = 9 * size;
+        const int na = pk.na, nf = pk.nf, ni = pk.ni, nsets = pk.nsets, nl = pk.nl, nz = pk.nsets + pk.nl;
         std::vector<const uint32_t*> ptrs;
         std::vector<size_t> strides;
-        auto map_col = [&](const uint32_t* sat, size_t stride_elems) -> bool {
-            for (const Family& f : fam) {
-                if (sat >= f.sat && sat < f.sat + f.ncols * size * 8) {
-                    const size_t col = (size_t)(sat - f.sat) / (size * 8);
-                    ptrs.push_back(f.f29 + col * 9 * size);
-                    strides.push_back(stride_elems * 9);      // (elements between proofs) x 9 words
-                    return true;
-                }
-            }
-            return false;
+        auto add = [&](const uint32_t* p, size_t stride_words) {
+            ptrs.push_back(p);
+            strides.push_back(stride_words);
         };
-        for (size_t i = 0; i < reg.ptr.size(); i++)
-            if (!map_col(reg.ptr[i], reg.stride[i])) return BZH_E_ARG;
-        for (size_t hi = 0; hi < pk.hoist_cols; hi++)
-            if (!map_col(pk.hoist + hi * size * 8, 0)) return BZH_E_ARG;
+        const uint32_t *k_fixed = pk.key29, *k_sigma = k_fixed + (size_t)nf * col, *k_misc = k_sigma + m * col, *k_hoist = k_misc + 5 * col;
+        for (int i = 0; i < na; i++) add(qp.adv + (size_t)i * col, (size_t)na * col);
+        for (int i = 0; i < nf; i++) add(k_fixed + (size_t)i * col, 0);
+        for (int i = 0; i < ni; i++) add(qp.inst + (size_t)i * col, (size_t)ni * col);
+        for (size_t j = 0; j < m; j++) add(k_sigma + j * col, 0);
+        for (int i = 0; i < nsets; i++) add(qp.z + (size_t)i * col, (size_t)nz * col);
+        for (int i = 0; i < nl; i++) {
+            add(qp.lk[(size_t)i], 2 * col);
+            add(qp.lk[(size_t)i] + col, 2 * col);
+            add(qp.z + (size_t)(nsets + i) * col, (size_t)nz * col);
+        }
+        for (int i = 0; i < 5; i++) add(k_misc + (size_t)i * col, 0);     // l0, l_last, l_blind, X, 1 / (X^n - 1)
+        {   // the same shape as the saturated registry, or the program's column indices would point elsewhere
+            Cols check;
+            quotient_registry(pk, QuotientPtrs{}, check);
+            if (check.ptr.size() != ptrs.size()) return BZH_E_ARG;
+        }
+        for (size_t hi = 0; hi < pk.hoist_cols; hi++) add(k_hoist + hi * col, 0);
         std::vector<uint32_t> cv(std::max<size_t>(B * nc, 1) * 12, 0u);
         for (size_t b = 0; b < B; b++)
             for (size_t i = 0; i < nc; i++) {
@@ -339,15 +335,16 @@ struct Prover {
         PV_TRY(upload_program(cv.data(), cv.size() * 4, pg.ops.data(), 0, ptrs.data(), strides.data(), ptrs.size(), pa));
         if (ctx->profiling) {
             double cols_read = 0;
-            for (size_t i = 0; i < reg.stride.size(); i++) cols_read += reg.stride[i] ? (double)B : 1.0;
+            for (size_t i = 0; i < strides.size() - pk.hoist_cols; i++) cols_read += strides[i] ? (double)B : 1.0;
             ctx->alg_bytes[BZH_T_QUOTIENT] += (cols_read + (double)B) * (double)size * 32.0;
         }
+        ScopedTimer t(ctx, BZH_T_QUOTIENT);
         pk.q_builtin29((unsigned)(size / 128), (unsigned)B, (void*)st, (const uint32_t* const*)pa.ptrs, (const size_t*)pa.strides, pa.consts, nc, size, d_out);
         BZH_HIP_TRY(ctx, hipGetLastError());
         return BZH_OK;
     }
 
-    int run_quotient(const Cols& reg, size_t size, uint32_t* d_out, const QuotientPtrs* qp = nullptr) {
+    int run_quotient(const Cols& reg, size_t size, uint32_t* d_out) {
         if (!pk.q_ok || size % 128 || size != pk.en) return BZH_E_RANGE;
         hipFunction_t q_fn = nullptr;
         bzh_quotient_launch_fn q_builtin = nullptr;
@@ -359,9 +356,6 @@ struct Prover {
         const Program2* pgp = &pk.qprog;
         const Program2& pg = *pgp;
         if (!pg.ok) return BZH_E_RANGE;
-        if constexpr (fe29_supported<SF>()) {
-            if (q_builtin && qp && pk.q_builtin29 && pk.key29) return run_quotient29(reg, *qp, size, d_out);
-        }
         const size_t nc = pg.consts.size(), ncols = reg.ptr.size() + pk.hoist_cols;
         std::vector<const uint32_t*> ptrs(reg.ptr);
         std::vector<size_t> strides(reg.stride);
@@ -476,8 +470,8 @@ int Prover<C>::prove(const uint32_t* d_advice_in, const uint64_t* instances, siz
     uint32_t *inst_cosets = nullptr, *adv_cosets = nullptr;
     auto extend_witness = [&]() -> int {  // queued late on purpose: runs on the device while the host sorts the lookups
         if (adv_cosets) return BZH_OK;
-        inst_cosets = dalloc(B * std::max(ni, 1) * en);
-        adv_cosets = dalloc(B * na * en);
+        inst_cosets = ext_alloc(B * std::max(ni, 1));
+        adv_cosets = ext_alloc(B * na);
         if (!inst_cosets || !adv_cosets) return BZH_E_OOM;
         PV_TRY(to_extended(inst_cosets, inst_polys, B * ni));
         return to_extended(adv_cosets, adv_polys, B * na);
@@ -584,7 +578,7 @@ int Prover<C>::prove(const uint32_t* d_advice_in, const uint64_t* instances, siz
     // ---- permutation and lookup grand products -----------------------------------------------------
     uint32_t* zs = dalloc(B * std::max(nz, 1) * n);
     uint32_t* z_polys = dalloc(B * std::max(nz, 1) * n);
-    uint32_t* z_cosets = dalloc(B * std::max(nz, 1) * en);
+    uint32_t* z_cosets = ext_alloc(B * std::max(nz, 1));
     // numerators and denominators of ALL grand products side by side, [product][proof][row]: one batch inversion, one
     // element-wise product and one scan for the lot (they were per product; the permutation sets are chained only through a
     // scalar carried from one set's last row into the next, applied afterwards)
@@ -677,7 +671,7 @@ int Prover<C>::prove(const uint32_t* d_advice_in, const uint64_t* instances, siz
         mark(" gp:extend_z");
     }
     for (auto& d : lk) {
-        d.cosets = dalloc(B * 2 * en);
+        d.cosets = ext_alloc(B * 2);
         if (!d.cosets) return BZH_E_OOM;
         PV_TRY(to_extended(d.cosets, d.polys, B * 2));
     }
@@ -720,10 +714,10 @@ int Prover<C>::prove(const uint32_t* d_advice_in, const uint64_t* instances, siz
         QuotientPtrs qp;
         qp.adv = adv_cosets, qp.inst = inst_cosets, qp.z = z_cosets;
         for (int i = 0; i < nl; i++) qp.lk.push_back(lk[i].cosets);
-        quotient_registry(pk, qp, reg);
+        quotient_registry(pk, qp, reg);   // (q29: the per-proof pointers are plane buffers; only run_quotient29 reads them)
         // VM v2 (gate-factored fold, shared subexpressions in LDS); the plain Horner fold through VM v1 if it does not fit
-        int qrc = getenv("BZH_QUOTIENT_V1") ? BZH_E_RANGE : run_quotient(reg, en, h, &qp);
-        if (qrc == BZH_E_RANGE) {
+        int qrc = q29 ? run_quotient29(qp, en, h) : (getenv("BZH_QUOTIENT_V1") ? BZH_E_RANGE : run_quotient(reg, en, h));
+        if (qrc == BZH_E_RANGE && !q29) {
             qrc = run(key(40, 0), [&](EPool& ep) {
                 int tinv = -1;
                 const std::vector<int> terms = quotient_terms<SF>(pk, reg, ep, &tinv);
