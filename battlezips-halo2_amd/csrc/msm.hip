@@ -1707,14 +1707,32 @@ __global__ void __launch_bounds__(256) k_collapse_generators(const uint32_t* __r
             for (int v = top; v >= 1; v--) {
                 const uint32_t lo = st[v], hi = st[v + 1];
                 if (lo < hi) {
-                    Xyzz<P> acc = xyzz_identity<P>();
-                    for (uint32_t e = lo; e < hi; e++) {
-                        const uint32_t ent = ls[e], tw = ent & 0x7fffffffu;
-                        const uint32_t t = tw / (uint32_t)nwin, w = tw - t * (uint32_t)nwin;
-                        Affine<P> q = affine_load<P>(table + ((size_t)w * row_stride + (size_t)t * m + i) * 16);
-                        if (!aff_is_id(q)) {
-                            if (ent >> 31) q.y = fe_neg(q.y);
-                            xyzz_madd(acc, q);
+                    Xyzz<P> acc;
+                    // the level's bucket in unsaturated limbs on the Pasta curves (csrc/curve29.cuh: the mixed addition at 1.28 x),
+                    // handed to the saturated running sums through the product-free conversion -- ~12 points per level
+                    if constexpr (fe29_supported<P>()) {
+                        const Fe29Consts<P> k29 = fe29_consts<P>();
+                        Xyzz29<P> acc29 = xyzz29_identity<P>();
+                        for (uint32_t e = lo; e < hi; e++) {
+                            const uint32_t ent = ls[e], tw = ent & 0x7fffffffu;
+                            const uint32_t t = tw / (uint32_t)nwin, w = tw - t * (uint32_t)nwin;
+                            Affine<P> q = affine_load<P>(table + ((size_t)w * row_stride + (size_t)t * m + i) * 16);
+                            if (!aff_is_id(q)) {
+                                if (ent >> 31) q.y = fe_neg(q.y);
+                                xyzz29_madd(acc29, q, k29);
+                            }
+                        }
+                        acc = xyzz29_to_sat_fast(acc29);
+                    } else {
+                        acc = xyzz_identity<P>();
+                        for (uint32_t e = lo; e < hi; e++) {
+                            const uint32_t ent = ls[e], tw = ent & 0x7fffffffu;
+                            const uint32_t t = tw / (uint32_t)nwin, w = tw - t * (uint32_t)nwin;
+                            Affine<P> q = affine_load<P>(table + ((size_t)w * row_stride + (size_t)t * m + i) * 16);
+                            if (!aff_is_id(q)) {
+                                if (ent >> 31) q.y = fe_neg(q.y);
+                                xyzz_madd(acc, q);
+                            }
                         }
                     }
                     xyzz_add(running, acc);

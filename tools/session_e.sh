@@ -2,6 +2,7 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/r04e
 mkdir -p $O
+python -m pytest $R/tests/test_gpu_env_paths.py $R/tests/test_gpu_ipa.py -x -q > $O/tests.log 2>&1; tail -3 $O/tests.log
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o d -- python3 $R/bench.py --no-cpu-baseline --other-workloads none --concurrency 1 --steps 5 --warmup 2 > $O/b64c1_under_rocprof.json 2> $O/prof.err
 s=$(find $O/prof -name "*kernel_stats.csv" | head -1); cp $s $O/b64c1_kernel_stats.csv; rm -rf $O/prof
