@@ -445,6 +445,7 @@ int bzh_bases_free(bzh_ctx* ctx, bzh_bases* bases) {
     std::lock_guard<std::mutex> lk(ctx->mu);
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(bases->d_xy);
+    if (bases->d_xy29) (void)hipFree(bases->d_xy29);
     delete bases;
     return BZH_OK;
 }

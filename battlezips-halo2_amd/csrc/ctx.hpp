@@ -24,6 +24,10 @@ struct bzh_bases {
     // array are row_stride points apart (0: n) and vector v of a batch reads the columns [v * vec_col_stride, + n)
     size_t row_stride = 0;
     size_t vec_col_stride = 0;
+    // Window tables of the Pasta curves carry a second copy for k_msm_accumulate's unsaturated-limb loop: point i as 20 words --
+    // x then y in 9 x 29-bit limbs (x 2^261, below 2 p, carried), 2 words of padding -- so that the loop loads its operands
+    // ready-made instead of re-slicing and folding two coordinates per addition (csrc/fe29.cuh).  Same indexing as d_xy.
+    uint32_t* d_xy29 = nullptr;
 };
 
 struct bzh_ctx {
@@ -283,7 +287,8 @@ int bases_precompute(bzh_ctx* ctx, bzh_bases* bases, int window_bits);
 // d_table: ceil(256 / c_tail) rows of batch * (m + 2) affine points; d_scratch: msm_collapse_scratch_bytes() bytes.
 // `out` is filled to describe the table array to msm_run_paired (it borrows d_table).
 size_t msm_collapse_scratch_bytes(const bzh_bases* srs, size_t cnt, size_t batch, int c_tail);
-int msm_collapse_table(bzh_ctx* ctx, const bzh_bases* srs, const uint32_t* d_s, size_t cnt, size_t batch, int c_tail, uint32_t* d_table,
+// (d_table29: room for the fe29 copy of the collapsed tables, 20 words per point, or null)
+int msm_collapse_table(bzh_ctx* ctx, const bzh_bases* srs, const uint32_t* d_s, size_t cnt, size_t batch, int c_tail, uint32_t* d_table29, uint32_t* d_table,
                        void* d_scratch, bzh_bases* out);
 // polyops.hip (device pointers, Montgomery form)
 int field_convert(bzh_ctx* ctx, int field, uint32_t* d, size_t count, int to_mont);

@@ -103,8 +103,11 @@ __device__ __noinline__
 #else
 inline
 #endif
-Madd29Special<P> xyzz29_madd_special(const Affine<P> q, const Fe29<P> pp_, const Fe29<P> r) {
+Madd29Special<P> xyzz29_madd_special(const Fe29<P> qx, const Fe29<P> qy, const Fe29<P> pp_, const Fe29<P> r) {
     const Fe29Consts<P> k = fe29_consts<P>();
+    Affine<P> q;   // the saturated point back from its limbs (here, not at the call: the compiler would hoist it into the main path)
+    q.x = fe29_to_sat_div32(qx);
+    q.y = fe29_to_sat_div32(qy);
     Madd29Special<P> out;
     out.v = xyzz29_identity<P>();                                                    // acc == -q
     out.handled = fe29_is_zero_mod_p(pp_, k);
@@ -112,10 +115,10 @@ Madd29Special<P> xyzz29_madd_special(const Affine<P> q, const Fe29<P> pp_, const
     return out;
 }
 
-// acc += q, q affine in the saturated form (not the identity).  madd-2008-s, 8 M + 2 S, as curve.cuh's xyzz_madd.
+// acc += (qx, qy), the point given in the R' form below 2 p with carried limbs (a table's fe29 copy, or fe29_from_sat_reduced of
+// its saturated coordinates), not the identity.  madd-2008-s, 8 M + 2 S, as curve.cuh's xyzz_madd.
 template <class P>
-BZH_HD void xyzz29_madd(Xyzz29<P>& acc, const Affine<P>& q, const Fe29Consts<P>& k) {
-    const Fe29<P> qx = fe29_from_sat_reduced(q.x), qy = fe29_from_sat_reduced(q.y);   // < 2 p, carried
+BZH_HD void xyzz29_madd_q29(Xyzz29<P>& acc, const Fe29<P>& qx, const Fe29<P>& qy, const Fe29Consts<P>& k) {
     if (acc.id) {   // first point of a bucket: lanes reach this on different iterations, so it has to be free
         acc.x = qx;
         acc.y = qy;
@@ -130,7 +133,7 @@ BZH_HD void xyzz29_madd(Xyzz29<P>& acc, const Affine<P>& q, const Fe29Consts<P>&
     const Fe29<P> r = fe29_sub<P, 16>(s2, acc.y);
     // p = 1 mod 2^29 and the carried low limb is exact: a multiple k p of p, 4 < k <= 18, shows its k there
     if (pp_.l[0] - 5u <= 13u) {
-        const Madd29Special<P> sp = xyzz29_madd_special<P>(q, pp_, r);
+        const Madd29Special<P> sp = xyzz29_madd_special<P>(qx, qy, pp_, r);
         if (sp.handled) {
             acc = sp.v;
             return;
@@ -145,6 +148,11 @@ BZH_HD void xyzz29_madd(Xyzz29<P>& acc, const Affine<P>& q, const Fe29Consts<P>&
     acc.x = x3;
     acc.zz = fe29_mul(acc.zz, pp);
     acc.zzz = fe29_mul(acc.zzz, ppp);
+}
+// the same for a point in the saturated form
+template <class P>
+BZH_HD void xyzz29_madd(Xyzz29<P>& acc, const Affine<P>& q, const Fe29Consts<P>& k) {
+    xyzz29_madd_q29(acc, fe29_from_sat_reduced(q.x), fe29_from_sat_reduced(q.y), k);
 }
 
 }  // namespace bzh

@@ -438,7 +438,7 @@ static int ipa_open_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_po
     // device arena (workspace slot 4), per proof: raw rng | rand scalars | s_poly | p x2 | b x2 | s x2 | LR | S scalars | small
     const size_t per = nrand * 16 + nrand * 8 + n * 8 + 2 * n * 8 + 2 * n * 8 + 2 * n * 8 + 2 * (n + 4) * 8 + (n + 2) * 8 +
                        (kHc + 4) * 8;
-    const size_t tail_words = jstar ? B * (tail_m + 2) * (size_t)tail_nwin * 16 + (tail_scratch + 3) / 4 + 64 : 0;
+    const size_t tail_words = jstar ? B * (tail_m + 2) * (size_t)tail_nwin * (16 + 20) + (tail_scratch + 3) / 4 + 64 : 0;   // table + its fe29 copy
     void* arena = nullptr;
     IPA_TRY(ws_ensure(ctx, 4, (B * per + tail_words) * 4 + 256 + 16 * 16, &arena));   // (+ the roundings of take())
     uint32_t* cur = (uint32_t*)arena;
@@ -460,6 +460,7 @@ static int ipa_open_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_po
     const bool paired = bases->pre_c != 0 && k >= 1;  // window table: L_j and R_j of a proof share one dense vector
     uint32_t* d_commit = take(B * (n + 2) * 8);
     uint32_t* d_tail_table = jstar ? take(B * (tail_m + 2) * (size_t)tail_nwin * 16) : nullptr;
+    uint32_t* d_tail_table29 = jstar ? take(B * (tail_m + 2) * (size_t)tail_nwin * 20) : nullptr;
     void* d_tail_scratch = jstar ? (void*)take((tail_scratch + 3) / 4) : nullptr;
     uint32_t* d_hc = take(B * kHc * 8);
     uint32_t* d_dv = take(B * 8);       // s(x3) / v per proof
@@ -531,7 +532,7 @@ static int ipa_open_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_po
     unsigned j0 = 0;        // the round its s vector restarted at
     for (unsigned j = 0; j < k; j++) {
         if (jstar && j == jstar) {
-            IPA_TRY(msm_collapse_table(ctx, bases, s_cur, (size_t)1 << j, B, tail_c, d_tail_table, d_tail_scratch, &tail_bases));
+            IPA_TRY(msm_collapse_table(ctx, bases, s_cur, (size_t)1 << j, B, tail_c, d_tail_table29, d_tail_table, d_tail_scratch, &tail_bases));
             rb = &tail_bases;
             rn = tail_m;
             j0 = j;

@@ -272,7 +272,7 @@ __device__ __forceinline__ Xyzz29<P> raw29_get(const uint4* planes, size_t strid
     return v;
 }
 template <class C, int T, bool U29>
-__device__ __forceinline__ void msm_accumulate_body(const uint32_t* __restrict__ bases,
+__device__ __forceinline__ void msm_accumulate_body(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ bases29,
                                                                   const uint16_t* __restrict__ digits, size_t n, int nwin,
                                                                   int M, size_t chunk, uint4* __restrict__ buckets,
                                                                   uint4* __restrict__ partials, size_t row_len,
@@ -449,9 +449,7 @@ __device__ __forceinline__ void msm_accumulate_body(const uint32_t* __restrict__
             }
             return pidx;
         };
-        uint32_t e_next = sorted[start];
-        Affine<P> q_next = affine_load<P>(base0 + point_index(e_next) * 16);
-        for (uint32_t j = start; j < end; j++) {
+        auto bucket_step = [&](uint32_t j) {   // bucket bookkeeping of item j (both arithmetics)
             if (j == bend) {  // bucket m ended inside this slice
                 if (bbeg < start) {  // head partial: parked in the stitch buffer, not in registers
                     put_head();
@@ -464,16 +462,52 @@ __device__ __forceinline__ void msm_accumulate_body(const uint32_t* __restrict__
                 bbeg = cnt[m - 1];
                 bend = cnt[m];
             }
-            const uint32_t e = e_next;
-            Affine<P> q = q_next;
-            if (j + 1 < end) {   // (a second point in flight -- prefetch two additions ahead -- measured no better: 39.7 vs 38.7 ms per batch)
-                e_next = sorted[j + 1];
-                q_next = affine_load<P>(base0 + point_index(e_next) * 16);
+        };
+        if constexpr (U) {
+            // operands straight from the table's fe29 copy (20 words per point: x, y in carried limbs below 2 p): nothing to
+            // re-slice or fold per addition; the gather of item j+1 is in flight while item j is added
+            const uint32_t* base29 = bases29 + ((vec0 + b) * vec_col_stride + c0) * 20;
+            auto load29 = [&](uint32_t e, Fe29<P>& x, Fe29<P>& y) {
+                const uint4* q = reinterpret_cast<const uint4*>(base29 + point_index(e) * 20);
+                const uint4 a = q[0], bb = q[1], c = q[2], d = q[3], f = q[4];
+                x.l[0] = a.x, x.l[1] = a.y, x.l[2] = a.z, x.l[3] = a.w, x.l[4] = bb.x, x.l[5] = bb.y, x.l[6] = bb.z, x.l[7] = bb.w, x.l[8] = c.x;
+                y.l[0] = c.y, y.l[1] = c.z, y.l[2] = c.w, y.l[3] = d.x, y.l[4] = d.y, y.l[5] = d.z, y.l[6] = d.w, y.l[7] = f.x, y.l[8] = f.y;
+            };
+            uint32_t e_next = sorted[start];
+            Fe29<P> x_next, y_next;
+            load29(e_next, x_next, y_next);
+            for (uint32_t j = start; j < end; j++) {
+                bucket_step(j);
+                const uint32_t e = e_next;
+                const Fe29<P> qx = x_next;
+                Fe29<P> qy = y_next;
+                if (j + 1 < end) {
+                    e_next = sorted[j + 1];
+                    load29(e_next, x_next, y_next);
+                }
+                uint32_t any = 0;   // the identity is stored as zeros
+#pragma unroll
+                for (int i = 0; i < 9; i++) any |= qx.l[i] | qy.l[i];
+                if (any) {
+                    if (e & 0x8000u) qy = fe29_sub<P, 4>(fe29_zero<P>(), qy);   // -y = 4 p - y
+                    xyzz29_madd_q29(run, qx, qy, k29);
+                }
             }
-            if (!aff_is_id(q)) {
-                if (e & 0x8000u) q.y = fe_neg(q.y);
-                if constexpr (U) xyzz29_madd(run, q, k29);
-                else xyzz_madd(run, q);
+        } else {
+            uint32_t e_next = sorted[start];
+            Affine<P> q_next = affine_load<P>(base0 + point_index(e_next) * 16);
+            for (uint32_t j = start; j < end; j++) {
+                bucket_step(j);
+                const uint32_t e = e_next;
+                Affine<P> q = q_next;
+                if (j + 1 < end) {   // (a second point in flight -- prefetch two additions ahead -- measured no better: 39.7 vs 38.7 ms per batch)
+                    e_next = sorted[j + 1];
+                    q_next = affine_load<P>(base0 + point_index(e_next) * 16);
+                }
+                if (!aff_is_id(q)) {
+                    if (e & 0x8000u) q.y = fe_neg(q.y);
+                    xyzz_madd(run, q);
+                }
             }
         }
         // last segment of the slice: bucket m, items [max(bbeg,start), min(bend,end))
@@ -507,7 +541,7 @@ __device__ __forceinline__ void msm_accumulate_body(const uint32_t* __restrict__
     }
     };
     if constexpr (U29) {
-        if (total >= 8u * (uint32_t)M) slice(std::true_type{});
+        if (bases29 && total >= 8u * (uint32_t)M) slice(std::true_type{});
         else slice(std::false_type{});
     } else {
         slice(std::false_type{});
@@ -545,11 +579,11 @@ __device__ __forceinline__ void msm_accumulate_body(const uint32_t* __restrict__
 }
 
 #define BZH_ACC_PARAMS                                                                                                       \
-    const uint32_t *__restrict__ bases, const uint16_t *__restrict__ digits, size_t n, int nwin, int M, size_t chunk,              \
+    const uint32_t *__restrict__ bases, const uint32_t *__restrict__ bases29, const uint16_t *__restrict__ digits, size_t n, int nwin, int M, size_t chunk,              \
         uint4 *__restrict__ buckets, uint4 *__restrict__ partials, size_t row_len, size_t row_stride, size_t dup_from,            \
         unsigned long long *__restrict__ add_counter, size_t vec_col_stride, size_t vec0, uint32_t xcd_vecs, uint32_t xcd_chunks
 #define BZH_ACC_ARGS \
-    bases, digits, n, nwin, M, chunk, buckets, partials, row_len, row_stride, dup_from, add_counter, vec_col_stride, vec0, xcd_vecs, xcd_chunks
+    bases, bases29, digits, n, nwin, M, chunk, buckets, partials, row_len, row_stride, dup_from, add_counter, vec_col_stride, vec0, xcd_vecs, xcd_chunks
 template <class C, int T, bool U29>
 __global__ void __launch_bounds__(T) k_msm_accumulate(BZH_ACC_PARAMS) {
     msm_accumulate_body<C, T, U29>(BZH_ACC_ARGS);
@@ -1366,7 +1400,7 @@ static int msm_run_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_sca
     // per segment: two stitch buffers (+ the ninth limbs of raw buckets and raw head partials when the accumulator is unsaturated:
     // msm_accumulate_body computes the same stride from its template arguments)
     static const bool acc_sat_env = getenv("BZH_ACC_SATURATED") != nullptr;
-    const bool acc_u29 = fe29_supported<typename C::Base>() && !acc_sat_env && !use_gs;
+    const bool acc_u29 = fe29_supported<typename C::Base>() && !acc_sat_env && !use_gs && bases->d_xy29 != nullptr;
     const size_t part_bytes = (size_t)2 * acc_threads * 128 + (acc_u29 ? ((size_t)M_acc + acc_threads) * 16 : 0);
     int rc;
     if ((rc = ws_ensure(ctx, 0, slice * (size_t)p.nwin * n * sizeof(uint16_t), &d_digits))) return rc;
@@ -1469,7 +1503,7 @@ static int msm_run_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_sca
             const bool acc_sat = !acc_u29;
             constexpr bool can29 = fe29_supported<typename C::Base>();
 #define BZH_LAUNCH_ACC_U(TT, UU)                                                                                         \
-    hipLaunchKernelGGL((k_msm_accumulate<C, TT, UU>), grid, dim3(TT), acc_lds, ctx->stream, bases->d_xy,                  \
+    hipLaunchKernelGGL((k_msm_accumulate<C, TT, UU>), grid, dim3(TT), acc_lds, ctx->stream, bases->d_xy, bases->d_xy29,   \
                        (const uint16_t*)d_digits, n_eff, acc_nwin, M_acc, p.chunk, (uint4*)d_buckets, d_partials, row_len, \
                        row_stride, pair_in ? n - 2 : (size_t)0, ctx->profiling ? ctx->d_add_counter : nullptr,            \
                        bases->vec_col_stride, b0, xv, xc)
@@ -1579,6 +1613,33 @@ int msm_run_paired(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_scala
     return BZH_E_ARG;
 }
 
+// the fe29 copy of a table (bzh_bases::d_xy29): 20 words per point
+template <class P>
+__global__ void __launch_bounds__(256) k_points_to_fe29(const uint32_t* __restrict__ xy, uint32_t* __restrict__ xy29, size_t count) {
+    const size_t i = blockIdx.x * (size_t)256 + threadIdx.x;
+    if (i >= count) return;
+    const Affine<P> q = affine_load<P>(xy + i * 16);
+    Fe29<P> x = fe29_zero<P>(), y = x;
+    if (!aff_is_id(q)) {
+        x = fe29_from_sat_reduced(q.x);
+        y = fe29_from_sat_reduced(q.y);
+    }
+    uint4* o = reinterpret_cast<uint4*>(xy29 + i * 20);
+    o[0] = make_uint4(x.l[0], x.l[1], x.l[2], x.l[3]);
+    o[1] = make_uint4(x.l[4], x.l[5], x.l[6], x.l[7]);
+    o[2] = make_uint4(x.l[8], y.l[0], y.l[1], y.l[2]);
+    o[3] = make_uint4(y.l[3], y.l[4], y.l[5], y.l[6]);
+    o[4] = make_uint4(y.l[7], y.l[8], 0u, 0u);
+}
+template <class C>
+static int table_to_fe29(bzh_ctx* ctx, const uint32_t* d_xy, uint32_t* d_xy29, size_t count) {
+    if constexpr (fe29_supported<typename C::Base>()) {
+        hipLaunchKernelGGL((k_points_to_fe29<typename C::Base>), dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream, d_xy, d_xy29, count);
+        BZH_HIP_TRY(ctx, hipGetLastError());
+    }
+    return BZH_OK;
+}
+
 template <class C>
 static int bases_precompute_t(bzh_ctx* ctx, bzh_bases* b, int c) {
     const int nwin = (256 + c - 1) / c;
@@ -1593,6 +1654,15 @@ static int bases_precompute_t(bzh_ctx* ctx, bzh_bases* b, int c) {
     b->d_xy = table;
     b->pre_c = c;
     b->pre_nwin = nwin;
+    if constexpr (fe29_supported<typename C::Base>()) {
+        static const bool no29 = getenv("BZH_ACC_SATURATED") != nullptr;
+        if (!no29) {   // the unsaturated-limb copy for the accumulation loop (+25 % of the table's HBM)
+            BZH_HIP_TRY(ctx, hipMalloc((void**)&b->d_xy29, (size_t)nwin * b->n * 80));
+            const int rc = table_to_fe29<C>(ctx, b->d_xy, b->d_xy29, (size_t)nwin * b->n);
+            if (rc) return rc;
+            BZH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        }
+    }
     return BZH_OK;
 }
 
@@ -1822,7 +1892,7 @@ size_t msm_collapse_scratch_bytes(const bzh_bases* srs, size_t cnt, size_t batch
 
 template <class C, class SF>
 static int msm_collapse_table_t(bzh_ctx* ctx, const bzh_bases* srs, const uint32_t* d_s, size_t cnt, size_t batch, int c_tail,
-                                uint32_t* d_table, void* d_scratch, bzh_bases* out) {
+                                uint32_t* d_table29, uint32_t* d_table, void* d_scratch, bzh_bases* out) {
     const size_t n = srs->n - 2, m = n / cnt, cols = m + 2, npts = batch * cols;
     const int c = srs->pre_c, nwin = srs->pre_nwin, nwin_t = (256 + c_tail - 1) / c_tail;
     if (!c || cnt < 2 || m * cnt != n || m < 2 || c_tail < 4 || c_tail > 13 || batch > 65535) return BZH_E_ARG;
@@ -1858,15 +1928,20 @@ static int msm_collapse_table_t(bzh_ctx* ctx, const bzh_bases* srs, const uint32
     out->pre_nwin = nwin_t;
     out->row_stride = npts;
     out->vec_col_stride = cols;
+    if (d_table29 && fe29_supported<typename C::Base>()) {
+        const int rc = table_to_fe29<C>(ctx, d_table, d_table29, npts * (size_t)nwin_t);
+        if (rc) return rc;
+        out->d_xy29 = d_table29;
+    }
     return BZH_OK;
 }
 
-int msm_collapse_table(bzh_ctx* ctx, const bzh_bases* srs, const uint32_t* d_s, size_t cnt, size_t batch, int c_tail, uint32_t* d_table,
-                       void* d_scratch, bzh_bases* out) {
+int msm_collapse_table(bzh_ctx* ctx, const bzh_bases* srs, const uint32_t* d_s, size_t cnt, size_t batch, int c_tail, uint32_t* d_table29,
+                       uint32_t* d_table, void* d_scratch, bzh_bases* out) {
     switch (srs->curve) {
-        case BZH_CURVE_VESTA: return msm_collapse_table_t<VestaCurve, FpParams>(ctx, srs, d_s, cnt, batch, c_tail, d_table, d_scratch, out);
-        case BZH_CURVE_PALLAS: return msm_collapse_table_t<PallasCurve, FqParams>(ctx, srs, d_s, cnt, batch, c_tail, d_table, d_scratch, out);
-        case BZH_CURVE_BN254: return msm_collapse_table_t<Bn254Curve, BnFrParams>(ctx, srs, d_s, cnt, batch, c_tail, d_table, d_scratch, out);
+        case BZH_CURVE_VESTA: return msm_collapse_table_t<VestaCurve, FpParams>(ctx, srs, d_s, cnt, batch, c_tail, d_table29, d_table, d_scratch, out);
+        case BZH_CURVE_PALLAS: return msm_collapse_table_t<PallasCurve, FqParams>(ctx, srs, d_s, cnt, batch, c_tail, d_table29, d_table, d_scratch, out);
+        case BZH_CURVE_BN254: return msm_collapse_table_t<Bn254Curve, BnFrParams>(ctx, srs, d_s, cnt, batch, c_tail, nullptr, d_table, d_scratch, out);
     }
     return BZH_E_ARG;
 }

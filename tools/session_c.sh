@@ -2,7 +2,7 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/r04c
 mkdir -p $O
-python -m pytest tests/test_gpu_real_circuit_parity.py tests/test_gpu_env_paths.py tests/test_gpu_exprvm.py -x -q -k "not 17 and not production" > $O/tests.log 2>&1; tail -4 $O/tests.log
+python -m pytest tests/test_gpu_msm.py tests/test_gpu_env_paths.py tests/test_gpu_ipa.py tests/test_gpu_config_sizes.py -x -q > $O/tests.log 2>&1; tail -4 $O/tests.log
 cd /tmp && export TMPDIR=/tmp
 for v in u29 sat; do
   if [ $v = sat ]; then export BZH_ACC_SATURATED=1; else unset BZH_ACC_SATURATED; fi
