@@ -28,7 +28,8 @@ def load(directory, counter):
             if row.get("Counter_Name") != counter:
                 continue
             name = re.sub(r"^void ", "", row["Kernel_Name"])
-            name = name.split("(")[0]
+            m = re.match(r"(.*?[\w>])\(", name)      # up to the argument list ("(anonymous namespace)::k(...)" keeps its prefix)
+            name = m.group(1) if m else name
             key = (name, int(row["Workgroup_Size"]), int(row["Grid_Size"]))
             a = acc[key]
             a[0] += float(row["Counter_Value"])
