@@ -72,6 +72,26 @@ int main(int argc, char** argv) {
 
     bzh_circuit* circuit = nullptr;
     CHECK(bzh_circuit_create(BZH_CIRCUIT_SHOT, K, 0, &circuit));  // ShotChip::configure + keygen synthesize
+    // The verifying-key digest (what create_proof / verify_proof absorb first: vk.hash_into) is an INPUT of the boundary: a Rust
+    // shim hands over Fp::to_repr of the scalar it captured from keygen_vk's key; here it can come from the
+    // environment as 64 hex digits (little-endian repr).  Without it the library's placeholder is used: such proofs verify with
+    // bzh_verify_batch, not with the reference's verify_proof.
+    if (const char* hex = getenv("BZH_EXAMPLE_VK_REPR")) {
+        uint8_t repr[32];
+        bool ok = strlen(hex) == 64;
+        for (int i = 0; i < 32 && ok; i++) {
+            unsigned v = 0;
+            ok = sscanf(hex + 2 * i, "%2x", &v) == 1;
+            repr[i] = (uint8_t)v;
+        }
+        if (!ok) {
+            fprintf(stderr, "BZH_EXAMPLE_VK_REPR: 64 hex digits expected\n");
+            return 1;
+        }
+        CHECK(bzh_circuit_set_vk_repr(circuit, repr));
+    }
+    int vk_placeholder = 0;
+    CHECK(bzh_circuit_vk_repr(circuit, nullptr, &vk_placeholder));
     size_t blob_len = 0;
     CHECK(bzh_circuit_blob(circuit, nullptr, 0, &blob_len));
     std::vector<uint8_t> blob(blob_len);
@@ -130,8 +150,9 @@ int main(int argc, char** argv) {
     for (size_t b = 0; b < batch; b++)
         for (size_t i = 0; i < lens[b]; i++) h = (h ^ proofs[b * max_proof + i]) * 1099511628211ull;
     printf("{\"circuit\": \"ShotCircuit k=11\", \"batch\": %zu, \"best_ms\": %.2f, \"proofs_per_s\": %.1f, \"proof_bytes\": %zu, \"verified\": %zu, "
-           "\"quotient\": \"%s\", \"fnv1a\": \"%016llx\"}\n", batch, best, batch / best * 1e3, lens[0], accepted,
-           flavour == BZH_QUOTIENT_BUILTIN ? "builtin kernel" : (flavour == BZH_QUOTIENT_MODULE ? "module" : "interpreted"), (unsigned long long)h);
+           "\"quotient\": \"%s\", \"vk_digest\": \"%s\", \"fnv1a\": \"%016llx\"}\n", batch, best, batch / best * 1e3, lens[0], accepted,
+           flavour == BZH_QUOTIENT_BUILTIN ? "builtin kernel" : (flavour == BZH_QUOTIENT_MODULE ? "module" : "interpreted"),
+           vk_placeholder ? "placeholder (BZH_EXAMPLE_VK_REPR not given)" : "caller's", (unsigned long long)h);
     // what the reference's wasm frontend returns per proof (src/wasm/circuit_wasm.rs:27-31,164-170): {commitment, proof}
     {
         const size_t stride = bzh_record_stride(max_proof);
