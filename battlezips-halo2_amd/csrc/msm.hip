@@ -741,43 +741,80 @@ __global__ void __launch_bounds__(64) k_msm_reduce_wave(const uint4* __restrict_
 // (xyzz_add_quad, csrc/curve.cuh): 16 logical lanes per wave, lane t owns L = M/16 buckets, the suffix scan and the final sum
 // run over 4 + 4 shuffle steps of 4 * d lanes.  2L + 8 quad additions of ~1 500 issue slots instead of 2(M/64) + 12 of ~3 700.
 // ---------------------------------------------------------------------------
-template <class C>
+// The arithmetic of the quad reductions as a policy: saturated XYZZ, or (Pasta curves) unsaturated limbs end to end -- buckets are
+// converted as they are loaded (lane ql of a quad converts coordinate ql, broadcasts), the running sums, their shuffles and their
+// LDS exchanges stay in 9 x 29-bit limbs, one product-free conversion at the very end.  Four products of 188 instructions per lane
+// and addition instead of four of 297.
+template <class P, bool U>
+struct QuadRep;
+template <class P>
+struct QuadRep<P, false> {
+    using X = Xyzz<P>;
+    static constexpr int kPlanes = 8;
+    static __device__ __forceinline__ X identity() { return xyzz_identity<P>(); }
+    static __device__ __forceinline__ X load(const uint4* seg, size_t stride, size_t idx, int) { return planes_get<P>(seg, stride, idx); }
+    static __device__ __forceinline__ void add(X& a, const X& b, int ql) { xyzz_add_quad(a, b, ql); }
+    static __device__ __forceinline__ X dbl(const X& a) { return xyzz_dbl_inl(a); }
+    static __device__ __forceinline__ X shfl_down(const X& a, int d) { return xyzz_shfl_down(a, d); }
+    static __device__ __forceinline__ void lds_put(uint4* buf, int TL, int lt, const X& v) { planes_put(buf, (size_t)TL, (size_t)lt, v); }
+    static __device__ __forceinline__ X lds_get(const uint4* buf, int TL, int lt) { return planes_get<P>(buf, (size_t)TL, (size_t)lt); }
+    static __device__ __forceinline__ Xyzz<P> sat(const X& v) { return v; }
+};
+template <class P>
+struct QuadRep<P, true> {
+    using X = Xyzz29<P>;
+    static constexpr int kPlanes = 9;
+    static __device__ __forceinline__ X identity() { return xyzz29_identity<P>(); }
+    static __device__ __forceinline__ X load(const uint4* seg, size_t stride, size_t idx, int ql) {
+        return xyzz29_from_sat_quad(planes_get<P>(seg, stride, idx), ql);
+    }
+    static __device__ __forceinline__ void add(X& a, const X& b, int ql) { xyzz29_add_quad(a, b, ql); }
+    static __device__ __forceinline__ X dbl(const X& a) { return xyzz29_dbl(a); }
+    static __device__ __forceinline__ X shfl_down(const X& a, int d) { return xyzz29_shfl_down(a, d); }
+    static __device__ __forceinline__ void lds_put(uint4* buf, int TL, int lt, const X& v) { raw29_put<P>(buf, (size_t)TL, (size_t)lt, buf + (size_t)8 * TL, v); }
+    static __device__ __forceinline__ X lds_get(const uint4* buf, int TL, int lt) { return raw29_get<P>(buf, (size_t)TL, (size_t)lt, buf + (size_t)8 * TL); }
+    static __device__ __forceinline__ Xyzz<P> sat(const X& v) { return xyzz29_to_sat_fast(v); }
+};
+
+template <class C, bool U>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) k_msm_reduce_quad(const uint4* __restrict__ buckets, int M, int nclass, size_t spv,
                                                          size_t aseg_mult, uint4* __restrict__ winsums, int form,
                                                          uint32_t* __restrict__ out_xyz) {
     using P = typename C::Base;
+    using Q = QuadRep<P, U>;
+    using X = typename Q::X;
     const int lane = threadIdx.x, ll = lane >> 2, ql = lane & 3;
     const size_t aseg = blockIdx.x / nclass, cls = blockIdx.x - aseg * nclass, MS = (size_t)M * nclass;
     const size_t segi = ((aseg / spv) * nclass + cls) * spv + aseg % spv;
     const uint4* seg = buckets + aseg * aseg_mult * MS * 8 + cls * M;
     const int L = M >> 4;  // host guarantees M >= 16, a power of two
 
-    Xyzz<P> S = xyzz_identity<P>(), W = xyzz_identity<P>();
+    X S = Q::identity(), W = Q::identity();
     for (int k = L; k >= 1; k--) {
-        const Xyzz<P> bkt = planes_get<P>(seg, MS, (size_t)(ll * L + k - 1));   // the four lanes of a quad read the same bucket
-        xyzz_add_quad(S, bkt, ql);
-        xyzz_add_quad(W, S, ql);
+        const X bkt = Q::load(seg, MS, (size_t)(ll * L + k - 1), ql);   // the four lanes of a quad read the same bucket
+        Q::add(S, bkt, ql);
+        Q::add(W, S, ql);
     }
-    Xyzz<P> suf = S;
+    X suf = S;
 #pragma unroll 1
     for (int d = 1; d < 16; d <<= 1) {
-        const Xyzz<P> o = xyzz_shfl_down(suf, 4 * d);
-        if (ll + d < 16) xyzz_add_quad(suf, o, ql);
+        const X o = Q::shfl_down(suf, 4 * d);
+        if (ll + d < 16) Q::add(suf, o, ql);
     }
     if (ll >= 1) {
-        for (int k = L; k > 1; k >>= 1) suf = xyzz_dbl_inl(suf);
-        xyzz_add_quad(W, suf, ql);
+        for (int k = L; k > 1; k >>= 1) suf = Q::dbl(suf);
+        Q::add(W, suf, ql);
     }
 #pragma unroll 1
     for (int d = 8; d >= 1; d >>= 1) {
-        const Xyzz<P> o = xyzz_shfl_down(W, 4 * d);
-        if (ll < d) xyzz_add_quad(W, o, ql);
+        const X o = Q::shfl_down(W, 4 * d);
+        if (ll < d) Q::add(W, o, ql);
     }
-    if (lane == 0) reduce_emit<P>(W, winsums, (size_t)gridDim.x, segi, form, out_xyz);
+    if (lane == 0) reduce_emit<P>(Q::sat(W), winsums, (size_t)gridDim.x, segi, form, out_xyz);
 }
 
 // The same with a whole workgroup: 256 threads = 64 logical lanes (lt = tid / 4), L = M/64 buckets each; the suffix scan and
-// the final tree run over LDS planes written by lane 0 of every quad (2 * T_l * 128 B of dynamic LDS): 2L + 12 quad additions.
+// the final tree run over LDS planes written by lane 0 of every quad (2 * T_l * kPlanes * 16 B of dynamic LDS): 2L + 12 quad additions.
 template <class P>
 __device__ __forceinline__ Xyzz<P> block_tree_sum_quad(Xyzz<P> v, uint4* buf, int TL, int lt, int ql) {
     for (int s = TL >> 1; s >= 1; s >>= 1) {
@@ -791,46 +828,61 @@ __device__ __forceinline__ Xyzz<P> block_tree_sum_quad(Xyzz<P> v, uint4* buf, in
     }
     return v;  // valid in logical lane 0
 }
-template <class C>
+template <class Q>
+__device__ __forceinline__ typename Q::X block_tree_sum_quad_rep(typename Q::X v, uint4* buf, int TL, int lt, int ql) {
+    for (int s = TL >> 1; s >= 1; s >>= 1) {
+        __syncthreads();
+        if (lt >= s && lt < 2 * s && ql == 0) Q::lds_put(buf, TL, lt, v);
+        __syncthreads();
+        if (lt < s) {
+            const typename Q::X o = Q::lds_get(buf, TL, lt + s);
+            Q::add(v, o, ql);
+        }
+    }
+    return v;  // valid in logical lane 0
+}
+template <class C, bool U>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) k_msm_reduce_quad_wg(
     const uint4* __restrict__ buckets, int M, int nclass, size_t spv, size_t aseg_mult, uint4* __restrict__ winsums, int form,
     uint32_t* __restrict__ out_xyz) {
     using P = typename C::Base;
+    using Q = QuadRep<P, U>;
+    using X = typename Q::X;
     extern __shared__ __align__(16) uint32_t lds[];
     const int tid = threadIdx.x, lt = tid >> 2, ql = tid & 3, TL = blockDim.x >> 2;
     uint4* bufA = reinterpret_cast<uint4*>(lds);
-    uint4* bufB = bufA + (size_t)TL * 8;
+    uint4* bufB = bufA + (size_t)TL * Q::kPlanes;
     const size_t aseg = blockIdx.x / nclass, cls = blockIdx.x - aseg * nclass, MS = (size_t)M * nclass;
     const size_t segi = ((aseg / spv) * nclass + cls) * spv + aseg % spv;
     const uint4* seg = buckets + aseg * aseg_mult * MS * 8 + cls * M;
     const int L = M / TL;  // host guarantees TL <= M, both powers of two
 
-    Xyzz<P> S = xyzz_identity<P>(), W = xyzz_identity<P>();
+    X S = Q::identity(), W = Q::identity();
     for (int k = L; k >= 1; k--) {
-        const Xyzz<P> bkt = planes_get<P>(seg, MS, (size_t)(lt * L + k - 1));
-        xyzz_add_quad(S, bkt, ql);
-        xyzz_add_quad(W, S, ql);
+        const X bkt = Q::load(seg, MS, (size_t)(lt * L + k - 1), ql);
+        Q::add(S, bkt, ql);
+        Q::add(W, S, ql);
     }
-    Xyzz<P> suf = S;
+    X suf = S;
     uint4* cur = bufA;
     uint4* nxt = bufB;
     for (int d = 1; d < TL; d <<= 1) {
-        if (ql == 0) planes_put(cur, (size_t)TL, (size_t)lt, suf);
+        if (ql == 0) Q::lds_put(cur, TL, lt, suf);
         __syncthreads();
         if (lt + d < TL) {
-            const Xyzz<P> o = planes_get<P>(cur, (size_t)TL, (size_t)(lt + d));
-            xyzz_add_quad(suf, o, ql);
+            const X o = Q::lds_get(cur, TL, lt + d);
+            Q::add(suf, o, ql);
         }
         uint4* tmp = cur;
         cur = nxt;
         nxt = tmp;
     }
     if (lt >= 1) {
-        for (int k = L; k > 1; k >>= 1) suf = xyzz_dbl_inl(suf);
-        xyzz_add_quad(W, suf, ql);
+        for (int k = L; k > 1; k >>= 1) suf = Q::dbl(suf);
+        Q::add(W, suf, ql);
     }
-    const Xyzz<P> lo = block_tree_sum_quad(W, bufA, TL, lt, ql);
-    if (tid == 0) reduce_emit<P>(lo, winsums, (size_t)gridDim.x, segi, form, out_xyz);
+    const X lo = block_tree_sum_quad_rep<Q>(W, bufA, TL, lt, ql);
+    if (tid == 0) reduce_emit<P>(Q::sat(lo), winsums, (size_t)gridDim.x, segi, form, out_xyz);
 }
 
 // k_msm_finalize in latency mode: per window the chunk results are summed by 64 logical lanes (quads of a 256-thread
@@ -1549,12 +1601,27 @@ static int msm_run_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_sca
             // latency mode: fewer reduction waves than SIMDs -- the dependent chain, not the work, is the cost: four lanes per addition
             static const bool no_quad = getenv("BZH_MSM_NO_QUAD") != nullptr;
             latency = !no_quad && p.M >= 16 && rseg * nclass <= 1024;
+            // (the quad reductions in unsaturated limbs on the Pasta curves; BZH_ACC_SATURATED=1: saturated like everything else)
+            constexpr bool red29 = fe29_supported<typename C::Base>();
+            const bool use_red29 = red29 && !acc_sat_env;
             if (latency && p.M >= 64 && rseg * nclass <= 256) {   // 256 workgroups of four waves: one wave per SIMD
-                hipLaunchKernelGGL((k_msm_reduce_quad_wg<C>), dim3((unsigned)(rseg * nclass)), dim3(256), (size_t)2 * 64 * 128, ctx->stream,
-                                   (const uint4*)d_buckets, p.M, nclass, rspv, mult, (uint4*)d_winsums, form, fout);
+                if constexpr (red29) {
+                    if (use_red29)
+                        hipLaunchKernelGGL((k_msm_reduce_quad_wg<C, true>), dim3((unsigned)(rseg * nclass)), dim3(256), (size_t)2 * 64 * 144, ctx->stream,
+                                           (const uint4*)d_buckets, p.M, nclass, rspv, mult, (uint4*)d_winsums, form, fout);
+                }
+                if (!use_red29)
+                    hipLaunchKernelGGL((k_msm_reduce_quad_wg<C, false>), dim3((unsigned)(rseg * nclass)), dim3(256), (size_t)2 * 64 * 128, ctx->stream,
+                                       (const uint4*)d_buckets, p.M, nclass, rspv, mult, (uint4*)d_winsums, form, fout);
             } else if (latency) {
-                hipLaunchKernelGGL((k_msm_reduce_quad<C>), dim3((unsigned)(rseg * nclass)), dim3(64), 0, ctx->stream,
-                                   (const uint4*)d_buckets, p.M, nclass, rspv, mult, (uint4*)d_winsums, form, fout);
+                if constexpr (red29) {
+                    if (use_red29)
+                        hipLaunchKernelGGL((k_msm_reduce_quad<C, true>), dim3((unsigned)(rseg * nclass)), dim3(64), 0, ctx->stream,
+                                           (const uint4*)d_buckets, p.M, nclass, rspv, mult, (uint4*)d_winsums, form, fout);
+                }
+                if (!use_red29)
+                    hipLaunchKernelGGL((k_msm_reduce_quad<C, false>), dim3((unsigned)(rseg * nclass)), dim3(64), 0, ctx->stream,
+                                       (const uint4*)d_buckets, p.M, nclass, rspv, mult, (uint4*)d_winsums, form, fout);
             } else if (p.M >= 64 && rseg * nclass >= 256) {
                 hipLaunchKernelGGL((k_msm_reduce_wave<C>), dim3((unsigned)(rseg * nclass)), dim3(64), 0, ctx->stream,
                                    (const uint4*)d_buckets, p.M, nclass, rspv, mult, (uint4*)d_winsums, form, fout);

@@ -128,6 +128,35 @@ static bool check(const char* name) {
                 expect(fe_eq(s1.x, s2.x) && fe_eq(s1.y, s2.y) && fe_eq(s1.zz, s2.zz) && fe_eq(s1.zzz, s2.zzz), "to_sat_fast == to_sat");
             }
         }
+        {   // full additions and doublings against the saturated code, incl. acc == q and acc == -q
+            Xyzz<P> r2 = xyzz_identity<P>(), other = xyzz_identity<P>();
+            Xyzz29<P> a2 = xyzz29_identity<P>(), o2 = xyzz29_identity<P>();
+            for (int i = 0; i < 12; i++) {
+                xyzz_madd(other, pts[(trial * 5 + i) % pts.size()]);
+                xyzz29_madd(o2, pts[(trial * 5 + i) % pts.size()], k);
+                xyzz_add(r2, other);
+                xyzz29_add(a2, o2);
+                if (i % 3 == 2) {
+                    r2 = xyzz_dbl(r2);
+                    a2 = xyzz29_dbl(a2);
+                }
+                const Affine<P> a = xyzz_to_affine(r2), b = xyzz_to_affine(xyzz29_to_sat_fast(a2));
+                expect(fe_eq(a.x, b.x) && fe_eq(a.y, b.y), "full-addition / doubling chain");
+            }
+            Xyzz<P> same = r2;
+            Xyzz29<P> same29 = a2;
+            xyzz_add(same, r2);
+            xyzz29_add(same29, a2);                                   // acc == q: the doubling case
+            const Affine<P> d1 = xyzz_to_affine(same), d2 = xyzz_to_affine(xyzz29_to_sat_fast(same29));
+            expect(fe_eq(d1.x, d2.x) && fe_eq(d1.y, d2.y), "addition of equal points");
+            Xyzz29<P> neg = a2;
+            neg.y = fe29_sub<P, 8>(fe29_zero<P>(), a2.y);
+            neg.y = fe29_fold(neg.y);
+            xyzz29_add(neg, a2);                                      // acc == -q
+            expect(neg.id, "addition of opposite points gives the identity");
+            for (int j = 0; j < 8; j++) expect(a2.x.l[j] < (1u << 29) + 8u && a2.y.l[j] < (1u << 29) + 8u, "sum limb bound");
+            expect(a2.x.l[8] < (12u << 22) && a2.y.l[8] < (8u << 22) && a2.zz.l[8] <= (2u << 22), "sum value bound");
+        }
         // invariants of the representation
         if (!acc.id) {
             for (int j = 0; j < 8; j++) expect(acc.x.l[j] < (1u << 29) + 8u && acc.y.l[j] < (1u << 29) + 8u, "accumulator limb bound");
