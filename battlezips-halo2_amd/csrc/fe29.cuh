@@ -172,6 +172,18 @@ BZH_HD Fe29<P> fe29_sub(const Fe29<P>& a, const Fe29<P>& b) {
     for (int i = 0; i < 9; i++) r.l[i] = a.l[i] + (fe29_bias<P, K>(i) - b.l[i]);
     return fe29_carry(r);
 }
+// a - b + K p WITHOUT the carry pass, the bias written as J copies of (K / J) p: b's limbs 0..7 may be anything up to
+// J (2^30 - 2) and its top limb up to K 2^22 - 2 J; the result's limbs grow by up to J (2^30 + 2^29) over a's.  For callers that
+// track limb bounds themselves (the quotient generator, quotient_program.hpp: a carry pass only where a product or a
+// subtrahend needs it).
+template <class P, int K, int J>
+BZH_HD Fe29<P> fe29_sub_lazy(const Fe29<P>& a, const Fe29<P>& b) {
+    static_assert(J >= 1 && K % J == 0, "fe29_sub_lazy: K p is written as J copies of (K / J) p");
+    Fe29<P> r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = a.l[i] + ((uint32_t)J * fe29_bias<P, K / J>(i) - b.l[i]);
+    return r;
+}
 // a - b - c - c + K p (the x3 of the mixed addition: R^2 - PPP - 2 Q), carried.  K p must dominate b + 2 c limb-wise: every bias
 // limb is ~2^30 + digit, so b, c are taken in carried form (limbs < 2^29 + 8) and the bias is used TWICE (2 K p).
 template <class P, int K>

@@ -347,14 +347,22 @@ static std::string program2_source(const Program2& pg, int field, bool builtin =
 }
 
 // The same program over UNSATURATED limbs (csrc/fe29.cuh): values are 9 x 29-bit limbs in R' = 2^261 Montgomery form, not kept
-// canonical; every value the kernel holds has carried limbs (< 2^29 + 8) and a statically known bound in multiples of p, tracked
-// HERE while the straight-line code is emitted: leaves and constants arrive below 2 p, a product leaves its result below 2 p,
-// a + b adds the bounds, a - b adds K p with K the power of two that dominates b's bound (fe29_sub<P, K>), and an operand is
-// folded back below 2 p (fe29_fold, ~45 instructions) whenever a product's operand bounds would multiply past 100 or a sum would
-// pass 100 (the representation holds 128 p).  Columns are fe29 planes (fe29_load_planes), constants 12 words apart; the result is
+// canonical.  For every value the emitter tracks, while it writes the straight-line code, a bound V in multiples of p and bounds
+// L, T on the limbs 0..7 and on limb 8:
+//   leaves / constants  carried, V = 2;   a product  V = 2, limbs < 2^29;
+//   a + b   limb-wise, NO carry pass (V, L, T add);   a - b   a + K p - b limb-wise, no carry pass either (fe29_sub_lazy: K p written
+//   as J copies of (K / J) p so that it dominates b limb by limb; V grows by K, L by J 1.5 2^30);
+//   a carry pass (fe29_carry, ~25 instructions) only where a consumer needs it: a product whose operands' limb bounds multiply past
+//   1.8e18 (a column of the schoolbook product is 9 such terms + 4 reduction terms of 2^58 in one 64-bit accumulator), a sum or
+//   difference that would pass 2^32, a subtrahend above 2 (2^30 - 2), a value parked in a shared-subexpression slot;
+//   a fold below 2 p (fe29_fold, ~45 instructions) where bounds would multiply past 100 or add past 100 (the limbs hold 128 p).
+// Board: 598 carry passes (one per + and -, the first version) -> 234.  A bound the emitter cannot establish fails the generation
+// (empty source), never the arithmetic.  Columns are fe29 planes (fe29_load_planes), constants 12 words apart; the result is
 // converted back to the saturated form by fe29_to_sat_div32 as it is stored, so h is what the saturated kernel writes, bit for bit.
-static std::string program2_source29(const Program2& pg, int field) {
+static std::string program2_source29_policy(const Program2& pg, int field, bool carry_at_store, int* passes) {
     std::string src;
+    int npass = 0;          // carry passes + folds emitted (what the two store policies are compared by)
+    bool pg_fail = false;   // a bound the emitter could not establish: no source (the saturated kernel is then the only flavour)
     char buf[640];
     auto add = [&](const char* fmt, auto... a) {
         snprintf(buf, sizeof(buf), fmt, a...);
@@ -383,8 +391,18 @@ static std::string program2_source29(const Program2& pg, int field) {
            "    Fe29<P> r0 = fe29_zero<P>(), r1 = r0, r2 = r0, r3 = r0;\n";
     const int nslots = std::max(pg.nlds, 1);
     for (int i = 0; i < nslots; i++) add("    Fe29<P> s%d = r0;\n", i);
-    std::vector<double> bs((size_t)nslots, 0.0);
-    double br[4] = {0, 0, 0, 0};
+    // what is known about a value: V (its bound in multiples of p), L (limbs 0..7 at most L), T (limb 8 at most T)
+    struct Bnd {
+        double V;
+        uint64_t L, T;
+    };
+    static const bool eager = getenv("BZH_QUOTIENT29_EAGER_CARRY") != nullptr;   // (measurement: the carry pass after every + and -)
+    constexpr uint64_t kCarried = ((uint64_t)1 << 29) + 8;                          // fe29_carry's output: limbs 0..7 below this
+    constexpr uint64_t kBiasLimb = ((uint64_t)1 << 30) + ((uint64_t)1 << 29);       // a limb of a bias K p stays below this
+    constexpr double kColumn = 1.8e18;                                              // A * B of a product's limb bounds (header)
+    const Bnd zero{0.0, 0, 0}, leaf{2.0, kCarried, ((uint64_t)1 << 23) + 16}, product{2.0, ((uint64_t)1 << 29) - 1, (uint64_t)1 << 23};   // (a product is below 1.8 p: limb 8 < 2^23)
+    std::vector<Bnd> bs((size_t)nslots, zero);
+    Bnd br[4] = {zero, zero, zero, zero};
     const size_t nops = pg.ops.size();
     auto is_mem = [](int kind) { return kind == BZH_EXPR_COLUMN || kind == BZH_EXPR_CONST; };
     auto emit_load = [&](const char* name, size_t i, int kind, int idx, int rot) {
@@ -402,73 +420,113 @@ static std::string program2_source29(const Program2& pg, int field) {
     };
     struct Val {
         std::string name;
-        double bound;
-        bool mem;   // a freshly loaded leaf (const Fe29: cannot be folded in place)
+        Bnd b;
+        bool mem;   // a freshly loaded leaf (const Fe29, carried, below 2 p: never needs a carry pass or a fold)
     };
     auto operand = [&](const char* name, size_t i, int kind, int idx) -> Val {
         char t[32];
         if (is_mem(kind)) {
             snprintf(t, sizeof(t), "%s%zu", name, i);
-            return Val{t, 2.0, true};
+            return Val{t, leaf, true};
         }
         snprintf(t, sizeof(t), "s%d", idx);
         return Val{t, bs[(size_t)idx], false};
     };
-    int ntmp = 0;
-    // bring an operand below 2 p
-    auto fold = [&](Val& x) {
-        if (x.bound <= 2.0) return;
-        if (x.mem) {
-            char t[32];
-            snprintf(t, sizeof(t), "f%d", ntmp++);
-            add("    const Fe29<P> %s = fe29_fold(%s);\n", t, x.name.c_str());
-            x.name = t;
-        } else {
-            add("    %s = fe29_fold(%s);\n", x.name.c_str(), x.name.c_str());
-            // the variable itself is now small: remember it
-            if (x.name[0] == 'r') br[x.name[1] - '0'] = 2.0;
-            else if (x.name[0] == 's') bs[(size_t)atoi(x.name.c_str() + 1)] = 2.0;
+    // what the kernel's variable `name` is known to be, after an in-place carry / fold
+    auto remember = [&](const Val& x) {
+        if (x.mem) return;
+        if (x.name[0] == 'r') br[x.name[1] - '0'] = x.b;
+        else if (x.name[0] == 's') bs[(size_t)atoi(x.name.c_str() + 1)] = x.b;
+    };
+    auto carry = [&](Val& x) {
+        if (x.b.L <= kCarried) return;
+        if (x.mem) {   // (cannot happen: leaves arrive carried)
+            pg_fail = true;
+            return;
         }
-        x.bound = 2.0;
+        add("    %s = fe29_carry(%s);\n", x.name.c_str(), x.name.c_str());
+        npass++;
+        x.b.T += x.b.L >> 29;
+        x.b.L = (((uint64_t)1 << 29) - 1) + (x.b.L >> 29);
+        remember(x);
+    };
+    // bring an operand below 2 p (fe29_fold takes a carried value)
+    auto fold = [&](Val& x) {
+        if (x.b.V <= 2.0) return;
+        if (x.mem) {
+            pg_fail = true;
+            return;
+        }
+        carry(x);
+        add("    %s = fe29_fold(%s);\n", x.name.c_str(), x.name.c_str());
+        npass += 2;
+        x.b = Bnd{2.0, kCarried, ((uint64_t)1 << 23) + 16};
+        remember(x);
     };
     auto pow2_over = [](double b) {
         int k = 4;
         while ((double)k < b + 1.0) k *= 2;
         return k;
     };
-    // dst = a (op) b with bounds; returns the bound of dst
-    auto arith = [&](int op, const std::string& dst, Val a, Val b) -> double {
+    auto limb_max = [](const Bnd& b) { return (double)std::max(b.L, b.T); };
+    // dst = a (op) b; returns what dst then is.  When a and b name the same variable (a square) every in-place change of one is
+    // a change of the other: `same` keeps the two descriptions equal.
+    auto arith = [&](int op, const std::string& dst, Val a, Val b) -> Bnd {
         if (op == V2_RSUB) {   // b - a
             std::swap(a, b);
             op = V2_SUB;
         }
+        const bool same = !a.mem && !b.mem && a.name == b.name;
+        auto sync = [&](Val& from, Val& to) {
+            if (same) to.b = from.b;
+        };
         if (op == V2_MUL) {
-            if (a.bound * b.bound > 100.0) {
-                if (a.bound >= b.bound) fold(a);
-                else fold(b);
+            for (int pass = 0; pass < 2 && a.b.V * b.b.V > 100.0; pass++) {
+                if (a.b.V >= b.b.V) fold(a), sync(a, b);
+                else fold(b), sync(b, a);
             }
-            if (a.bound * b.bound > 100.0) {
-                fold(a);
-                fold(b);
+            for (int pass = 0; pass < 2 && limb_max(a.b) * limb_max(b.b) > kColumn; pass++) {
+                if (a.b.L >= b.b.L) carry(a), sync(a, b);
+                else carry(b), sync(b, a);
             }
+            if (a.b.V * b.b.V > 100.0 || limb_max(a.b) * limb_max(b.b) > kColumn) pg_fail = true;
             add("    %s = mulx(%s, %s);\n", dst.c_str(), a.name.c_str(), b.name.c_str());
-            return 2.0;
+            return product;
         }
         if (op == V2_ADD) {
-            if (a.bound + b.bound > 100.0) {
-                if (a.bound >= b.bound) fold(a);
-                else fold(b);
+            for (int pass = 0; pass < 2 && a.b.V + b.b.V > 100.0; pass++) {
+                if (a.b.V >= b.b.V) fold(a), sync(a, b);
+                else fold(b), sync(b, a);
             }
-            if (a.bound + b.bound > 100.0) fold(a.bound >= b.bound ? a : b);
-            add("    %s = fe29_add_c(%s, %s);\n", dst.c_str(), a.name.c_str(), b.name.c_str());
-            return a.bound + b.bound;
+            for (int pass = 0; pass < 2 && a.b.L + b.b.L > 0xffffffffull; pass++) {
+                if (a.b.L >= b.b.L) carry(a), sync(a, b);
+                else carry(b), sync(b, a);
+            }
+            if (a.b.V + b.b.V > 100.0 || a.b.L + b.b.L > 0xffffffffull) pg_fail = true;
+            const Bnd sum{a.b.V + b.b.V, a.b.L + b.b.L, a.b.T + b.b.T};
+            if (eager) {
+                add("    %s = fe29_add_c(%s, %s);\n", dst.c_str(), a.name.c_str(), b.name.c_str());
+                return Bnd{sum.V, (((uint64_t)1 << 29) - 1) + (sum.L >> 29), sum.T + (sum.L >> 29)};
+            }
+            add("    %s = fe29_add(%s, %s);\n", dst.c_str(), a.name.c_str(), b.name.c_str());
+            return sum;
         }
-        // a - b
-        if (b.bound > 60.0) fold(b);
-        int K = pow2_over(b.bound);
-        if (a.bound + K > 100.0) fold(a);
-        add("    %s = fe29_sub<P, %d>(%s, %s);\n", dst.c_str(), K, a.name.c_str(), b.name.c_str());
-        return a.bound + K;
+        // a - b: the bias K p = J copies of (K / J) p has to dominate b limb by limb
+        if (b.b.V > 60.0) fold(b), sync(b, a);
+        if (b.b.L > 2 * (((uint64_t)1 << 30) - 2) || eager) carry(b), sync(b, a);
+        const int J = b.b.L > ((uint64_t)1 << 30) - 2 ? 2 : 1;
+        int K = pow2_over(b.b.V);
+        while ((uint64_t)K * ((uint64_t)1 << 22) < b.b.T + 2 * (uint64_t)J) K *= 2;
+        if (a.b.V + K > 100.0) fold(a), sync(a, b);
+        if (a.b.L + (uint64_t)J * kBiasLimb > 0xffffffffull) carry(a), sync(a, b);
+        if (same || a.b.V + K > 100.0 || K > 64 || a.b.L + (uint64_t)J * kBiasLimb > 0xffffffffull) pg_fail = true;   // (x - x is never emitted)
+        const Bnd diff{a.b.V + K, a.b.L + (uint64_t)J * kBiasLimb, a.b.T + (uint64_t)K * ((uint64_t)1 << 22) + (uint64_t)K};
+        if (eager) {
+            add("    %s = fe29_sub<P, %d>(%s, %s);\n", dst.c_str(), K, a.name.c_str(), b.name.c_str());
+            return Bnd{diff.V, (((uint64_t)1 << 29) - 1) + (diff.L >> 29), diff.T + (diff.L >> 29)};
+        }
+        add("    %s = fe29_sub_lazy<P, %d, %d>(%s, %s);\n", dst.c_str(), K, J, a.name.c_str(), b.name.c_str());
+        return diff;
     };
     static const char* const regs[4] = {"r0", "r1", "r2", "r3"};
     emit_loads(0);
@@ -484,26 +542,37 @@ static std::string program2_source29(const Program2& pg, int field) {
         } else if (form == V2_LL) {
             br[pos] = arith(op, ra, operand("la", i, o.a_kind, o.a_idx), operand("lb", i, o.b_kind, o.b_idx));
         } else if (op == V2_NEG) {
-            Val a{ra, br[pos], false};
-            if (a.bound > 60.0) fold(a);
-            const int K = pow2_over(a.bound);
-            add("    %s = fe29_sub<P, %d>(fe29_zero<P>(), %s);\n", ra.c_str(), K, ra.c_str());
-            br[pos] = (double)K;
+            src += "    { const Fe29<P> z = fe29_zero<P>();\n";
+            const Bnd d = arith(V2_SUB, ra, Val{"z", zero, true}, Val{ra, br[pos], false});
+            src += "    }\n";
+            br[pos] = d;
         } else if (op == V2_LOAD) {
             const Val a = operand("la", i, o.a_kind, o.a_idx);
             src += "    " + ra + " = " + a.name + ";\n";
-            br[pos] = a.bound;
+            br[pos] = a.b;
         } else {
+            // a value kept for later uses: carried once here rather than once per copy (policy; the cheaper one is kept)
+            Val x{ra, br[pos], false};
+            if (carry_at_store) carry(x);
             add("    s%d = %s;\n", o.a_idx, ra.c_str());
             bs[(size_t)o.a_idx] = br[pos];
         }
         src += "    __builtin_amdgcn_sched_barrier(0);\n";
     }
+    if (br[0].L > 0xfffffff0ull || br[0].V > 120.0) pg_fail = true;
+    if (pg_fail) return std::string();
+    *passes = npass;
     src += "    fe_store(out + (v * size + r) * 8, fe29_to_sat_div32(r0));\n}\n";
     add("static void launch(unsigned gx, unsigned gy, void* st, const uint32_t* const* cols, const size_t* strides, const uint32_t* consts, "
         "size_t nc, size_t size, uint32_t* out) {\n    hipLaunchKernelGGL(%s, dim3(gx, gy), dim3(128), 0, (hipStream_t)st, cols, strides, consts, nc, size, out);\n}\n", kname);
     add("}  // namespace bzh_q29_%016llx\n", hash);
     return src;
+}
+static std::string program2_source29(const Program2& pg, int field) {
+    int pa = 0, pb = 0;
+    const std::string a = program2_source29_policy(pg, field, true, &pa), b = program2_source29_policy(pg, field, false, &pb);
+    if (a.empty() || b.empty()) return a.empty() ? b : a;
+    return pb < pa ? b : a;
 }
 
 struct Compiler2 {
