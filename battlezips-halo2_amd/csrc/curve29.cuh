@@ -216,6 +216,44 @@ BZH_HD void xyzz29_add(Xyzz29<P>& acc, const Xyzz29<P>& q) {
     acc.zzz = fe29_mul(fe29_mul(acc.zzz, q.zzz), ppp);
 }
 
+// acc += q with the equal-x cases INLINE through the saturated addition (no call: a callee's registers count towards its
+// kernel's, and xyzz29_add_special's 250 would halve k_msm_chunksum's occupancy).  Whatever the filter lets through -- equal
+// points, opposite points, or the 3-in-2^29 coincidence -- takes the saturated path, which handles every case; the limbs are
+// made opaque inside the branch so that none of its work is hoisted above the test.
+template <class P>
+BZH_HD void xyzz29_add_nocall(Xyzz29<P>& acc, const Xyzz29<P>& q) {
+    if (q.id) return;
+    if (acc.id) {
+        acc = q;
+        return;
+    }
+    const Fe29<P> u1 = fe29_mul(acc.x, q.zz), u2 = fe29_mul(q.x, acc.zz);
+    const Fe29<P> s1 = fe29_mul(acc.y, q.zzz), s2 = fe29_mul(q.y, acc.zzz);
+    const Fe29<P> pp_ = fe29_sub<P, 4>(u2, u1), r = fe29_sub<P, 4>(s2, s1);
+    if (__builtin_expect(pp_.l[0] - 3u <= 2u, 0)) {
+        Xyzz29<P> a = acc, b = q;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            asm volatile("" : "+v"(a.x.l[i]), "+v"(a.y.l[i]), "+v"(a.zz.l[i]), "+v"(a.zzz.l[i]));
+            asm volatile("" : "+v"(b.x.l[i]), "+v"(b.y.l[i]), "+v"(b.zz.l[i]), "+v"(b.zzz.l[i]));
+        }
+#endif
+        Xyzz<P> sa = xyzz29_to_sat_fast(a);
+        xyzz_add_inl(sa, xyzz29_to_sat_fast(b));
+        acc.x = fe29_from_sat_reduced(sa.x), acc.y = fe29_from_sat_reduced(sa.y);
+        acc.zz = fe29_from_sat_reduced(sa.zz), acc.zzz = fe29_from_sat_reduced(sa.zzz);
+        acc.id = xyzz_is_id(sa);
+        return;
+    }
+    const Fe29<P> pp = fe29_sqr(pp_), ppp = fe29_mul(pp_, pp), qq = fe29_mul(u1, pp);
+    const Fe29<P> x3 = fe29_sub3<P, 4>(fe29_sqr(r), ppp, qq);
+    acc.y = fe29_sub<P, 4>(fe29_mul(r, fe29_sub<P, 16>(qq, x3)), fe29_mul(s1, ppp));
+    acc.x = x3;
+    acc.zz = fe29_mul(fe29_mul(acc.zz, q.zz), pp);
+    acc.zzz = fe29_mul(fe29_mul(acc.zzz, q.zzz), ppp);
+}
+
 // ---- the same addition with the FOUR lanes of a quad on it (latency mode; see curve.cuh's xyzz_add_quad): every lane holds the same
 //      acc and q, multiplies ONE of the up to four independent products of each of the four dependency levels and receives the
 //      others by DPP quad broadcasts of the nine limbs.  4 products of 188 instructions per lane instead of 4 of 297.

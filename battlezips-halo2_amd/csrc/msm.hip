@@ -936,41 +936,76 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
 // chunks (next segment's load in flight during the addition), then two LDS combining steps: a dependent chain of
 // nchunks / 4 + 2 additions (~4.5 us each at this occupancy) instead of nchunks - 1.
 // ---------------------------------------------------------------------------
-template <class C>
+// The element the sums run on: the saturated XYZZ point, or (U) its unsaturated-limb form -- converted once per loaded bucket
+// (4 re-slices) and once per stored sum, 14 products of 188 instead of 297 instructions per addition in between.
+template <class P, bool U>
+struct SumRep;
+template <class P>
+struct SumRep<P, false> {
+    using X = Xyzz<P>;
+    static constexpr int kPlanes = 8;
+    static __device__ __forceinline__ X identity() { return xyzz_identity<P>(); }
+    static __device__ __forceinline__ X from_sat(const Xyzz<P>& v) { return v; }
+    static __device__ __forceinline__ void add(X& a, const X& b) { xyzz_add_inl(a, b); }
+    static __device__ __forceinline__ void lds_put(uint4* buf, int lane, const X& v) { planes_put(buf, (size_t)64, (size_t)lane, v); }
+    static __device__ __forceinline__ X lds_get(const uint4* buf, int lane) { return planes_get<P>(buf, (size_t)64, (size_t)lane); }
+    static __device__ __forceinline__ Xyzz<P> sat(const X& v) { return v; }
+};
+template <class P>
+struct SumRep<P, true> {
+    using X = Xyzz29<P>;
+    static constexpr int kPlanes = 9;
+    static __device__ __forceinline__ X identity() { return xyzz29_identity<P>(); }
+    static __device__ __forceinline__ X from_sat(const Xyzz<P>& v) {   // (re-slice + fold per coordinate, no product)
+        X r;
+        r.x = fe29_from_sat_reduced(v.x), r.y = fe29_from_sat_reduced(v.y), r.zz = fe29_from_sat_reduced(v.zz), r.zzz = fe29_from_sat_reduced(v.zzz);
+        r.id = xyzz_is_id(v);
+        return r;
+    }
+    static __device__ __forceinline__ void add(X& a, const X& b) { xyzz29_add_nocall(a, b); }
+    static __device__ __forceinline__ void lds_put(uint4* buf, int lane, const X& v) { raw29_put<P>(buf, (size_t)64, (size_t)lane, buf + 8 * 64, v); }
+    static __device__ __forceinline__ X lds_get(const uint4* buf, int lane) { return raw29_get<P>(buf, (size_t)64, (size_t)lane, buf + 8 * 64); }
+    static __device__ __forceinline__ Xyzz<P> sat(const X& v) { return xyzz29_to_sat_fast(v); }
+};
+template <class C, bool U>
 __global__ void __launch_bounds__(256) k_msm_chunksum(uint4* __restrict__ buckets, int MS, size_t nchunks) {
     using P = typename C::Base;
-    __shared__ __align__(16) uint4 part[3 * 64 * 8];  // partial sums of waves 1..3, plane layout (stride 64)
+    using R = SumRep<P, U>;
+    using X = typename R::X;
+    constexpr int KP = R::kPlanes;
+    __shared__ __align__(16) uint4 part[3 * 64 * KP];  // partial sums of waves 1..3, plane layout (stride 64)
     const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
     const size_t m = blockIdx.x * (size_t)64 + lane, v = blockIdx.y;
     const bool live = m < (size_t)MS;
     uint4* seg0 = buckets + v * nchunks * (size_t)MS * 8;
     // wave q sums chunks [c0, c1)
     const size_t per = (nchunks + 3) / 4, c0 = min((size_t)q * per, nchunks), c1 = min(c0 + per, nchunks);
-    Xyzz<P> acc = xyzz_identity<P>();
+    X acc = R::identity();
     if (live && c0 < c1) {
-        acc = planes_get<P>(seg0 + c0 * (size_t)MS * 8, (size_t)MS, m);
-        Xyzz<P> nxt = acc;
+        Xyzz<P> nxt = planes_get<P>(seg0 + c0 * (size_t)MS * 8, (size_t)MS, m);
+        acc = R::from_sat(nxt);
         if (c0 + 1 < c1) nxt = planes_get<P>(seg0 + (c0 + 1) * (size_t)MS * 8, (size_t)MS, m);
         for (size_t ck = c0 + 1; ck < c1; ck++) {
-            const Xyzz<P> o = nxt;
+            const X o = R::from_sat(nxt);
             if (ck + 1 < c1) nxt = planes_get<P>(seg0 + (ck + 1) * (size_t)MS * 8, (size_t)MS, m);
-            xyzz_add_inl(acc, o);
+            R::add(acc, o);
         }
     }
-    if (q) planes_put(part + (size_t)(q - 1) * 64 * 8, (size_t)64, (size_t)lane, acc);
-    __syncthreads();
-    if (q == 0 || q == 2) {  // 0 += 1, 2 += 3
-        const Xyzz<P> o = planes_get<P>(part + (size_t)q * 64 * 8, (size_t)64, (size_t)lane);
-        xyzz_add_inl(acc, o);
+    // waves 1..3 park their sums; 0 += 1 and 2 += 3, then 0 += 2 (ONE addition site in a two-step loop: three inlined copies of
+    // the unsaturated addition cost the kernel its second wave per SIMD)
+#pragma unroll 1
+    for (int step = 0; step < 2; step++) {
+        const bool put = step == 0 ? q != 0 : q == 2, take = step == 0 ? (q == 0 || q == 2) : q == 0;
+        const int put_slot = step == 0 ? q - 1 : 1, take_slot = step == 0 ? q : 1;
+        if (put) R::lds_put(part + (size_t)put_slot * 64 * KP, lane, acc);
+        __syncthreads();
+        if (take) {
+            const X o = R::lds_get(part + (size_t)take_slot * 64 * KP, lane);
+            R::add(acc, o);
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    if (q == 2) planes_put(part + (size_t)1 * 64 * 8, (size_t)64, (size_t)lane, acc);
-    __syncthreads();
-    if (q == 0) {
-        const Xyzz<P> o = planes_get<P>(part + (size_t)1 * 64 * 8, (size_t)64, (size_t)lane);
-        xyzz_add_inl(acc, o);
-        if (live) planes_put(seg0, (size_t)MS, m, acc);
-    }
+    if (q == 0 && live) planes_put(seg0, (size_t)MS, m, R::sat(acc));
 }
 
 // ---------------------------------------------------------------------------
@@ -1588,8 +1623,12 @@ static int msm_run_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_sca
                 rspv = 1;
             }
             if (presum) {
-                hipLaunchKernelGGL((k_msm_chunksum<C>), dim3((unsigned)((M_acc + 63) / 64), (unsigned)nb), dim3(256), 0, ctx->stream,
-                                   (uint4*)d_buckets, M_acc, p.nchunks);
+                if (fe29_supported<typename C::Base>() && !acc_sat_env)
+                    hipLaunchKernelGGL((k_msm_chunksum<C, fe29_supported<typename C::Base>()>), dim3((unsigned)((M_acc + 63) / 64), (unsigned)nb), dim3(256), 0,
+                                       ctx->stream, (uint4*)d_buckets, M_acc, p.nchunks);
+                else
+                    hipLaunchKernelGGL((k_msm_chunksum<C, false>), dim3((unsigned)((M_acc + 63) / 64), (unsigned)nb), dim3(256), 0, ctx->stream,
+                                       (uint4*)d_buckets, M_acc, p.nchunks);
                 rseg = nb;
                 rspv = 1;
                 mult = p.nchunks;

@@ -152,8 +152,26 @@ static bool check(const char* name) {
             Xyzz29<P> neg = a2;
             neg.y = fe29_sub<P, 8>(fe29_zero<P>(), a2.y);
             neg.y = fe29_fold(neg.y);
+            Xyzz29<P> neg_b = neg;
             xyzz29_add(neg, a2);                                      // acc == -q
             expect(neg.id, "addition of opposite points gives the identity");
+            // the call-free flavour (k_msm_chunksum): plain, equal and opposite operands
+            Xyzz29<P> n1 = a2, n2 = a2;
+            xyzz29_add_nocall(n1, o2);
+            xyzz29_add(n2, o2);
+            const Affine<P> e1 = xyzz_to_affine(xyzz29_to_sat_fast(n1)), e2 = xyzz_to_affine(xyzz29_to_sat_fast(n2));
+            expect(fe_eq(e1.x, e2.x) && fe_eq(e1.y, e2.y), "call-free addition == addition");
+            Xyzz29<P> n3 = a2;
+            xyzz29_add_nocall(n3, a2);
+            const Affine<P> e3 = xyzz_to_affine(xyzz29_to_sat_fast(n3));
+            expect(fe_eq(d1.x, e3.x) && fe_eq(d1.y, e3.y), "call-free addition of equal points");
+            xyzz29_add_nocall(neg_b, a2);
+            expect(neg_b.id, "call-free addition of opposite points gives the identity");
+            Xyzz29<P> n4 = xyzz29_identity<P>();
+            xyzz29_add_nocall(n4, a2);
+            xyzz29_add_nocall(n4, xyzz29_identity<P>());
+            const Affine<P> e4 = xyzz_to_affine(xyzz29_to_sat_fast(n4)), e5 = xyzz_to_affine(xyzz29_to_sat_fast(a2));
+            expect(fe_eq(e4.x, e5.x) && fe_eq(e4.y, e5.y), "call-free addition with the identity on either side");
             for (int j = 0; j < 8; j++) expect(a2.x.l[j] < (1u << 29) + 8u && a2.y.l[j] < (1u << 29) + 8u, "sum limb bound");
             expect(a2.x.l[8] < (12u << 22) && a2.y.l[8] < (8u << 22) && a2.zz.l[8] <= (2u << 22), "sum value bound");
         }
