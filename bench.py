@@ -498,7 +498,8 @@ class Workload:
             self.k = k
             kind = circuit if circuit != "auto" else ("shot" if k == 11 else "board")
             if k >= 16:
-                batch = min(batch, 8)   # 2^17-row tables: 8 proofs per batch already fill the GPU (and 21 GB of cosets per worker)
+                # 2^17-row tables: 8 proofs per batch already fill the GPU (and 21 GB of cosets per worker); BZH_BENCH_BIG_BATCH lifts the cap
+                batch = min(batch, int(os.environ.get("BZH_BENCH_BIG_BATCH", "8")))
             wb = window_bits or (8 if batch == 1 else 0)
             self.window_bits = wb
             self.runner = ProofRunner(kind, k, ctx, device, seed, batch=batch, workers=concurrency, window_bits=wb, first_ctx=ctx)
