@@ -448,6 +448,24 @@ __device__ __forceinline__ void fe29_store_planes(uint32_t* __restrict__ col, si
     reinterpret_cast<uint4*>(col + 4 * size)[idx] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
     col[8 * size + idx] = v.l[8];
 }
+// The same load through a GLOBAL-address-space pointer with a 32-bit element index (the quotient kernels: their column pointers
+// come out of a pointer table, so the compiler only knows them as generic -- flat_load with a 64-bit per-lane address, and a flat
+// access also counts on lgkmcnt, so every wait for a scalar load waited for the prefetched columns too).  Uniform base in SGPRs +
+// zero-extended 32-bit lane offset is the global_load saddr form: no per-lane 64-bit address arithmetic.  size * 16 < 2^32.
+#define BZH_AS1 __attribute__((address_space(1)))
+typedef const char BZH_AS1* fe29_gbytes;
+typedef uint32_t fe29_u32x4 __attribute__((ext_vector_type(4)));
+template <class P>
+__device__ __forceinline__ Fe29<P> fe29_load_planes_g(fe29_gbytes col, uint32_t idx, size_t size) {
+    const uint32_t off16 = idx << 4, off4 = idx << 2;
+    const fe29_u32x4 a = *(const fe29_u32x4 BZH_AS1*)(col + off16);
+    const fe29_u32x4 b = *(const fe29_u32x4 BZH_AS1*)(col + 16 * size + off16);
+    Fe29<P> r;
+    r.l[0] = a.x, r.l[1] = a.y, r.l[2] = a.z, r.l[3] = a.w;
+    r.l[4] = b.x, r.l[5] = b.y, r.l[6] = b.z, r.l[7] = b.w;
+    r.l[8] = *(const uint32_t BZH_AS1*)(col + 32 * size + off4);
+    return r;
+}
 // An Fe29 across a CALL: a 36-byte struct goes through scratch memory (byval / sret), a 9-lane vector travels in VGPRs.
 typedef uint32_t fe29_vec __attribute__((ext_vector_type(9)));
 template <class P>

@@ -52,7 +52,7 @@ struct Prover {
         if constexpr (!fe29_supported<SF>()) return false;
         std::lock_guard<std::mutex> lk(pk.mu);
         return pk.q_ok && pk.q_builtin29 && pk.key29 && pk.q_select == BZH_QUOTIENT_BUILTIN && pk.en % 128 == 0 && pk.ek >= 12 &&
-               !getenv("BZH_QUOTIENT_V1");
+               pk.ek <= 27 /* 32-bit byte offsets into a plane (fe29_load_planes_g) */ && !getenv("BZH_QUOTIENT_V1");
     }();
     uint32_t* ext_alloc(size_t cols) { return q29 ? (uint32_t*)arena.alloc(cols * 9 * en * 4) : dalloc(cols * en); }
     int zero(uint32_t* p, size_t elems) {

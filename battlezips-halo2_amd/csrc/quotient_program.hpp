@@ -407,7 +407,7 @@ static std::string program2_source29_policy(const Program2& pg, int field, bool 
     auto is_mem = [](int kind) { return kind == BZH_EXPR_COLUMN || kind == BZH_EXPR_CONST; };
     auto emit_load = [&](const char* name, size_t i, int kind, int idx, int rot) {
         if (kind == BZH_EXPR_COLUMN)
-            add("    const Fe29<P> %s%zu = fe29_load_planes<P>(cols[%d] + v * strides[%d], (r + (size_t)(long)(%d)) & mask, size);\n", name, i, idx, idx, rot);
+            add("    const Fe29<P> %s%zu = fe29_load_planes_g<P>((fe29_gbytes)(cols[%d] + v * strides[%d]), (uint32_t)((r + (size_t)(long)(%d)) & mask), size);\n", name, i, idx, idx, rot);
         else if (kind == BZH_EXPR_CONST)
             add("    const Fe29<P> %s%zu = fe29_load_const<P>(cv + %d * 12);\n", name, i, idx);
     };

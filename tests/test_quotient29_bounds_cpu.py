@@ -71,7 +71,7 @@ def check_program(text, p):
         ln = ln.strip()
         if not ln or ln.startswith("//") or "sched_barrier" in ln or ln in ("}", "{"):
             continue
-        m = re.match(r"(?:const )?Fe29<P> (%s) = fe29_load_(planes|const)<P>\(" % ident, ln)
+        m = re.match(r"(?:const )?Fe29<P> (%s) = fe29_load_(planes_g|planes|const)<P>\(" % ident, ln)
         if m:
             env[m.group(1)] = LEAF
             continue
