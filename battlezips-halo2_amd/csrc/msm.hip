@@ -1643,7 +1643,14 @@ static int msm_run_t(bzh_ctx* ctx, const bzh_bases* bases, const uint32_t* d_sca
             // (the quad reductions in unsaturated limbs on the Pasta curves; BZH_ACC_SATURATED=1: saturated like everything else)
             constexpr bool red29 = fe29_supported<typename C::Base>();
             const bool use_red29 = red29 && !acc_sat_env;
-            if (latency && p.M >= 64 && rseg * nclass <= 256) {   // 256 workgroups of four waves: one wave per SIMD
+            // the workgroup flavour while its four-wave workgroups fit one or two per CU (a second wave per SIMD interleaves with the
+            // first one's dependent chain almost for free); beyond that one wave per segment
+            static const size_t wg_max = [] {
+                const char* e = getenv("BZH_RED_WG_MAX");   // tuning knob
+                const long v = e ? atol(e) : 512;
+                return (size_t)(v >= 0 ? v : 512);
+            }();
+            if (latency && p.M >= 64 && rseg * nclass <= wg_max) {
                 if constexpr (red29) {
                     if (use_red29)
                         hipLaunchKernelGGL((k_msm_reduce_quad_wg<C, true>), dim3((unsigned)(rseg * nclass)), dim3(256), (size_t)2 * 64 * 144, ctx->stream,
