@@ -27,6 +27,8 @@ SETTINGS = [
     {"BZH_ACC_SATURATED": "1"},                             # bucket accumulation in saturated 8 x 32 limbs (default: unsaturated 9 x 29, csrc/fe29.cuh)
     {"BZH_ACC_SATURATED": "1", "BZH_ACC_THREADS": "512", "BZH_ACC_CHUNK": "4096"},
     {"BZH_QUOTIENT_SATURATED": "1"},                        # the builtin quotient kernel in saturated limbs (default: its unsaturated-limb flavour)
+    {"BZH_RED_WG_MAX": "0"},                                # latency-mode reductions: one wave per segment everywhere
+    {"BZH_RED_WG_MAX": "4096"},                             # ... the workgroup flavour everywhere
     {"BZH_MSM_NO_QUAD": "1"},                               # bucket reductions without the four-lanes-per-addition latency mode
     {"BZH_ACC_NO_XCD_MAP": "1"},                            # accumulate workgroups in plain (vector, chunk) grid order
     {"BZH_NO_COMMIT_SHIFT": "1"},                           # grand products committed without taking their constant stretch out
@@ -41,7 +43,7 @@ SETTINGS = [
 def _digest(extra):
     env = dict(os.environ)
     for k in ("BZH_MSM_GS", "BZH_ACC_THREADS", "BZH_ACC_CHUNK", "BZH_QUOTIENT_V1", "BZH_NO_HOIST", "BZH_VM2_CSE", "BZH_QUOTIENT", "BZH_NTT_LDS",
-              "BZH_IPA_COLLAPSE", "BZH_IPA_TAIL_C", "BZH_NO_COMMIT_SHIFT", "BZH_MSM_NO_QUAD", "BZH_ACC_NO_XCD_MAP", "BZH_ACC_SATURATED", "BZH_QUOTIENT_SATURATED"):
+              "BZH_IPA_COLLAPSE", "BZH_IPA_TAIL_C", "BZH_NO_COMMIT_SHIFT", "BZH_MSM_NO_QUAD", "BZH_ACC_NO_XCD_MAP", "BZH_ACC_SATURATED", "BZH_QUOTIENT_SATURATED", "BZH_RED_WG_MAX"):
         env.pop(k, None)
     env.update(extra)
     out = subprocess.run([sys.executable, CASE], env=env, capture_output=True, text=True, timeout=600)
