@@ -381,7 +381,13 @@ static std::string program2_source29_policy(const Program2& pg, int field, bool 
            "__device__ __forceinline__ Fe29<P> mulx(const Fe29<P>& a, const Fe29<P>& b) { return fe29_unpack_vec<P>(mulv(fe29_pack_vec(a), fe29_pack_vec(b))); }\n";
     // (132 VGPRs, three waves per SIMD: forcing four with amdgpu_waves_per_eu(4, 4) -- 128 VGPRs, 3 spilled -- measured slower,
     // 34.2 against 33.4 ms per batch of 64)
-    add("extern \"C\" __global__ void __launch_bounds__(128) %s(const uint32_t* const* __restrict__ cols, ", kname);
+    // A scheduling barrier after every operation keeps the compiler from hoisting the column loads of the whole program to its top.
+    // BZH_QUOTIENT29_NO_BARRIERS=1 (generation time) drops them and caps the kernel at three waves' registers instead: LLVM then
+    // merges the program's repeated products (mulv is pure: Board 565 -> 426 calls) but spills ~1 900 words per row to scratch
+    // -- measured 30.2 vs 31.1 ms for Board and ShotCircuit's throughput -4 %: not the default.
+    static const bool barriers = getenv("BZH_QUOTIENT29_NO_BARRIERS") == nullptr;
+    add("extern \"C\" __global__ void __launch_bounds__(128) %s%s(const uint32_t* const* __restrict__ cols, ",
+        barriers ? "" : "__attribute__((amdgpu_waves_per_eu(3, 3))) ", kname);
     src += "const size_t* __restrict__ strides, const uint32_t* __restrict__ consts, size_t const_stride, size_t size, "
            "uint32_t* __restrict__ out) {\n"
            "    const size_t r = blockIdx.x * (size_t)128 + threadIdx.x, v = blockIdx.y;\n"
@@ -557,7 +563,7 @@ static std::string program2_source29_policy(const Program2& pg, int field, bool 
             add("    s%d = %s;\n", o.a_idx, ra.c_str());
             bs[(size_t)o.a_idx] = br[pos];
         }
-        src += "    __builtin_amdgcn_sched_barrier(0);\n";
+        if (barriers) src += "    __builtin_amdgcn_sched_barrier(0);\n";
     }
     if (br[0].L > 0xfffffff0ull || br[0].V > 120.0) pg_fail = true;
     if (pg_fail) return std::string();
@@ -582,7 +588,10 @@ struct Compiler2 {
     std::map<int, int> cse;              // node -> LDS slot holding its value (current scope)
     std::map<int, int> hoisted;          // node -> registry column holding its precomputed values (proof-independent)
     std::vector<int> label;              // Sethi-Ullman numbers (leaves 0), memoised per scope
-    int spill_used = 0, cse_slots = 2, max_lds = kV2LdsInner;   // measured (k = 14, batch 16): 2 shared-subexpression slots beat 0, 4, 6, 8 -- occupancy matters more than the last 40 multiplications
+    // shared-subexpression slots per gate group.  Round 2 measured 2 against 0, 4, 6, 8 on the INTERPRETER (slots are LDS there:
+    // occupancy mattered more than the last 40 multiplications); the builtin kernels hold them in registers and have room
+    // (130 -> 138 VGPRs of the 168 that three waves allow): 6 takes 41 more products out of the Board program (581 -> 540)
+    int spill_used = 0, cse_slots = 6, max_lds = kV2LdsInner;
     explicit Compiler2(const EPool& p) : pool(p), label(p.n.size(), -1) {
         if (const char* e = getenv("BZH_VM2_CSE")) cse_slots = std::max(0, std::min(kV2LdsCseMax, atoi(e)));
     }
