@@ -224,7 +224,7 @@ enum { BZH_EXPR_LDS = 3 };
 enum { V2_ADD = 0, V2_SUB = 1, V2_MUL = 2, V2_RSUB = 3 };
 enum { V2_SS = 0, V2_SL = 1, V2_LL = 2, V2_UN = 3, V2_NEG = 0, V2_LOAD = 1, V2_STORE = 2 };
 // LDS slots: 0 ACC, 1 IN, then the shared-subexpression slots, spill slots last (allocated only if a program uses them)
-static constexpr int kV2Regs = 4, kV2LdsAcc = 0, kV2LdsInner = 1, kV2LdsCse0 = 2, kV2LdsCseMax = 8, kV2LdsSpills = 2;
+static constexpr int kV2Regs = 4, kV2LdsAcc = 0, kV2LdsInner = 1, kV2LdsCse0 = 2, kV2LdsCseMax = 8, kV2LdsSpills = 2, kV2LdsGlobalMax = 6;
 enum { SY_YPOW0 = 4096 /* + m: y^m */ };
 
 struct Program2 {
@@ -592,8 +592,17 @@ struct Compiler2 {
     // occupancy mattered more than the last 40 multiplications); the builtin kernels hold them in registers and have room
     // (130 -> 138 VGPRs of the 168 that three waves allow): 6 takes 41 more products out of the Board program (581 -> 540)
     int spill_used = 0, cse_slots = 6, max_lds = kV2LdsInner;
+    // Values shared ACROSS gate groups (the same sub-polynomial in several gates: Board 94, Shot 71 products that per-group slots
+    // recompute): up to `global_slots` more slots, each holding one value from the first to the last group that uses it; values
+    // with disjoint ranges share a slot (select_globals).
+    struct GlobalEnt {
+        int slot, first, last;
+    };
+    int global_slots = 6;   // Board 541 -> 475 products, Shot 398 -> 356 (2: 495 / 376; perfect sharing: 447 / 327); 138 -> 146 VGPRs
+    std::map<int, GlobalEnt> gsel;
     explicit Compiler2(const EPool& p) : pool(p), label(p.n.size(), -1) {
         if (const char* e = getenv("BZH_VM2_CSE")) cse_slots = std::max(0, std::min(kV2LdsCseMax, atoi(e)));
+        if (const char* e = getenv("BZH_VM2_GLOBAL")) global_slots = std::max(0, std::min(kV2LdsGlobalMax, atoi(e)));
     }
     int nlds() const { return max_lds + 1; }
 
@@ -727,11 +736,12 @@ struct Compiler2 {
         if (it == want.end() || cse.count(i)) return;
         op(V2_UN, V2_STORE, depth - 1, Leaf{BZH_EXPR_LDS, it->second, 0});
         cse[i] = it->second;
+        if (gsel.count(i)) gparked.insert(i);
         std::fill(label.begin(), label.end(), -1);   // nodes above it are cheaper to reach now
     }
     void count_uses(int i, std::map<int, int>& uses, std::map<int, int>& weight) {
         const ENode& e = pool.n[i];
-        if (e.tag == EX_CONST || e.tag == EX_SYMBOL || e.tag == EX_QUERY || hoisted.count(i)) return;
+        if (e.tag == EX_CONST || e.tag == EX_SYMBOL || e.tag == EX_QUERY || hoisted.count(i) || cse.count(i)) return;
         if (uses[i]++) return;
         int w = 1;
         if (e.a >= 0) {
@@ -744,15 +754,74 @@ struct Compiler2 {
         }
         weight[i] = w;
     }
-    void open_scope(const std::vector<int>& roots) {
+    // distinct operation nodes under i (`stop` and parked / hoisted values are leaves): products and other operations
+    void reach(int i, std::set<int>& seen, const std::set<int>& stop, int* products, int* others) const {
+        const ENode& e = pool.n[i];
+        if (e.tag == EX_CONST || e.tag == EX_SYMBOL || e.tag == EX_QUERY || hoisted.count(i) || stop.count(i)) return;
+        if (!seen.insert(i).second) return;
+        if (e.tag == EX_MUL || e.tag == EX_SCALE) ++*products;
+        else ++*others;
+        if (e.a >= 0) reach(e.a, seen, stop, products, others);
+        if (e.b >= 0) reach(e.b, seen, stop, products, others);
+    }
+    // choose the values kept across groups: greedily the best saving per group of residence that still finds a free slot
+    void select_globals(const std::vector<std::vector<int>>& group_roots) {
+        gsel.clear();
+        if (global_slots <= 0) return;
+        const int base = kV2LdsCse0 + cse_slots + kV2LdsSpills;
+        std::vector<std::vector<std::pair<int, int>>> busy((size_t)global_slots);
+        std::set<int> chosen;
+        for (int round = 0; round < 256; round++) {
+            std::map<int, std::vector<int>> where;
+            for (size_t gi = 0; gi < group_roots.size(); gi++) {
+                std::set<int> seen;
+                int p = 0, o = 0;
+                for (int r : group_roots[gi]) reach(r, seen, chosen, &p, &o);
+                for (int n : seen) where[n].push_back((int)gi);
+            }
+            double best_score = 0;
+            int best_n = -1, best_slot = -1;
+            for (auto& kv : where) {
+                if (kv.second.size() < 2) continue;
+                std::set<int> seen;
+                int p = 0, o = 0;
+                reach(kv.first, seen, chosen, &p, &o);
+                if (p == 0) continue;   // sums alone are cheaper to redo than to hold
+                const int first = kv.second.front(), last = kv.second.back();
+                int slot = -1;
+                for (int sl = 0; sl < global_slots && slot < 0; sl++) {
+                    bool free_ = true;
+                    for (auto& iv : busy[(size_t)sl]) free_ &= last < iv.first || first > iv.second;
+                    if (free_) slot = sl;
+                }
+                if (slot < 0) continue;
+                const double benefit = (double)(kv.second.size() - 1) * (200.0 * p + 25.0 * o) - 30.0;   // (- the store)
+                const double score = benefit / (double)(last - first + 1);
+                if (benefit > 0 && score > best_score) best_score = score, best_n = kv.first, best_slot = slot;
+            }
+            if (best_n < 0) break;
+            const std::vector<int>& gs = where[best_n];
+            gsel[best_n] = GlobalEnt{base + best_slot, gs.front(), gs.back()};
+            busy[(size_t)best_slot].push_back({gs.front(), gs.back()});
+            chosen.insert(best_n);
+            max_lds = std::max(max_lds, base + best_slot);
+        }
+    }
+    std::set<int> gparked;
+    void open_scope(const std::vector<int>& roots, int group = -1) {
         cse.clear();
         want.clear();
+        for (auto& kv : gsel) {   // values living across groups: parked ones are leaves here, the others are parked when first computed
+            if (group < kv.second.first || group > kv.second.last) continue;
+            if (gparked.count(kv.first)) cse[kv.first] = kv.second.slot;
+            else want[kv.first] = kv.second.slot;
+        }
         std::fill(label.begin(), label.end(), -1);
         std::map<int, int> uses, weight;
         for (int r : roots) count_uses(r, uses, weight);
         std::vector<std::pair<long, int>> cand;
         for (auto& kv : uses) {
-            if (kv.second >= 2) cand.push_back({-(long)(kv.second - 1) * weight[kv.first], kv.first});
+            if (kv.second >= 2 && !gsel.count(kv.first)) cand.push_back({-(long)(kv.second - 1) * weight[kv.first], kv.first});
         }
         std::sort(cand.begin(), cand.end());
         for (size_t k = 0; k < cand.size() && k < (size_t)cse_slots; k++) {
@@ -774,13 +843,57 @@ struct Compiler2 {
             if (s >= 0 && !groups.empty() && groups.back().s == s) groups.back().c.push_back(e.b);
             else groups.push_back(Group{s, {s >= 0 ? e.b : t}});
         }
+        if (getenv("BZH_VM2_DEBUG")) {   // how many products a perfect (unbounded) sharing across all groups would leave
+            std::map<int, int> uses, weight;
+            size_t horner = 0;
+            for (auto& g : groups) {
+                for (int r : g.c) count_uses(r, uses, weight);
+                if (g.s >= 0) count_uses(g.s, uses, weight);
+                horner += g.c.size() - 1 + (g.s >= 0 ? 1 : 0) + 1;
+            }
+            size_t uniq_mul = 0, shared = 0;
+            for (auto& kv : uses) {
+                const ENode& e = pool.n[kv.first];
+                if (e.tag == EX_MUL || e.tag == EX_SCALE) uniq_mul++;
+                if (kv.second >= 2) shared++;
+            }
+            {   // shared nodes: weight (products under them), the groups that use them
+                std::map<int, std::vector<int>> where;
+                for (size_t gi = 0; gi < groups.size(); gi++) {
+                    std::map<int, int> u2, w2;
+                    for (int r : groups[gi].c) count_uses(r, u2, w2);
+                    if (groups[gi].s >= 0) count_uses(groups[gi].s, u2, w2);
+                    for (auto& kv : u2) where[kv.first].push_back((int)gi);
+                }
+                for (auto& kv : uses) {
+                    if (kv.second < 2 || where[kv.first].size() < 2) continue;
+                    const ENode& e = pool.n[kv.first];
+                    fprintf(stderr, "[vm2-shared] node %d tag %d weight %d uses %d groups", kv.first, (int)e.tag, weight[kv.first], kv.second);
+                    for (int gi : where[kv.first]) fprintf(stderr, " %d", gi);
+                    fprintf(stderr, "\n");
+                }
+            }
+            fprintf(stderr, "[vm2] groups %zu, unique product nodes %zu, glue products (y powers, selectors, ACC) ~%zu, nodes used more than once %zu\n",
+                    groups.size(), uniq_mul, horner, shared);
+        }
         const Leaf y{BZH_EXPR_CONST, const_index(SY_Y, nullptr), 0};
         const Leaf acc{BZH_EXPR_LDS, kV2LdsAcc, 0}, inner{BZH_EXPR_LDS, kV2LdsInner, 0};
+        {
+            std::vector<std::vector<int>> group_roots;
+            for (auto& g : groups) {
+                group_roots.push_back(g.c);
+                if (g.s >= 0) group_roots.back().push_back(g.s);
+            }
+            gparked.clear();
+            select_globals(group_roots);
+        }
         bool first_group = true;
+        int group_index = -1;
         for (auto& g : groups) {
+            group_index++;
             std::vector<int> roots = g.c;
             if (g.s >= 0) roots.push_back(g.s);
-            open_scope(roots);
+            open_scope(roots, group_index);
             const size_t m = g.c.size();
             if (m > 64) prog.ok = false;   // y^m symbols are provided up to 64
             for (size_t j = 0; j < m; j++) {

@@ -20,8 +20,10 @@ SETTINGS = [
     {"BZH_ACC_THREADS": "512", "BZH_ACC_CHUNK": "4096"},
     {"BZH_QUOTIENT_V1": "1"},
     {"BZH_NO_HOIST": "1"},
-    {"BZH_VM2_CSE": "0"},
-    {"BZH_VM2_CSE": "6"},
+    {"BZH_VM2_CSE": "0"},                                   # (other slot counts = another program: no builtin kernel, the interpreter runs it)
+    {"BZH_VM2_CSE": "2"},
+    {"BZH_VM2_GLOBAL": "0"},                                # no values kept across gate groups
+    {"BZH_VM2_GLOBAL": "2", "BZH_VM2_CSE": "8"},
     {"BZH_QUOTIENT": "interp"},
     {"BZH_NTT_LDS": "1"},
     {"BZH_ACC_SATURATED": "1"},                             # bucket accumulation in saturated 8 x 32 limbs (default: unsaturated 9 x 29, csrc/fe29.cuh)
@@ -43,7 +45,7 @@ SETTINGS = [
 def _digest(extra):
     env = dict(os.environ)
     for k in ("BZH_MSM_GS", "BZH_ACC_THREADS", "BZH_ACC_CHUNK", "BZH_QUOTIENT_V1", "BZH_NO_HOIST", "BZH_VM2_CSE", "BZH_QUOTIENT", "BZH_NTT_LDS",
-              "BZH_IPA_COLLAPSE", "BZH_IPA_TAIL_C", "BZH_NO_COMMIT_SHIFT", "BZH_MSM_NO_QUAD", "BZH_ACC_NO_XCD_MAP", "BZH_ACC_SATURATED", "BZH_QUOTIENT_SATURATED", "BZH_RED_WG_MAX"):
+              "BZH_IPA_COLLAPSE", "BZH_IPA_TAIL_C", "BZH_NO_COMMIT_SHIFT", "BZH_MSM_NO_QUAD", "BZH_ACC_NO_XCD_MAP", "BZH_ACC_SATURATED", "BZH_QUOTIENT_SATURATED", "BZH_RED_WG_MAX", "BZH_VM2_GLOBAL"):
         env.pop(k, None)
     env.update(extra)
     out = subprocess.run([sys.executable, CASE], env=env, capture_output=True, text=True, timeout=600)
