@@ -128,6 +128,26 @@ BZH_HD Fe29<P> fe29_mul(const Fe29<P>& a, const Fe29<P>& b) {
     return r;
 }
 
+// (a * b + c * d + m * p) / 2^261: two products into the same columns, ONE Montgomery pass (162 + 45 multiply-adds instead of
+// 2 x 126).  Inputs: limb products A * B + C * D <= 1.8e18 in all (a column then stays below 2^64) and a b + c d < 2^515; output as
+// fe29_mul's.  The quotient kernels' y-power glue -- ACC y^m + S inner, IN y + C -- is made of these.
+template <class P>
+BZH_HD Fe29<P> fe29_dot2(const Fe29<P>& a, const Fe29<P>& b, const Fe29<P>& c, const Fe29<P>& d) {
+    static_assert(fe29_supported<P>(), "fe29: unsupported modulus");
+    uint64_t col[17];
+#pragma unroll
+    for (int k = 0; k < 17; k++) {
+        col[k] = k < 9 ? (uint64_t)kM29 : 0;
+#pragma unroll
+        for (int j = (k > 8 ? k - 8 : 0); j <= (k < 8 ? k : 8); j++) col[k] += (uint64_t)a.l[j] * b.l[k - j];
+#pragma unroll
+        for (int j = (k > 8 ? k - 8 : 0); j <= (k < 8 ? k : 8); j++) col[k] += (uint64_t)c.l[j] * d.l[k - j];
+    }
+    Fe29<P> r;
+    fe29_montgomery_pass<P>(col, r);
+    return r;
+}
+
 template <class P>
 BZH_HD Fe29<P> fe29_sqr(const Fe29<P>& a) {
     static_assert(fe29_supported<P>(), "fe29: unsupported modulus");
@@ -464,6 +484,16 @@ __device__ __forceinline__ Fe29<P> fe29_load_planes_g(fe29_gbytes col, uint32_t 
     r.l[0] = a.x, r.l[1] = a.y, r.l[2] = a.z, r.l[3] = a.w;
     r.l[4] = b.x, r.l[5] = b.y, r.l[6] = b.z, r.l[7] = b.w;
     r.l[8] = *(const uint32_t BZH_AS1*)(col + 32 * size + off4);
+    return r;
+}
+// a per-proof constant through a global-address-space pointer (for a callee that fetches its own operand)
+template <class P>
+__device__ __forceinline__ Fe29<P> fe29_load_const_g(fe29_gbytes p) {
+    const fe29_u32x4 a = *(const fe29_u32x4 BZH_AS1*)p, b = *(const fe29_u32x4 BZH_AS1*)(p + 16);
+    Fe29<P> r;
+    r.l[0] = a.x, r.l[1] = a.y, r.l[2] = a.z, r.l[3] = a.w;
+    r.l[4] = b.x, r.l[5] = b.y, r.l[6] = b.z, r.l[7] = b.w;
+    r.l[8] = *(const uint32_t BZH_AS1*)(p + 32);
     return r;
 }
 // An Fe29 across a CALL: a 36-byte struct goes through scratch memory (byval / sret), a 9-lane vector travels in VGPRs.

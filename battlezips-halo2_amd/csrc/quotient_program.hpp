@@ -378,7 +378,14 @@ static std::string program2_source29_policy(const Program2& pg, int field, bool 
     // (out of line like the saturated flavour's, for the instruction cache; operands as 9-lane vectors: a 36-byte struct would
     // cross the call through scratch memory)
     src += "__device__ __noinline__ fe29_vec mulv(fe29_vec a, fe29_vec b) { return fe29_pack_vec(fe29_mul(fe29_unpack_vec<P>(a), fe29_unpack_vec<P>(b))); }\n"
-           "__device__ __forceinline__ Fe29<P> mulx(const Fe29<P>& a, const Fe29<P>& b) { return fe29_unpack_vec<P>(mulv(fe29_pack_vec(a), fe29_pack_vec(b))); }\n";
+           "__device__ __forceinline__ Fe29<P> mulx(const Fe29<P>& a, const Fe29<P>& b) { return fe29_unpack_vec<P>(mulv(fe29_pack_vec(a), fe29_pack_vec(b))); }\n"
+           // a b + c d with ONE reduction; d is a per-proof constant the callee fetches itself (four 9-lane operands would not fit the
+           // 32 argument registers), first thing, so that the a b multiply-adds cover the load
+           "__device__ __noinline__ fe29_vec dot2v(fe29_vec a, fe29_vec b, fe29_vec c, fe29_gbytes d) {\n"
+           "    const Fe29<P> dd = fe29_load_const_g<P>(d);\n"
+           "    return fe29_pack_vec(fe29_dot2(fe29_unpack_vec<P>(a), fe29_unpack_vec<P>(b), fe29_unpack_vec<P>(c), dd));\n}\n"
+           "__device__ __forceinline__ Fe29<P> dot2x(const Fe29<P>& a, const Fe29<P>& b, const Fe29<P>& c, const uint32_t* d) {\n"
+           "    return fe29_unpack_vec<P>(dot2v(fe29_pack_vec(a), fe29_pack_vec(b), fe29_pack_vec(c), (fe29_gbytes)d));\n}\n";
     // (132 VGPRs, three waves per SIMD: forcing four with amdgpu_waves_per_eu(4, 4) -- 128 VGPRs, 3 spilled -- measured slower,
     // 34.2 against 33.4 ms per batch of 64)
     // A scheduling barrier after every operation keeps the compiler from hoisting the column loads of the whole program to its top.
@@ -417,8 +424,59 @@ static std::string program2_source29_policy(const Program2& pg, int field, bool 
         else if (kind == BZH_EXPR_CONST)
             add("    const Fe29<P> %s%zu = fe29_load_const<P>(cv + %d * 12);\n", name, i, idx);
     };
+    // ---- fused pairs: X = (product) ; Y = slot * constant ; X + Y  ->  one dot2 with one reduction.  Two shapes come out of
+    //      Compiler2::quotient: [rP = a * b] [rP+1 = ACC * y^m] [rP += rP+1] (adjacent), and Horner's [rP = IN * y] ... [rP+1 = a * b]
+    //      [rP += rP+1] (the first product is deferred to the second: its operands are a slot nothing stores to in between and a constant).
+    struct Fuse {
+        int slot = -1, cst = -1, dst = -1;   // at the surviving product: the other product's slot and constant, the register that gets the sum
+    };
+    std::vector<Fuse> fuse(nops);
+    std::vector<char> skip(nops, 0);
+    static const bool no_dot2 = getenv("BZH_QUOTIENT29_NO_DOT2") != nullptr;
+    {
+        auto fm = [&](size_t i) { return pg.ops[i].code >> 4; };
+        auto opc = [&](size_t i) { return (pg.ops[i].code >> 2) & 3; };
+        auto ps = [&](size_t i) { return pg.ops[i].code & 3; };
+        auto is_mul = [&](size_t i) { return fm(i) != V2_UN && opc(i) == V2_MUL; };
+        auto slot_times_const = [&](size_t i) {
+            return is_mul(i) && fm(i) == V2_LL && pg.ops[i].a_kind == BZH_EXPR_LDS && pg.ops[i].b_kind == BZH_EXPR_CONST;
+        };
+        auto reads = [&](size_t i, int p) {
+            if (fm(i) == V2_SS) return ps(i) == p || ps(i) + 1 == p;
+            if (fm(i) == V2_SL) return ps(i) == p;
+            if (fm(i) == V2_UN) return opc(i) != V2_LOAD && ps(i) == p;
+            return false;
+        };
+        auto writes = [&](size_t i, int p) { return !(fm(i) == V2_UN && opc(i) == V2_STORE) && ps(i) == p; };
+        for (size_t k = 2; k < nops && !no_dot2; k++) {
+            if (!(fm(k) == V2_SS && opc(k) == V2_ADD) || skip[k]) continue;
+            const int P = ps(k);
+            if (skip[k - 1] || skip[k - 2] || fuse[k - 1].dst >= 0 || fuse[k - 2].dst >= 0) continue;
+            if (slot_times_const(k - 1) && ps(k - 1) == P + 1 && is_mul(k - 2) && ps(k - 2) == P) {   // adjacent
+                fuse[k - 2] = Fuse{pg.ops[k - 1].a_idx, pg.ops[k - 1].b_idx, P};
+                skip[k - 1] = skip[k] = 1;
+                continue;
+            }
+            if (!(is_mul(k - 1) && ps(k - 1) == P + 1)) continue;
+            size_t j = k - 1;
+            bool ok = false;
+            while (j-- > 0) {   // the last writer of rP before the second product
+                if (writes(j, P)) {
+                    ok = slot_times_const(j) && !skip[j] && fuse[j].dst < 0;
+                    break;
+                }
+                if (reads(j, P)) break;
+            }
+            if (!ok) continue;
+            for (size_t x = j + 1; x < k && ok; x++)   // its slot operand must still hold the same value
+                ok = !(fm(x) == V2_UN && opc(x) == V2_STORE && pg.ops[x].a_idx == pg.ops[j].a_idx);
+            if (!ok) continue;
+            fuse[k - 1] = Fuse{pg.ops[j].a_idx, pg.ops[j].b_idx, P};
+            skip[j] = skip[k] = 1;
+        }
+    }
     auto emit_loads = [&](size_t i) {
-        if (i >= nops) return;
+        if (i >= nops || skip[i]) return;   // (a skipped product's operands are a slot and a constant the callee fetches)
         const ExprOp2& o = pg.ops[i];
         const int form = o.code >> 4, op = (o.code >> 2) & 3;
         if (form == V2_LL || (form == V2_UN && op == V2_LOAD)) emit_load("la", i, o.a_kind, o.a_idx, o.a_rot);
@@ -534,13 +592,51 @@ static std::string program2_source29_policy(const Program2& pg, int field, bool 
         add("    %s = fe29_sub_lazy<P, %d, %d>(%s, %s);\n", dst.c_str(), K, J, a.name.c_str(), b.name.c_str());
         return diff;
     };
+    // dst = a * b + slot * constant (one reduction)
+    auto dot2 = [&](const std::string& dst, Val a, Val b, const Fuse& f) -> Bnd {
+        char sn[32];
+        snprintf(sn, sizeof(sn), "s%d", f.slot);
+        Val c{sn, bs[(size_t)f.slot], false};
+        const bool same = !a.mem && !b.mem && a.name == b.name;
+        auto sync = [&](Val& from, Val& to) {
+            if (same) to.b = from.b;
+        };
+        // (the constant: carried, below 2 p)
+        for (int pass = 0; pass < 4 && a.b.V * b.b.V + c.b.V * 2.0 > 100.0; pass++) {
+            if (c.b.V * 2.0 >= a.b.V * b.b.V) fold(c);
+            else if (a.b.V >= b.b.V) fold(a), sync(a, b);
+            else fold(b), sync(b, a);
+        }
+        // one column holds 9 terms of each product: A B + C D <= kColumn (the constant's limbs: carried)
+        if (limb_max(c.b) * (double)kCarried > 0.5 * kColumn) carry(c);
+        if (a.name == c.name) a.b = c.b;
+        if (b.name == c.name) b.b = c.b;
+        const double room = kColumn - limb_max(c.b) * (double)kCarried;
+        for (int pass = 0; pass < 2 && limb_max(a.b) * limb_max(b.b) > room; pass++) {
+            if (a.b.L >= b.b.L) carry(a), sync(a, b);
+            else carry(b), sync(b, a);
+        }
+        if (a.b.V * b.b.V + c.b.V * 2.0 > 100.0 || limb_max(a.b) * limb_max(b.b) > room || limb_max(c.b) * (double)kCarried > 0.5 * kColumn)
+            pg_fail = true;
+        add("    %s = dot2x(%s, %s, %s, cv + %d * 12);\n", dst.c_str(), a.name.c_str(), b.name.c_str(), c.name.c_str(), f.cst);
+        return product;
+    };
     static const char* const regs[4] = {"r0", "r1", "r2", "r3"};
     emit_loads(0);
     for (size_t i = 0; i < nops; i++) {
         const ExprOp2& o = pg.ops[i];
         const int form = o.code >> 4, op = (o.code >> 2) & 3, pos = o.code & 3;
         emit_loads(i + 1);
+        if (skip[i]) continue;
         const std::string ra = regs[pos];
+        if (fuse[i].dst >= 0) {   // this product and a skipped slot * constant one, summed
+            const std::string rd = regs[fuse[i].dst];
+            const Val a = form == V2_LL ? operand("la", i, o.a_kind, o.a_idx) : Val{ra, br[pos], false};
+            const Val b = form == V2_SS ? Val{regs[(pos + 1) & 3], br[(pos + 1) & 3], false} : operand("lb", i, o.b_kind, o.b_idx);
+            br[fuse[i].dst] = dot2(rd, a, b, fuse[i]);
+            if (barriers) src += "    __builtin_amdgcn_sched_barrier(0);\n";
+            continue;
+        }
         if (form == V2_SS) {
             br[pos] = arith(op, ra, Val{ra, br[pos], false}, Val{regs[(pos + 1) & 3], br[(pos + 1) & 3], false});
         } else if (form == V2_SL) {

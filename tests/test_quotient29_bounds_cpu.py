@@ -6,6 +6,7 @@ statement with exact integers, one bound PER LIMB (the emitter keeps two numbers
 modulus here, and checks the preconditions of every operation as csrc/fe29.cuh states them:
   mulx        every column of the 9 x 9 schoolbook product, with its reduction terms and carry, stays below 2^64;
               the operands' values multiply to less than 2^515 (the Montgomery result is then below 2 p)
+  dot2x       a b + c d into the same columns with one reduction: the same two conditions on the sums
   fe29_add    no limb passes 2^32
   sub_lazy    J copies of the (K / J) p bias dominate the subtrahend limb by limb; no limb of the result passes 2^32
   fe29_carry  (any input); fe29_fold: carried input, value below 128 p
@@ -102,6 +103,22 @@ def check_program(text, p):
             env[m.group(1)] = Val([M29] * 8 + [1 << 23], 2.0)
             stats["mul"] += 1
             continue
+        m = re.match(r"(%s) = dot2x\((%s), (%s), (%s), cv \+ \d+ \* 12\);" % (ident, ident, ident, ident), ln)
+        if m:   # a b + c d with one reduction, d a per-proof constant (carried, below 2 p)
+            a, b, c, d = env[m.group(2)], env[m.group(3)], env[m.group(4)], LEAF
+            assert a.V * b.V + c.V * d.V <= 128.0, ln
+            run = 0
+            for k in range(17):
+                col = M29 if k < 9 else 0
+                col += sum(a.L[j] * b.L[k - j] + c.L[j] * d.L[k - j] for j in range(max(0, k - 8), min(k, 8) + 1))
+                col += sum(M29 * plimbs[l] for l in (1, 2, 3, 4, 8) if 0 <= k - l < 9)
+                col += run
+                assert col < (1 << 64), (ln, k)
+                run = col >> 29
+            env[m.group(1)] = Val([M29] * 8 + [1 << 23], 2.0)
+            stats["mul"] += 2
+            stats["dot2"] = stats.get("dot2", 0) + 1
+            continue
         m = re.match(r"(%s) = fe29_add\((%s), (%s)\);" % (ident, ident, ident), ln)
         if m:
             a, b = env[m.group(2)], env[m.group(3)]
@@ -175,7 +192,7 @@ def test_every_operation_of_the_unsaturated_quotient_kernel_is_inside_its_bounds
     stats = check_program(text[text.index(ns):], P_FP)
     # the circuits' known sizes: 475 / 356 products with the default six per-group and six cross-group shared-subexpression slots; far fewer carry passes than additions + subtractions
     assert stats["mul"] == (475 if kind_name == "BoardCircuit" else 356), stats
-    assert stats["carry"] < (stats["add"] + stats["sub"]) // 2, stats
+    assert stats["carry"] < (stats["add"] + stats["sub"]) // 2 and stats["dot2"] >= 40, stats
 
 
 def test_the_checker_rejects_a_missing_carry_pass():
