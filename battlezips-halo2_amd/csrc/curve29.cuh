@@ -1,6 +1,6 @@
 // The bucket accumulator of k_msm_accumulate in unsaturated limbs (csrc/fe29.cuh): XYZZ mixed addition with the running sum
 // held as 4 x 9 limbs of 29 bits in R' = 2^261 Montgomery form, NOT canonical -- invariants after every operation:
-//     x < 11.5 p, y < 7.5 p, zz < 2 p, zzz < 2 p, every limb carried (< 2^29 + 8), identity kept as a flag.
+//     x < 11.5 p, y < 3.7 p (anything below 8 p is accepted), zz < 2 p, zzz < 2 p, every limb carried (< 2^29 + 8), identity kept as a flag.
 // The table points arrive in the saturated 2^256 form every other kernel uses and are re-sliced on the fly (x 2^5 = the R' form,
 // ~25 shifts per coordinate); a finished bucket goes back through one product per coordinate (fe29_to_sat).  Same group element
 // as curve.cuh's xyzz_madd computes, hence the same MSM result and the same proof bytes.
@@ -143,8 +143,9 @@ BZH_HD void xyzz29_madd_q29(Xyzz29<P>& acc, const Fe29<P>& qx, const Fe29<P>& qy
     const Fe29<P> ppp = fe29_mul(pp_, pp);                   // < 2 p
     const Fe29<P> qq = fe29_mul(acc.x, pp);                  // < 2 p
     const Fe29<P> x3 = fe29_sub3<P, 4>(fe29_sqr(r), ppp, qq);   // R^2 - PPP - 2 Q + 8 p < 11.5 p
-    const Fe29<P> t = fe29_mul(acc.y, ppp);                  // < 2 p
-    acc.y = fe29_sub<P, 4>(fe29_mul(r, fe29_sub<P, 16>(qq, x3)), t);   // < 3.5 p + 4 p
+    // Y3 = R (Q - X3) - Y1 PPP as ONE reduction: (8 p - Y1) PPP differs from -Y1 PPP by a multiple of p, so both products go into
+    // the same columns (fe29_dot2; limb products 2.9e17 + 8.7e17 of the 1.8e18 a column holds; 324 p^2 + 16 p^2: below 3.7 p)
+    acc.y = fe29_dot2(r, fe29_sub<P, 16>(qq, x3), fe29_sub_lazy<P, 8, 1>(fe29_zero<P>(), acc.y), ppp);
     acc.x = x3;
     acc.zz = fe29_mul(acc.zz, pp);
     acc.zzz = fe29_mul(acc.zzz, ppp);
@@ -156,7 +157,7 @@ BZH_HD void xyzz29_madd(Xyzz29<P>& acc, const Affine<P>& q, const Fe29Consts<P>&
 }
 
 // ---- full additions and doublings in unsaturated limbs (the bucket reductions) -----------------------------------------
-// invariants in and out: x < 11.5 p, y < 7.5 p, zz, zzz < 2 p, limbs carried
+// invariants in and out: x < 11.5 p, y < 3.7 p (7.5 p accepted), zz, zzz < 2 p, limbs carried
 // 2 p: dbl-2008-s-1 (a = 0).  y and x are folded below 2 p first: (2 y)^2 and x^2 would leave the product's input range.
 template <class P>
 BZH_HD Xyzz29<P> xyzz29_dbl(const Xyzz29<P>& p) {
@@ -170,7 +171,7 @@ BZH_HD Xyzz29<P> xyzz29_dbl(const Xyzz29<P>& p) {
     const Fe29<P> m = fe29_add_c(fe29_add_c(xx, xx), xx);      // < 6 p
     Xyzz29<P> r;
     r.x = fe29_sub3<P, 4>(fe29_sqr(m), fe29_zero<P>(), s);     // M^2 - 2 S + 8 p < 10 p
-    r.y = fe29_sub<P, 4>(fe29_mul(m, fe29_sub<P, 16>(s, r.x)), fe29_mul(w, yf));
+    r.y = fe29_dot2(m, fe29_sub<P, 16>(s, r.x), fe29_sub_lazy<P, 4, 1>(fe29_zero<P>(), yf), w);   // M (S - X3) - W Y, one reduction
     r.zz = fe29_mul(v, p.zz);
     r.zzz = fe29_mul(w, p.zzz);
     r.id = false;
@@ -210,7 +211,7 @@ BZH_HD void xyzz29_add(Xyzz29<P>& acc, const Xyzz29<P>& q) {
     }
     const Fe29<P> pp = fe29_sqr(pp_), ppp = fe29_mul(pp_, pp), qq = fe29_mul(u1, pp);
     const Fe29<P> x3 = fe29_sub3<P, 4>(fe29_sqr(r), ppp, qq);                  // < 10 p
-    acc.y = fe29_sub<P, 4>(fe29_mul(r, fe29_sub<P, 16>(qq, x3)), fe29_mul(s1, ppp));
+    acc.y = fe29_dot2(r, fe29_sub<P, 16>(qq, x3), fe29_sub_lazy<P, 4, 1>(fe29_zero<P>(), s1), ppp);   // R (Q - X3) - S1 PPP, one reduction
     acc.x = x3;
     acc.zz = fe29_mul(fe29_mul(acc.zz, q.zz), pp);
     acc.zzz = fe29_mul(fe29_mul(acc.zzz, q.zzz), ppp);
@@ -248,7 +249,7 @@ BZH_HD void xyzz29_add_nocall(Xyzz29<P>& acc, const Xyzz29<P>& q) {
     }
     const Fe29<P> pp = fe29_sqr(pp_), ppp = fe29_mul(pp_, pp), qq = fe29_mul(u1, pp);
     const Fe29<P> x3 = fe29_sub3<P, 4>(fe29_sqr(r), ppp, qq);
-    acc.y = fe29_sub<P, 4>(fe29_mul(r, fe29_sub<P, 16>(qq, x3)), fe29_mul(s1, ppp));
+    acc.y = fe29_dot2(r, fe29_sub<P, 16>(qq, x3), fe29_sub_lazy<P, 4, 1>(fe29_zero<P>(), s1), ppp);   // R (Q - X3) - S1 PPP, one reduction
     acc.x = x3;
     acc.zz = fe29_mul(fe29_mul(acc.zz, q.zz), pp);
     acc.zzz = fe29_mul(fe29_mul(acc.zzz, q.zzz), ppp);
