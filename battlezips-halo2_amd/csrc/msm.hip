@@ -1943,7 +1943,7 @@ __global__ void __launch_bounds__(256) k_collapse_generators(const uint32_t* __r
 // one thread per point walks the rows in XYZZ (c doublings each, parked in `scratch` with the running product of the zzz
 // coordinates), inverts that product ONCE and walks back handing every row its own inverse (Montgomery's trick along the
 // rows of a point: no cross-lane traffic), where 1 / zz = (1 / zzz)^2 * zz^2.
-template <class C>
+template <class C, bool U>
 __global__ void __launch_bounds__(256) k_expand_rows_shared_inverse(uint32_t* __restrict__ table, size_t npts, int c, int nwin,
                                                                       uint4* __restrict__ scratch) {
     using P = typename C::Base;
@@ -1970,18 +1970,42 @@ __global__ void __launch_bounds__(256) k_expand_rows_shared_inverse(uint32_t* __
         v.l[0] = a.x, v.l[1] = a.y, v.l[2] = a.z, v.l[3] = a.w, v.l[4] = b.x, v.l[5] = b.y, v.l[6] = b.z, v.l[7] = b.w;
         return v;
     };
-    Xyzz<P> q = xyzz_dbl_affine(p0);
     Fe<P> prefix = fe_one<P>();
-    for (int w = 1; w < nwin; w++) {
-        if (w > 1) q = xyzz_dbl(q);
-        for (int k = 1; k < c; k++) q = xyzz_dbl(q);
-        const size_t slot = (size_t)(w - 1) * npts + i;
-        put(4, slot, prefix);   // product of the zzz of the rows before this one
-        prefix = fe_mul(prefix, q.zzz);
-        put(0, slot, q.x);
-        put(1, slot, q.y);
-        put(2, slot, q.zz);
-        put(3, slot, q.zzz);
+    if constexpr (U) {
+        // the chain of c (nwin - 1) doublings in unsaturated limbs (xyzz29_dbl: products of 188 instructions, Y3 one fused reduction);
+        // a row's coordinates go back to the saturated form as they are parked (the normalisation below multiplies saturated)
+        Xyzz29<P> q29;
+        {
+            const Xyzz<P> q1 = xyzz_dbl_affine(p0);
+            q29.x = fe29_from_sat_reduced(q1.x), q29.y = fe29_from_sat_reduced(q1.y);
+            q29.zz = fe29_from_sat_reduced(q1.zz), q29.zzz = fe29_from_sat_reduced(q1.zzz);
+            q29.id = false;
+        }
+        for (int w = 1; w < nwin; w++) {
+            if (w > 1) q29 = xyzz29_dbl(q29);
+            for (int k = 1; k < c; k++) q29 = xyzz29_dbl(q29);
+            const Xyzz<P> q = xyzz29_to_sat_fast(q29);
+            const size_t slot = (size_t)(w - 1) * npts + i;
+            put(4, slot, prefix);   // product of the zzz of the rows before this one
+            prefix = fe_mul(prefix, q.zzz);
+            put(0, slot, q.x);
+            put(1, slot, q.y);
+            put(2, slot, q.zz);
+            put(3, slot, q.zzz);
+        }
+    } else {
+        Xyzz<P> q = xyzz_dbl_affine(p0);
+        for (int w = 1; w < nwin; w++) {
+            if (w > 1) q = xyzz_dbl(q);
+            for (int k = 1; k < c; k++) q = xyzz_dbl(q);
+            const size_t slot = (size_t)(w - 1) * npts + i;
+            put(4, slot, prefix);   // product of the zzz of the rows before this one
+            prefix = fe_mul(prefix, q.zzz);
+            put(0, slot, q.x);
+            put(1, slot, q.y);
+            put(2, slot, q.zz);
+            put(3, slot, q.zzz);
+        }
     }
     Fe<P> inv = fe_inv(prefix);
     for (int w = nwin - 1; w >= 1; w--) {
@@ -2028,7 +2052,12 @@ static int msm_collapse_table_t(bzh_ctx* ctx, const bzh_bases* srs, const uint32
         hipLaunchKernelGGL((k_collapse_generators<C>), dim3((unsigned)((m + 255) / 256), (unsigned)batch), dim3(256), lds, ctx->stream,
                            srs->d_xy, srs->row_stride ? srs->row_stride : srs->n, c, nwin, (const uint16_t*)d_digits, cnt, m, n, d_table,
                            cols, ctx->profiling ? ctx->d_add_counter : nullptr);
-        hipLaunchKernelGGL((k_expand_rows_shared_inverse<C>), dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, ctx->stream, d_table, npts,
+        static const bool rows_sat = getenv("BZH_ACC_SATURATED") != nullptr;
+        if (fe29_supported<typename C::Base>() && !rows_sat)
+            hipLaunchKernelGGL((k_expand_rows_shared_inverse<C, fe29_supported<typename C::Base>()>), dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, ctx->stream, d_table, npts,
+                           c_tail, nwin_t, (uint4*)d_scratch);
+        else
+            hipLaunchKernelGGL((k_expand_rows_shared_inverse<C, false>), dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, ctx->stream, d_table, npts,
                            c_tail, nwin_t, (uint4*)d_scratch);
     }
     BZH_HIP_TRY(ctx, hipGetLastError());

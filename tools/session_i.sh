@@ -5,7 +5,7 @@ mkdir -p $O
 cd $R
 timeout -k 10 900 python3 -m pytest tests/test_gpu_msm.py tests/test_gpu_ipa.py tests/test_gpu_real_circuit_parity.py -x -q -k "not 17" > $O/tests.log 2>&1 || { tail -30 $O/tests.log; exit 1; }
 tail -2 $O/tests.log
-timeout -k 10 600 python3 -m pytest tests/test_gpu_env_paths.py -x -q -k "ACC_SATURATED or NO_QUAD or ACC_THREADS" > $O/tests_env.log 2>&1 || { tail -30 $O/tests_env.log; exit 1; }
+timeout -k 10 600 python3 -m pytest tests/test_gpu_env_paths.py -x -q -k "ACC_SATURATED or NO_QUAD or ACC_THREADS or COLLAPSE" > $O/tests_env.log 2>&1 || { tail -30 $O/tests_env.log; exit 1; }
 tail -2 $O/tests_env.log
 cd /tmp && export TMPDIR=/tmp
 for v in u29 sat; do
@@ -17,7 +17,7 @@ for v in u29 sat; do
 import csv
 rows=list(csv.DictReader(open("$O/b64c1_${v}_kernel_stats.csv")))
 tot=sum(int(r["TotalDurationNs"]) for r in rows)
-sel=[r for r in rows if any(x in r["Name"] for x in ("chunksum","k_msm_accumulate","reduce_quad"))]
+sel=[r for r in rows if any(x in r["Name"] for x in ("chunksum","k_msm_accumulate","reduce_quad","expand_rows","collapse"))]
 print("$v", [(r["Name"][:34], round(int(r["TotalDurationNs"])/7e6,2)) for r in sel], "total", round(tot/7e6,1))
 P
   python3 $R/bench.py --no-cpu-baseline --other-workloads none --steps 10 --warmup 3 > $O/default_$v.json 2>/dev/null
