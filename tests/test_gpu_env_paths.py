@@ -38,6 +38,7 @@ SETTINGS = [
     {"BZH_IPA_COLLAPSE": "1"},                              # forced at round 1, also for the 2-proof batch
     {"BZH_IPA_COLLAPSE": "3", "BZH_IPA_TAIL_C": "7"},
     {"BZH_IPA_COLLAPSE": "6", "BZH_IPA_TAIL_C": "11"},
+    {"BZH_IPA_COLLAPSE": "3", "BZH_IPA_TAIL_C": "7", "BZH_ACC_SATURATED": "1"},   # the collapse's table expansion in saturated limbs
     {"BZH_IPA_COLLAPSE": "9", "BZH_IPA_TAIL_C": "5"},      # m = 4 folded generators
 ]
 
