@@ -1825,7 +1825,8 @@ int bases_to_montgomery(bzh_ctx* ctx, int curve, uint32_t* d_xy, size_t n) {
 // only, so they are wave-uniform, and a wave's table reads are 64 consecutive points.
 // ---------------------------------------------------------------------------
 template <class C>
-__global__ void __launch_bounds__(256) k_collapse_generators(const uint32_t* __restrict__ table, size_t row_stride, int c, int nwin,
+__global__ void __launch_bounds__(256) k_collapse_generators(const uint32_t* __restrict__ table, const uint32_t* __restrict__ table29,
+                                                               size_t row_stride, int c, int nwin,
                                                                const uint16_t* __restrict__ digits, size_t cnt, size_t m, size_t n_srs,
                                                                uint32_t* __restrict__ out, size_t out_cols,
                                                                unsigned long long* __restrict__ add_counter) {
@@ -1896,13 +1897,44 @@ __global__ void __launch_bounds__(256) k_collapse_generators(const uint32_t* __r
                     if constexpr (fe29_supported<P>()) {
                         const Fe29Consts<P> k29 = fe29_consts<P>();
                         Xyzz29<P> acc29 = xyzz29_identity<P>();
-                        for (uint32_t e = lo; e < hi; e++) {
-                            const uint32_t ent = ls[e], tw = ent & 0x7fffffffu;
-                            const uint32_t t = tw / (uint32_t)nwin, w = tw - t * (uint32_t)nwin;
-                            Affine<P> q = affine_load<P>(table + ((size_t)w * row_stride + (size_t)t * m + i) * 16);
-                            if (!aff_is_id(q)) {
-                                if (ent >> 31) q.y = fe_neg(q.y);
-                                xyzz29_madd(acc29, q, k29);
+                        if (table29) {
+                            // operands from the SRS table's fe29 copy (20 words per point, as k_msm_accumulate reads them), the
+                            // next item's gather in flight while this one is added
+                            auto load29 = [&](uint32_t ent, Fe29<P>& x, Fe29<P>& y) {
+                                const uint32_t tw = ent & 0x7fffffffu, t = tw / (uint32_t)nwin, w = tw - t * (uint32_t)nwin;
+                                const uint4* q = reinterpret_cast<const uint4*>(table29 + ((size_t)w * row_stride + (size_t)t * m + i) * 20);
+                                const uint4 a = q[0], bb = q[1], cc = q[2], d = q[3], f = q[4];
+                                x.l[0] = a.x, x.l[1] = a.y, x.l[2] = a.z, x.l[3] = a.w, x.l[4] = bb.x, x.l[5] = bb.y, x.l[6] = bb.z, x.l[7] = bb.w, x.l[8] = cc.x;
+                                y.l[0] = cc.y, y.l[1] = cc.z, y.l[2] = cc.w, y.l[3] = d.x, y.l[4] = d.y, y.l[5] = d.z, y.l[6] = d.w, y.l[7] = f.x, y.l[8] = f.y;
+                            };
+                            uint32_t ent_next = ls[lo];
+                            Fe29<P> x_next, y_next;
+                            load29(ent_next, x_next, y_next);
+                            for (uint32_t e = lo; e < hi; e++) {
+                                const uint32_t ent = ent_next;
+                                const Fe29<P> qx = x_next;
+                                Fe29<P> qy = y_next;
+                                if (e + 1 < hi) {
+                                    ent_next = ls[e + 1];
+                                    load29(ent_next, x_next, y_next);
+                                }
+                                uint32_t any = 0;   // the identity is stored as zeros
+#pragma unroll
+                                for (int j = 0; j < 9; j++) any |= qx.l[j] | qy.l[j];
+                                if (any) {
+                                    if (ent >> 31) qy = fe29_sub<P, 4>(fe29_zero<P>(), qy);
+                                    xyzz29_madd_q29(acc29, qx, qy, k29);
+                                }
+                            }
+                        } else {
+                            for (uint32_t e = lo; e < hi; e++) {
+                                const uint32_t ent = ls[e], tw = ent & 0x7fffffffu;
+                                const uint32_t t = tw / (uint32_t)nwin, w = tw - t * (uint32_t)nwin;
+                                Affine<P> q = affine_load<P>(table + ((size_t)w * row_stride + (size_t)t * m + i) * 16);
+                                if (!aff_is_id(q)) {
+                                    if (ent >> 31) q.y = fe_neg(q.y);
+                                    xyzz29_madd(acc29, q, k29);
+                                }
                             }
                         }
                         acc = xyzz29_to_sat_fast(acc29);
@@ -2050,7 +2082,8 @@ static int msm_collapse_table_t(bzh_ctx* ctx, const bzh_bases* srs, const uint32
         const size_t lds = ((size_t)4 * LV + 2 * cnt * (size_t)nwin) * 4;
         if (lds > 60 * 1024) return BZH_E_RANGE;
         hipLaunchKernelGGL((k_collapse_generators<C>), dim3((unsigned)((m + 255) / 256), (unsigned)batch), dim3(256), lds, ctx->stream,
-                           srs->d_xy, srs->row_stride ? srs->row_stride : srs->n, c, nwin, (const uint16_t*)d_digits, cnt, m, n, d_table,
+                           srs->d_xy, (!srs->row_stride || srs->row_stride == srs->n) ? srs->d_xy29 : (const uint32_t*)nullptr,   // (the copy has rows of n points)
+                           srs->row_stride ? srs->row_stride : srs->n, c, nwin, (const uint16_t*)d_digits, cnt, m, n, d_table,
                            cols, ctx->profiling ? ctx->d_add_counter : nullptr);
         static const bool rows_sat = getenv("BZH_ACC_SATURATED") != nullptr;
         if (fe29_supported<typename C::Base>() && !rows_sat)
